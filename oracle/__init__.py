@@ -1,0 +1,25 @@
+"""oracle/ -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (pure PyTorch-CPU + numpy/scipy) of the PointNet2 hot path of
+IGNF/StrataNet2-Vegetation-Coverage-Maps: `model/point_net2.py` (SA / FP stacks, head) and
+`model/project_to_2d.py` (max-projection rasters), plus the third-party primitives those files call
+(torch-cluster 1.5.9 `fps`/`radius`/`knn`, torch-geometric 1.7.2 `PointConv`/`knn_interpolate`/
+`global_max_pool`, torch-scatter 2.0.7 `scatter_max`/`scatter_mean`; pins:
+`setup_environment/torch_extensions.txt:1-3`), none of which are installed here.
+
+Who may import this package: `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg --
+as the checker / the timed CPU baseline, never as the product path.  The product
+(`stratanet2_vegetation_coverage_maps_amd`) never imports it and fails loudly without its HIP library.
+
+Parity status
+-------------
+* Reference glue (`PointNet2.forward`, `SAModule`, `GlobalSAModule`, `FPModule`, `MLP`,
+  `project_to_plotwise_coverages`, `project_to_2d_rasters`, `loss_functions`): PINNED -- the goldens under
+  `tests/golden/` were produced by `oracle/make_golden.py`, which imports that code from
+  `/root/reference` in the build container and runs it; `oracle/network.py`, `oracle/projection.py` and
+  `oracle/losses.py` are checked against those goldens by `tests/test_oracle_golden.py`.
+* Third-party primitives (`oracle/primitives.py`): PARITY UNPINNED -- the reference holds no tests,
+  fixtures or golden vectors and the wheels are absent and un-fetchable, so the
+  primitives are restated from their published algorithms; every assumption is listed in the
+  docstring of the function that makes it.
+"""

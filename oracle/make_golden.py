@@ -1,0 +1,131 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE'S OWN GLUE CODE.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).  What is imported from
+the reference, unmodified: `model.point_net2` (PointNet2, SAModule, GlobalSAModule, FPModule, MLP),
+`model.project_to_2d` (both projection functions) and `learning.loss_functions`.  Their third-party imports
+(`torch_geometric.nn`, `torch_scatter`, plus `comet_ml` pulled in by `utils/utils.py:5`) are absent here and
+un-fetchable, so `oracle.primitives` -- the restatement of those libraries' published algorithms -- is
+registered under their module names.  Consequently the goldens pin the reference GLUE
+exactly; the primitives underneath remain "parity unpinned" (see oracle/__init__.py).
+
+Only data is written: inputs and expected outputs as .npz.  No reference source text is stored.
+
+    python -m oracle.make_golden            # rewrites tests/golden/*.npz
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # reference architecture defaults (config.py:77-80) at BASELINE config-1 size
+    "c1_ref_defaults": dict(B=1, N=4096, ratio1=0.25, r1=math.sqrt(2.0), ratio2=0.25, r2=math.sqrt(8.0),
+                            first_plot=0, starts=([0], [0])),
+    # two plots, C2-style radii (1 m / 2 m), non-zero FPS starts
+    "b2_c2_style": dict(B=2, N=2048, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0,
+                        first_plot=100, starts=([17, 1203], [5, 0])),
+}
+
+
+def _install_standins():
+    from oracle import primitives as P
+    comet = types.ModuleType("comet_ml")
+    comet.Experiment = comet.OfflineExperiment = type("Experiment", (), {})
+    sys.modules["comet_ml"] = comet
+    tg = types.ModuleType("torch_geometric")
+    tgnn = types.ModuleType("torch_geometric.nn")
+    for name in ("knn_interpolate", "PointConv", "fps", "radius", "global_max_pool"):
+        setattr(tgnn, name, getattr(P, name))
+    tg.nn = tgnn
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.nn"] = tgnn
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_max, ts.scatter_mean = P.scatter_max, P.scatter_mean
+    sys.modules["torch_scatter"] = ts
+    return P
+
+
+def main():
+    assert os.path.isdir(REF), "the reference is only present in the build container"
+    P = _install_standins()
+    sys.path.insert(0, REF)
+    argv, sys.argv = sys.argv, [sys.argv[0]]          # config.py parses argv at import
+    from model.point_net2 import PointNet2            # noqa: E402  (reference code)
+    from model.project_to_2d import project_to_plotwise_coverages, project_to_2d_rasters  # noqa: E402
+    from learning import loss_functions as LF         # noqa: E402
+    sys.argv = argv
+    from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
+
+    os.makedirs(OUT, exist_ok=True)
+    for name, c in CASES.items():
+        args = make_args(subsample_size=c["N"], ratio1=c["ratio1"], r1=c["r1"], ratio2=c["ratio2"], r2=c["r2"])
+        data = make_batch(c["B"], c["N"], first_plot=c["first_plot"])
+        starts = c["starts"]
+        provider = lambda b, n, call: starts[call][b]          # noqa: E731
+
+        torch.manual_seed(0)
+        model = PointNet2(args)
+        # perturb BN affine/running stats so eval-mode parity is not trivially the identity
+        g = torch.Generator().manual_seed(1234)
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                if k.endswith(".2.weight"):
+                    v.copy_(1.0 + 0.2 * (torch.rand(v.shape, generator=g) - 0.5))
+                elif k.endswith(".2.bias") or k.endswith("running_mean"):
+                    v.copy_(0.1 * (torch.rand(v.shape, generator=g) - 0.5))
+                elif k.endswith("running_var"):
+                    v.copy_(0.5 + torch.rand(v.shape, generator=g))
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        out = {f"sd/{k}": v.numpy() for k, v in sd0.items()}
+        out["in/cloud"], out["in/xyz"] = data["cloud"].numpy(), data["xyz"].numpy()
+        out["in/coverages"], out["in/pdf_all"] = data["coverages"].numpy(), data["pdf_all"].numpy()
+        out["in/fps_start"] = np.asarray(starts, dtype=np.int64)
+
+        # ---------------- eval-mode forward + P1 rasters + P2
+        model.eval()
+        P.set_fps_start_provider(provider)
+        with torch.no_grad():
+            cov, proba = model({"cloud": data["cloud"], "xyz": data["xyz"]})
+            pred = project_to_plotwise_coverages(cov, data["cloud"], args)
+        out["eval/coverages_pointwise"], out["eval/proba_pointwise"] = cov.numpy(), proba.numpy()
+        out["eval/pred_coverages"] = pred.numpy()
+        cov_b = model.get_batch_format(cov)                                            # (B,4,N)
+        out["eval/rasters"] = np.stack([project_to_2d_rasters(data["cloud"][b], cov_b[b], args)
+                                        for b in range(c["B"])])
+
+        # ---------------- train-mode forward + loss + backward  (learning/train.py:52-64)
+        model.train()
+        P.set_fps_start_provider(provider)
+        pdf = data["pdf_all"].numpy()
+        args.kde_mixture = types.SimpleNamespace(predict=lambda z: (pdf[:, 0], pdf[:, 1], pdf[:, 2]))
+        cov, proba = model({"cloud": data["cloud"], "xyz": data["xyz"]})
+        pred = project_to_plotwise_coverages(cov, data["cloud"], args)
+        loss_abs = LF.get_absolute_loss(pred, data["coverages"])
+        loss_log, _ = LF.get_NLL_loss(proba, data["cloud"], args)
+        loss_e = LF.get_entropy_loss(proba)
+        loss = loss_abs + args.m * loss_log + args.e * loss_e
+        loss.backward()
+        out["train/coverages_pointwise"], out["train/proba_pointwise"] = cov.detach().numpy(), proba.detach().numpy()
+        out["train/pred_coverages"] = pred.detach().numpy()
+        out["train/losses"] = np.asarray([loss.item(), loss_abs.item(), loss_log.item(), loss_e.item()])
+        for k, p in model.named_parameters():
+            out[f"grad/{k}"] = p.grad.numpy()
+        for k, v in model.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                out[f"sd_after/{k}"] = v.numpy()
+        P.set_fps_start_provider(None)
+
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays -> {path} ({os.path.getsize(path) / 1024:.0f} KiB), "
+              f"loss={loss.item():.6f}")
+
+
+if __name__ == "__main__":
+    main()
