@@ -1,0 +1,160 @@
+/* strata_hip.h -- C ABI of libstrata_hip.so: the MI355X (gfx950) implementation of the PointNet2 hot path of
+ * IGNF/StrataNet2-Vegetation-Coverage-Maps.
+ *
+ * The reference has no FFI: its boundary is the Python API of model/point_net2.py and model/project_to_2d.py,
+ * whose arithmetic lives in un-vendored wheels (torch-cluster 1.5.9, torch-geometric 1.7.2, torch-scatter 2.0.7).
+ * Each entry point below names the reference call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()) unless it points to one of the structs below, which
+ *     live in host memory and are only read during the call;
+ *   - the caller owns every buffer including workspaces; nothing is allocated, freed or synchronised inside;
+ *   - every call is asynchronous on `stream` (a hipStream_t; NULL = default stream);
+ *   - fp32 data, int32 indices; indices are LOCAL to their plot (0..N-1) unless stated;
+ *   - return value: 0 = ok, >0 = hipError_t of a failed launch, <0 = argument error (SN2_E*), never throws.
+ *
+ * Layouts
+ *   "SoA"   (B,3,N)   x-row, y-row, z-row per plot          (what the reference DataLoader hands over as `xyz`)
+ *   "AoS4"  (B*N,4)   x,y,z,0 per point
+ *   rows    (R,C)     row-major feature rows
+ */
+#ifndef STRATA_HIP_H
+#define STRATA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN2_VERSION 100
+#define SN2_EINVAL (-1) /* bad size / null pointer             */
+#define SN2_ELIMIT (-2) /* size outside what the kernels cover */
+
+#define SN2_MAX_NEIGHBORS 2000 /* model/point_net2.py:24  max_num_neighbors */
+
+int sn2_version(void);
+
+/* ---- one (Linear -> ReLU -> BatchNorm1d) block, model/point_net2.py:45-53 -------------------------------- */
+typedef struct sn2_block {
+    int cin, cout;
+    const float *W, *b;            /* Linear weight (cout,cin) row-major, bias (cout)                            */
+    const float *gamma, *beta;     /* BatchNorm affine (cout)                                                   */
+    float *running_mean, *running_var; /* (cout) updated in place when training (momentum 0.1, unbiased var)    */
+    float *a, *c;                  /* out (cout): the block's output is  a*relu(W u + b) + c                    */
+    float *mean, *invstd;          /* out (cout): batch statistics saved for backward (training)                */
+    double *sum, *sumsq;           /* workspace (cout each), must be ZERO on entry of a training forward        */
+    float *dW, *db, *dgamma, *dbeta; /* backward outputs, ACCUMULATED; must be ZERO on entry of the backward call
+                                        (dgamma/dbeta are read back inside it)                                   */
+} sn2_block;
+
+/* ---- geometry -------------------------------------------------------------------------------------------- */
+
+/* (cloud (B,C,N), xyz (B,3,N)) -> rows0 (B*N,12) = [cloud rows 2..9 | x y z 0]
+ * replaces the long-form/concat glue of PointNet2.forward, model/point_net2.py:107-124 (C must be 10). */
+int sn2_pack_rows(const float *cloud, const float *xyz, int B, int C, int N, float *rows0, void *stream);
+
+/* farthest point sampling -- torch_cluster.fps, model/point_net2.py:22.
+ * start (B) local start index per plot or NULL (= 0, i.e. random_start=False).
+ * idx (B,M) local indices in selection order; cpos_soa (B,3,M) and cpos_aos (B*M,4) = the selected positions. */
+int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
+            float *cpos_aos, void *stream);
+
+/* radius ball query -- torch_cluster.radius, model/point_net2.py:23-25.
+ * For centroid i of plot b: all source points j of plot b with d2 < r2 (strict, canonical fp32 arithmetic),
+ * ascending j, at most `cap` of them: nbr[(b*M+i)*cap + 0..cnt-1], cnt[b*M+i]. *total += sum of cnt. */
+int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, int M, float r2, int cap,
+                   int *nbr, int *cnt, unsigned long long *total, void *stream);
+
+/* k nearest sources (k = 1..3) + inverse squared distance weights -- the no_grad part of
+ * torch_geometric.nn.knn_interpolate, model/point_net2.py:63.
+ * idx (B*T,3), w (B*T,3): w = 1/max(d2,1e-16); unused slots (k<3 or S<k) get w = 0 and idx = idx[0]. */
+int sn2_three_nn(const float *src_soa, int B, int S, const float *dst_soa, int T, int k, int *idx, float *w,
+                 void *stream);
+
+/* ---- set abstraction: gather + shared MLP + BN + max -- SAModule/PointConv, model/point_net2.py:19,21-29 --- */
+typedef struct sn2_sa {
+    int B, Nsrc, M, cap;            /* plots, source points per plot, centroids per plot, stride of nbr        */
+    int cf;                         /* feature channels of a source row (8 or 16); message = [feat | pos_j-pos_i] */
+    int nl;                         /* blocks in local_nn: 1 or 2                                               */
+    const float *feat; int feat_stride;  /* source feature rows (B*Nsrc, feat_stride)                           */
+    const float *spos; int spos_stride;  /* source positions (x,y,z,.) rows                                      */
+    const float *cpos;              /* centroid positions AoS4 (B*M,4)                                          */
+    const int *nbr, *cnt;           /* from sn2_ball_query                                                      */
+    const unsigned long long *total;/* number of messages E (device)                                            */
+    sn2_block blk[2];
+    float *ext; int *arg;           /* (B*M,cout): signed extremum of the last block's pre-BN activation and the
+                                       neighbour slot attaining it                                              */
+    float *out;                     /* (B*M,cout) = a*ext + c : the module output x                             */
+    const float *dout;              /* backward in : d loss / d out (B*M,cout)                                  */
+    float *dfeat;                   /* backward out: ACCUMULATED d loss / d feat (B*Nsrc,cf) or NULL            */
+} sn2_sa;
+int sn2_sa_forward(const sn2_sa *p, int training, void *stream);
+int sn2_sa_backward(const sn2_sa *p, void *stream);
+
+/* ---- dense-row block with interpolated + skip inputs: FPModule / GlobalSAModule, model/point_net2.py:37-42,62-67
+ * u_r = [ interp_r (ca) | skip_r (cb) ],  interp_r = sa*( sum_k w_k src[idx_k] / sum_k w_k ) + sc,
+ * h = relu(W u + b) (R,cout) stored pre-BN; consumers apply (a,c).  knn_idx = NULL: interp_r = src row r. */
+typedef struct sn2_fp {
+    int B, R_per_plot, S_per_plot;  /* rows per plot (targets), source rows per plot                            */
+    int ca, cb;                     /* interpolated channels, skip channels (cb may be 0)                       */
+    const float *src; int src_stride; const float *src_a, *src_c; /* source rows (pre-BN) + their affine or NULL */
+    const int *knn_idx; const float *knn_w;                        /* (B*R,3) from sn2_three_nn or NULL          */
+    const float *skip; int skip_stride;                            /* (B*R, skip_stride) or NULL                 */
+    sn2_block blk;
+    float *h; int h_stride;         /* (B*R,h_stride) pre-BN activations; h_stride = cout rounded up to 4        */
+    const float *dy;                /* backward in : d loss / d (a*h+c)  (B*R,h_stride)                          */
+    float *dsrc; int dsrc_stride;   /* backward out: ACCUMULATED d loss / d (sa*src+sc) (B*S,dsrc_stride) or NULL */
+    float *dskip; int dskip_stride; /* backward out: ACCUMULATED (B*R, >=cb) or NULL                             */
+    float *du_scratch;              /* backward workspace (B*R,ca) when knn_idx and dsrc are given               */
+} sn2_fp;
+int sn2_fp_forward(const sn2_fp *p, int training, void *stream);
+int sn2_fp_backward(const sn2_fp *p, void *stream);
+
+/* per-plot max over R_per_plot rows of a*h+c -- global_max_pool, model/point_net2.py:39.
+ * h has row stride C rounded up to 4.  out (B,C); arg (B,C) row attaining it; backward scatters dout into dy
+ * (B*R, same stride), which the caller zeroed. */
+int sn2_plot_max_forward(const float *h, const float *a, const float *c, int B, int R_per_plot, int C, float *out,
+                         int *arg, void *stream);
+int sn2_plot_max_backward(const float *dout, const int *arg, int B, int R_per_plot, int C, float *dy, void *stream);
+
+/* ---- pointwise head: lin1+ReLU, lin2, softmax/sigmoid/product -- model/point_net2.py:141-151 ----------------
+ * f (R,34) pre-BN with affine (fa,fc); coverages (R,4), proba (R,4). */
+typedef struct sn2_head {
+    int R, cin, f_stride;           /* rows, 34, 36                                                              */
+    const float *f, *fa, *fc;
+    const float *W1, *b1, *W2, *b2; /* (16,34),(16),(5,16),(5)                                                   */
+    float *coverages, *proba;
+    const float *dcoverages, *dproba; /* backward in (R,4) each, either may be NULL                              */
+    float *dy;                      /* backward out: d loss / d (fa*f+fc) (R,f_stride)                           */
+    float *dW1, *db1, *dW2, *db2;   /* ACCUMULATED                                                               */
+} sn2_head;
+int sn2_head_forward(const sn2_head *p, void *stream);
+int sn2_head_backward(const sn2_head *p, void *stream);
+
+/* ---- 2D projections -- model/project_to_2d.py -------------------------------------------------------------- */
+
+/* P2 project_to_plotwise_coverages (:7-55): bbox-normalised diam_pix^2 grid per plot, per-pixel max of channels
+ * 0,2,3 (first point wins ties), bare soil = 1 - low-veg max, mean over occupied pixels.
+ * cloud_xy: plot b's normalised x row at cloud_xy + b*plot_stride, y row at + b*plot_stride + N.
+ * keys (B*D*D*3) u64 workspace; pix (B*N) int32 out (x_pix*D + y_pix, bit-exact); arg (B*D*D*3) int32 out;
+ * nocc (B) int32 out; pred (B,4) out. */
+int sn2_plot_project_forward(const float *pred_pointwise, const float *cloud_xy, long plot_stride, int B, int N,
+                             int D, unsigned long long *keys, int *pix, int *arg, int *nocc, float *pred,
+                             void *stream);
+/* d pred (B,4) -> d pred_pointwise (B*N,4), which the caller zeroed. */
+int sn2_plot_project_backward(const float *dpred, const int *arg, const int *nocc, int B, int N, int D,
+                              float *dpointwise, void *stream);
+
+/* P1 project_to_2d_rasters (:58-113): fixed grid, clipped; rasters (B,3,D,D) [low,med,high], image[y,x], NaN where
+ * empty, rows flipped; pix (B*N) int32 out = y_pix*D + x_pix (unflipped).  coverages (B*N,4) row-major. */
+int sn2_raster_project(const float *coverages, const float *cloud_xy, long plot_stride, int B, int N, int D,
+                       int diam_meters, unsigned long long *keys, int *pix, float *rasters, void *stream);
+
+/* ---- optimiser step of the timed training step -- torch.optim.Adam as configured in learning/train.py:180-185
+ * (L2 weight decay added to the gradient), on flat buffers; grad_scale multiplies the gradient first (1/world). */
+int sn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRATA_HIP_H */

@@ -1,0 +1,73 @@
+// common.h -- device helpers shared by the gfx950 kernels of libstrata_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/strata_hip.h"
+
+#define SN2_WAVE 64
+
+#define SN2_RETURN_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        return e__ == hipSuccess ? 0 : (int)e__;              \
+    } while (0)
+
+#define SN2_TRY(expr)                \
+    do {                             \
+        int r__ = (expr);            \
+        if (r__ != 0) return r__;    \
+    } while (0)
+
+static inline int sn2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- canonical squared distance: (dx*dx + dy*dy) + dz*dz, every operation rounded to fp32 on its
+// own.  The pragma removes the `contract` flag from these operations so the backend cannot fuse them into FMAs even
+// after inlining into a kernel compiled with the default -ffp-contract=fast.
+__device__ __forceinline__ float sn2_d2(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    float dx = ax - bx;
+    float dy = ay - by;
+    float dz = az - bz;
+    float xx = dx * dx;
+    float yy = dy * dy;
+    float zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// order-preserving map float -> uint32 (any non-NaN float maps to a value > 0)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}

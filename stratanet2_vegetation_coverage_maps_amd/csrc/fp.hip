@@ -1,0 +1,554 @@
+// fp.hip -- dense-row (Linear->ReLU->BN) blocks with interpolated + skip inputs, forward and backward, and the pointwise
+// head.  Replaces FPModule.forward (knn_interpolate's differentiable half + cat + MLP), GlobalSAModule's MLP and the
+// head of PointNet2.forward: /root/reference/model/point_net2.py:37-42, 62-67, 141-151.
+//
+// One row per lane.  A row's input u = [ interp (ca) | skip (cb) ] is rebuilt in registers from the 1 or 3 source rows
+// (16-byte gathers out of an L2-resident table), the Linear layer runs against wave-uniform weights (SGPR operands),
+// the pre-BN activation h is stored once (row stride padded to 16 B) and its batch statistics are reduced per wave and
+// added as fp64 atomics.  Consumers apply the BN affine (a, c) when they read h, so no BN-apply pass exists.
+// Backward: (1) dgamma/dbeta reduction over rows, (2) main pass: dpre, dW|db through the MFMA outer-product accumulator
+// (rows = MFMA K), input gradient du; (3) the interpolation's transpose: du rows are scattered onto their 1..3 source
+// rows with LDS float atomics on a per-plot tile of the source table (global float atomics onto random rows run ~17x
+// below the streaming atomic rate on this chip), then flushed with one global atomic per element.
+#include "mlp.h"
+
+namespace {
+
+template <int CA, int CB, bool KNN>
+__device__ __forceinline__ void build_input(const float* __restrict__ src, int src_stride, const float* __restrict__ src_a,
+                                            const float* __restrict__ src_c, const int* __restrict__ knn_idx,
+                                            const float* __restrict__ knn_w, const float* __restrict__ skip,
+                                            int skip_stride, size_t r, size_t src_plot_base, float (&u)[CA + CB + 1]) {
+    constexpr int Q = (CA + 3) / 4;
+    if constexpr (KNN) {
+        const int i0 = knn_idx[r * 3 + 0], i1 = knn_idx[r * 3 + 1], i2 = knn_idx[r * 3 + 2];
+        const float w0 = knn_w[r * 3 + 0], w1 = knn_w[r * 3 + 1], w2 = knn_w[r * 3 + 2];
+        const float inv = 1.0f / ((w0 + w1) + w2);
+        const float4* s0 = reinterpret_cast<const float4*>(src + (src_plot_base + i0) * src_stride);
+        const float4* s1 = reinterpret_cast<const float4*>(src + (src_plot_base + i1) * src_stride);
+        const float4* s2 = reinterpret_cast<const float4*>(src + (src_plot_base + i2) * src_stride);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float4 a = s0[q], b = s1[q], c = s2[q];
+            const float v[4] = {(a.x * w0 + b.x * w1) + c.x * w2, (a.y * w0 + b.y * w1) + c.y * w2,
+                                (a.z * w0 + b.z * w1) + c.z * w2, (a.w * w0 + b.w * w1) + c.w * w2};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (4 * q + t < CA) u[4 * q + t] = v[t] * inv;
+        }
+    } else {
+        const float4* s0 = reinterpret_cast<const float4*>(src + r * src_stride);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float4 a = s0[q];
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (4 * q + t < CA) u[4 * q + t] = v[t];
+        }
+    }
+    if (src_a) {
+#pragma unroll
+        for (int k = 0; k < CA; ++k) u[k] = fmaf(src_a[k], u[k], src_c[k]);
+    }
+    if constexpr (CB > 0) {
+        const float* sk = skip + r * skip_stride;
+        if constexpr (CB % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < CB / 4; ++q) {
+                const float4 a = reinterpret_cast<const float4*>(sk)[q];
+                u[CA + 4 * q + 0] = a.x;
+                u[CA + 4 * q + 1] = a.y;
+                u[CA + 4 * q + 2] = a.z;
+                u[CA + 4 * q + 3] = a.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CB; ++k) u[CA + k] = sk[k];
+        }
+    }
+    u[CA + CB] = 1.0f;  // the bias column of the outer-product accumulator
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int CA, int CB, int CO, bool KNN>
+__global__ __launch_bounds__(256) void fp_fwd_kernel(int R, int R_per_plot, int S_per_plot, int src_stride, int skip_stride,
+                                                     int h_stride, const float* __restrict__ src,
+                                                     const float* __restrict__ src_a, const float* __restrict__ src_c,
+                                                     const int* __restrict__ knn_idx, const float* __restrict__ knn_w,
+                                                     const float* __restrict__ skip, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ h,
+                                                     double* __restrict__ sum, double* __restrict__ sumsq) {
+    constexpr int CI = CA + CB;
+    float ssum[CO], ssq[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) ssum[o] = ssq[o] = 0.f;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
+        float u[CI + 1];
+        const size_t plot = (size_t)(r / R_per_plot);
+        build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, (size_t)r,
+                                 plot * S_per_plot, u);
+        float* hr = h + (size_t)r * h_stride;
+#pragma unroll
+        for (int o4 = 0; o4 < CO; o4 += 4) {
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = o4 + t;
+                float acc = 0.f;
+                if (o < CO) {
+                    acc = bias[o];
+#pragma unroll
+                    for (int k = 0; k < CI; ++k) acc = fmaf(W[o * CI + k], u[k], acc);
+                    acc = fmaxf(acc, 0.f);
+                    ssum[o] += acc;
+                    ssq[o] = fmaf(acc, acc, ssq[o]);
+                }
+                v[t] = acc;
+            }
+            *reinterpret_cast<float4*>(hr + o4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (sum) {
+        flush_sums_f64<CO>(ssum, sum);
+        flush_sums_f64<CO>(ssq, sumsq);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward (1)
+// dbeta[o] = sum_r dy[r][o];  dgamma[o] = sum_r dy[r][o] * (h[r][o] - mean[o]) * invstd[o]
+template <int CO>
+__global__ __launch_bounds__(256) void fp_bwd_bn_kernel(int R, int h_stride, const float* __restrict__ h,
+                                                        const float* __restrict__ dy, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+    float sb[CO], sg[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) sb[o] = sg[o] = 0.f;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
+        const float4* hr = reinterpret_cast<const float4*>(h + (size_t)r * h_stride);
+        const float4* dr = reinterpret_cast<const float4*>(dy + (size_t)r * h_stride);
+#pragma unroll
+        for (int q = 0; q < (CO + 3) / 4; ++q) {
+            const float4 hv = hr[q], dv = dr[q];
+            const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = 4 * q + t;
+                if (o < CO) {
+                    sb[o] += dd[t];
+                    sg[o] = fmaf(dd[t], (hh[t] - mean[o]) * invstd[o], sg[o]);
+                }
+            }
+        }
+    }
+    flush_sums<CO>(sb, dbeta);
+    flush_sums<CO>(sg, dgamma);
+}
+
+// ---------------------------------------------------------------------------------------------- backward (2)
+template <int CA, int CB, int CO, bool KNN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
+    int R, int R_per_plot, int S_per_plot, int src_stride, int skip_stride, int h_stride, int dskip_stride,
+    int du_stride, float invR,
+    const float* __restrict__ src, const float* __restrict__ src_a, const float* __restrict__ src_c,
+    const int* __restrict__ knn_idx, const float* __restrict__ knn_w, const float* __restrict__ skip,
+    const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+    const float* __restrict__ h, const float* __restrict__ dy, float* __restrict__ dW, float* __restrict__ db,
+    float* __restrict__ du_out /* KNN: (R,CA) scratch; else ACCUMULATED rows (R,du_stride) */,
+    float* __restrict__ dskip) {
+    constexpr int CI = CA + CB;
+    using Acc = OuterAcc<CO, CI + 1>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds = smem + (threadIdx.x >> 6) * Acc::LDS_FLOATS;
+    Acc acc;
+    acc.init(lds);
+    const long nthreads = (long)gridDim.x * WAVES * 64;
+    const long rounds = (R + nthreads - 1) / nthreads;  // every lane of a wave runs the same number of rounds
+    for (long it = 0; it < rounds; ++it) {
+        const long r = it * nthreads + (long)blockIdx.x * WAVES * 64 + threadIdx.x;
+        const bool valid = r < R;
+        const size_t rr = valid ? (size_t)r : 0;
+        float u[CI + 1];
+        build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, rr,
+                                 (rr / R_per_plot) * S_per_plot, u);
+        float dp[CO];
+        const float4* hr = reinterpret_cast<const float4*>(h + rr * h_stride);
+        const float4* dr = reinterpret_cast<const float4*>(dy + rr * h_stride);
+#pragma unroll
+        for (int q = 0; q < (CO + 3) / 4; ++q) {
+            const float4 hv = hr[q], dv = dr[q];
+            const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = 4 * q + t;
+                if (o < CO) {
+                    const float is = invstd[o];
+                    const float xh = (hh[t] - mean[o]) * is;
+                    const float dh = gamma[o] * is * (dd[t] - dbeta[o] * invR - xh * dgamma[o] * invR);
+                    dp[o] = (valid && hh[t] > 0.f) ? dh : 0.f;
+                }
+            }
+        }
+        acc.add(lds, dp, u);
+        if (!valid) continue;
+        // input gradient
+        if (du_out) {
+#pragma unroll
+            for (int k4 = 0; k4 < CA; k4 += 4) {
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float a = 0.f;
+                    if (k4 + t < CA) {
+#pragma unroll
+                        for (int o = 0; o < CO; ++o) a = fmaf(W[o * CI + k4 + t], dp[o], a);
+                    }
+                    v[t] = a;
+                }
+                float* dst = du_out + rr * du_stride + k4;
+                if constexpr (KNN) {
+                    if constexpr (CA % 4 == 0) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (k4 + t < CA) dst[t] = v[t];
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (k4 + t < CA) dst[t] += v[t];
+                }
+            }
+        }
+        if constexpr (CB > 0) {
+            if (dskip) {
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) a = fmaf(W[o * CI + CA + k], dp[o], a);
+                    dskip[rr * dskip_stride + k] += a;
+                }
+            }
+        }
+    }
+    acc.flush_with_bias(dW, CI, db, CO);
+}
+
+// ---------------------------------------------------------------------------------------------- backward (3)
+// dsrc[plot*S + idx_j][k] += (w_j / sum w) * du[r][k] for the 1..3 neighbours of every target row r of the plot.
+// grid (slices, tiles, B); LDS holds a tile of TS source rows x CA channels.
+template <int CA>
+__global__ __launch_bounds__(1024) void interp_scatter_kernel(int R_per_plot, int S_per_plot, int TS, int dsrc_stride,
+                                                              const int* __restrict__ knn_idx,
+                                                              const float* __restrict__ knn_w,
+                                                              const float* __restrict__ du, float* __restrict__ dsrc) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int b = blockIdx.z;
+    const int s_lo = blockIdx.y * TS;
+    const int s_hi = min(S_per_plot, s_lo + TS);
+    const int nt = (s_hi - s_lo) * CA;
+    for (int i = threadIdx.x; i < nt; i += 1024) tile[i] = 0.f;
+    __syncthreads();
+    const int rows_per_slice = (R_per_plot + gridDim.x - 1) / gridDim.x;
+    const int r_lo = blockIdx.x * rows_per_slice;
+    const int r_hi = min(R_per_plot, r_lo + rows_per_slice);
+    // a group of 4 consecutive lanes... keep it simple: one lane per (row, channel) pair, channel fastest, so the 3 adds
+    // of a wave-instruction land on contiguous LDS words of at most a few source rows.
+    const long total = (long)(r_hi - r_lo) * CA;
+    for (long t = threadIdx.x; t < total; t += 1024) {
+        const int rl = (int)(t / CA), k = (int)(t - (long)rl * CA);
+        const size_t r = (size_t)b * R_per_plot + r_lo + rl;
+        const float w0 = knn_w[r * 3 + 0], w1 = knn_w[r * 3 + 1], w2 = knn_w[r * 3 + 2];
+        const float g = du[r * CA + k] / ((w0 + w1) + w2);
+        const int i0 = knn_idx[r * 3 + 0], i1 = knn_idx[r * 3 + 1], i2 = knn_idx[r * 3 + 2];
+        if (i0 >= s_lo && i0 < s_hi) atomicAdd(&tile[(i0 - s_lo) * CA + k], g * w0);
+        if (w1 != 0.f && i1 >= s_lo && i1 < s_hi) atomicAdd(&tile[(i1 - s_lo) * CA + k], g * w1);
+        if (w2 != 0.f && i2 >= s_lo && i2 < s_hi) atomicAdd(&tile[(i2 - s_lo) * CA + k], g * w2);
+    }
+    __syncthreads();
+    float* dst = dsrc + ((size_t)b * S_per_plot + s_lo) * dsrc_stride;
+    for (int i = threadIdx.x; i < nt; i += 1024) {
+        const float v = tile[i];
+        const int sr = i / CA, k = i - sr * CA;
+        if (v != 0.f) atomicAdd(&dst[(size_t)sr * dsrc_stride + k], v);
+    }
+}
+
+int pick_grid(long R, int threads, int rows_per_lane) {
+    long g = (R + (long)threads * rows_per_lane - 1) / ((long)threads * rows_per_lane);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+template <int CA, int CB, int CO, bool KNN>
+int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
+    const int R = p->B * p->R_per_plot;
+    hipLaunchKernelGGL((fp_fwd_kernel<CA, CB, CO, KNN>), dim3(pick_grid(R, 256, 4)), dim3(256), 0, st, R, p->R_per_plot,
+                       p->S_per_plot, p->src_stride, p->skip_stride, p->h_stride, p->src, p->src_a, p->src_c, p->knn_idx,
+                       p->knn_w, p->skip, p->blk.W, p->blk.b, p->h, training ? p->blk.sum : (double*)nullptr,
+                       training ? p->blk.sumsq : (double*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return sn2_bn_finalize(&p->blk, nullptr, R, training, st);
+}
+
+template <int CA, int CB, int CO, bool KNN>
+int fp_backward_t(const sn2_fp* p, hipStream_t st) {
+    constexpr int CI = CA + CB;
+    using Acc = OuterAcc<CO, CI + 1>;
+    constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : ((Acc::LDS_FLOATS * 4 * 2 <= 150 * 1024) ? 2 : 1);
+    const int R = p->B * p->R_per_plot;
+    hipLaunchKernelGGL((fp_bwd_bn_kernel<CO>), dim3(pick_grid(R, 256, 8)), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
+                       p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    constexpr size_t lds_bytes = (size_t)Acc::LDS_FLOATS * 4 * WAVES;
+    auto kern = &fp_bwd_main_kernel<CA, CB, CO, KNN, WAVES>;
+    if (lds_bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes);
+    float* du_out = KNN ? p->du_scratch : p->dsrc;
+    if (KNN && p->dsrc && !p->du_scratch) return SN2_EINVAL;
+    if (KNN && !p->dsrc) du_out = nullptr;
+    int grid = pick_grid(R, WAVES * 64, 4);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,
+                       p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src, p->src_a, p->src_c,
+                       p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma, (const float*)p->blk.mean,
+                       (const float*)p->blk.invstd, (const float*)p->blk.dgamma, (const float*)p->blk.dbeta,
+                       (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out, p->dskip);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (KNN && p->dsrc) {
+        int TS = (144 * 1024) / (CA * 4);
+        if (TS > p->S_per_plot) TS = p->S_per_plot;
+        const int tiles = sn2_cdiv(p->S_per_plot, TS);
+        int slices = sn2_cdiv(p->R_per_plot, 2048);
+        if (slices < 1) slices = 1;
+        if (slices > 32) slices = 32;
+        const size_t tb = (size_t)TS * CA * 4;
+        if (tb > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&interp_scatter_kernel<CA>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
+        hipLaunchKernelGGL((interp_scatter_kernel<CA>), dim3(slices, tiles, p->B), dim3(1024), tb, st, p->R_per_plot,
+                           p->S_per_plot, TS, p->dsrc_stride, p->knn_idx, p->knn_w, (const float*)p->du_scratch, p->dsrc);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+int check_fp(const sn2_fp* p) {
+    if (!p || p->B <= 0 || p->R_per_plot <= 0 || p->S_per_plot <= 0 || !p->src || !p->h || !p->blk.W || !p->blk.b)
+        return SN2_EINVAL;
+    if ((p->src_stride & 3) || p->src_stride < p->ca || (p->h_stride & 3) || p->h_stride < p->blk.cout) return SN2_EINVAL;
+    if (p->cb > 0 && (!p->skip || p->skip_stride < p->cb)) return SN2_EINVAL;
+    if (p->cb % 4 == 0 && p->cb > 0 && (p->skip_stride & 3)) return SN2_EINVAL;
+    if ((p->knn_idx == nullptr) != (p->knn_w == nullptr)) return SN2_EINVAL;
+    if (p->dsrc && p->dsrc_stride < p->ca) return SN2_EINVAL;
+    if (p->blk.cin != p->ca + p->cb) return SN2_EINVAL;
+    return 0;
+}
+
+// the four dense-row blocks of the reference architecture (model/point_net2.py:83,88-93)
+#define FP_DISPATCH(FN, ...)                                                                                      \
+    do {                                                                                                          \
+        const bool knn = p->knn_idx != nullptr;                                                                   \
+        if (!knn && p->ca == 32 && p->cb == 3 && p->blk.cout == 64) return FN<32, 3, 64, false>(__VA_ARGS__);     \
+        if (knn && p->ca == 64 && p->cb == 32 && p->blk.cout == 64) return FN<64, 32, 64, true>(__VA_ARGS__);     \
+        if (knn && p->ca == 64 && p->cb == 16 && p->blk.cout == 34) return FN<64, 16, 34, true>(__VA_ARGS__);     \
+        if (knn && p->ca == 34 && p->cb == 8 && p->blk.cout == 34) return FN<34, 8, 34, true>(__VA_ARGS__);       \
+        return SN2_ELIMIT;                                                                                        \
+    } while (0)
+
+}  // namespace
+
+extern "C" int sn2_fp_forward(const sn2_fp* p, int training, void* stream) {
+    SN2_TRY(check_fp(p));
+    FP_DISPATCH(fp_forward_t, p, training, (hipStream_t)stream);
+}
+
+extern "C" int sn2_fp_backward(const sn2_fp* p, void* stream) {
+    SN2_TRY(check_fp(p));
+    if (!p->dy || !p->blk.dW || !p->blk.db || !p->blk.dgamma || !p->blk.dbeta) return SN2_EINVAL;
+    FP_DISPATCH(fp_backward_t, p, (hipStream_t)stream);
+}
+
+// =============================================================================================== head
+namespace {
+
+struct HeadOut {
+    float y[35];   // fa*f+fc | 1
+    float z1[17];  // relu(lin1) | 1
+    float p[4];
+    float dens;
+};
+
+__device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, const float* __restrict__ fa,
+                                         const float* __restrict__ fc, const float* __restrict__ W1,
+                                         const float* __restrict__ b1, const float* __restrict__ W2,
+                                         const float* __restrict__ b2, size_t r, HeadOut& o) {
+    const float4* fr = reinterpret_cast<const float4*>(f + r * f_stride);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const float4 v = fr[q];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * q + t < 34) o.y[4 * q + t] = fmaf(fa[4 * q + t], vv[t], fc[4 * q + t]);
+    }
+    o.y[34] = 1.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float acc = b1[j];
+#pragma unroll
+        for (int k = 0; k < 34; ++k) acc = fmaf(W1[j * 34 + k], o.y[k], acc);
+        o.z1[j] = fmaxf(acc, 0.f);
+    }
+    o.z1[16] = 1.f;
+    float s[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float acc = b2[i];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fmaf(W2[i * 16 + j], o.z1[j], acc);
+        s[i] = acc;
+    }
+    const float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    float e[4], den = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        e[i] = expf(s[i] - m);
+        den += e[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.p[i] = e[i] / den;
+    o.dens = 1.0f / (1.0f + expf(-s[4]));
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(int R, int f_stride, const float* __restrict__ f,
+                                                       const float* __restrict__ fa, const float* __restrict__ fc,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       const float* __restrict__ W2, const float* __restrict__ b2,
+                                                       float* __restrict__ cov, float* __restrict__ proba) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
+        HeadOut o;
+        head_row(f, f_stride, fa, fc, W1, b1, W2, b2, (size_t)r, o);
+        reinterpret_cast<float4*>(proba)[r] = make_float4(o.p[0], o.p[1], o.p[2], o.p[3]);
+        reinterpret_cast<float4*>(cov)[r] = make_float4(o.p[0] * o.dens, o.p[1] * o.dens, o.p[2] * o.dens, o.p[3] * o.dens);
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(int R, int f_stride, const float* __restrict__ f,
+                                                       const float* __restrict__ fa, const float* __restrict__ fc,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       const float* __restrict__ W2, const float* __restrict__ b2,
+                                                       const float* __restrict__ dcov, const float* __restrict__ dproba,
+                                                       float* __restrict__ dy, float* __restrict__ dW1,
+                                                       float* __restrict__ db1, float* __restrict__ dW2,
+                                                       float* __restrict__ db2) {
+    using Acc2 = OuterAcc<16, 17>;  // rows 0..4 = d scores, rest zero;  Q = [z1 | 1]
+    using Acc1 = OuterAcc<16, 35>;  // d pre-activation of lin1;          Q = [y | 1]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds2 = smem + (threadIdx.x >> 6) * (Acc2::LDS_FLOATS + Acc1::LDS_FLOATS);
+    float* lds1 = lds2 + Acc2::LDS_FLOATS;
+    Acc2 acc2;
+    Acc1 acc1;
+    acc2.init(lds2);
+    acc1.init(lds1);
+    const long nthreads = (long)gridDim.x * 256;
+    const long rounds = (R + nthreads - 1) / nthreads;
+    for (long it = 0; it < rounds; ++it) {
+        const long r = it * nthreads + (long)blockIdx.x * 256 + threadIdx.x;
+        const bool valid = r < R;
+        const size_t rr = valid ? (size_t)r : 0;
+        HeadOut o;
+        head_row(f, f_stride, fa, fc, W1, b1, W2, b2, rr, o);
+        float gc[4] = {0.f, 0.f, 0.f, 0.f}, gp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (dcov) {
+            const float4 v = reinterpret_cast<const float4*>(dcov)[rr];
+            gc[0] = v.x; gc[1] = v.y; gc[2] = v.z; gc[3] = v.w;
+        }
+        if (dproba) {
+            const float4 v = reinterpret_cast<const float4*>(dproba)[rr];
+            gp[0] = v.x; gp[1] = v.y; gp[2] = v.z; gp[3] = v.w;
+        }
+        float dp[4], dot = 0.f, ddens = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dp[i] = fmaf(gc[i], o.dens, gp[i]);
+            ddens = fmaf(gc[i], o.p[i], ddens);
+            dot = fmaf(dp[i], o.p[i], dot);
+        }
+        float ds[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ds[i] = valid ? o.p[i] * (dp[i] - dot) : 0.f;
+        ds[4] = valid ? ddens * o.dens * (1.f - o.dens) : 0.f;
+#pragma unroll
+        for (int i = 5; i < 16; ++i) ds[i] = 0.f;
+        acc2.add(lds2, ds, o.z1);
+        float dpre[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a = fmaf(W2[i * 16 + j], ds[i], a);
+            dpre[j] = o.z1[j] > 0.f ? a : 0.f;
+        }
+        acc1.add(lds1, dpre, o.y);
+        if (valid) {
+            float* dr = dy + rr * f_stride;
+#pragma unroll
+            for (int k4 = 0; k4 < 36; k4 += 4) {
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float a = 0.f;
+                    if (k4 + t < 34) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) a = fmaf(W1[j * 34 + k4 + t], dpre[j], a);
+                    }
+                    v[t] = a;
+                }
+                *reinterpret_cast<float4*>(dr + k4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    acc2.flush_with_bias(dW2, 16, db2, 5);
+    acc1.flush_with_bias(dW1, 34, db1, 16);
+}
+
+int check_head(const sn2_head* p) {
+    if (!p || p->R <= 0 || p->cin != 34 || p->f_stride != 36) return p && p->R > 0 ? SN2_ELIMIT : SN2_EINVAL;
+    if (!p->f || !p->fa || !p->fc || !p->W1 || !p->b1 || !p->W2 || !p->b2) return SN2_EINVAL;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
+    SN2_TRY(check_head(p));
+    if (!p->coverages || !p->proba) return SN2_EINVAL;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f_stride,
+                       p->f, p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
+    SN2_TRY(check_head(p));
+    if (!p->dy || !p->dW1 || !p->db1 || !p->dW2 || !p->db2) return SN2_EINVAL;
+    constexpr size_t lds_bytes = (size_t)(OuterAcc<16, 17>::LDS_FLOATS + OuterAcc<16, 35>::LDS_FLOATS) * 4 * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+    int grid = pick_grid(p->R, 256, 4);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
+                       p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
+                       p->db2);
+    SN2_RETURN_LAUNCH();
+}

@@ -1,0 +1,144 @@
+// misc.hip -- BatchNorm finalisation, per-plot max pool, flat Adam step.
+#include "mlp.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// BatchNorm1d finalisation (torch defaults: eps 1e-5, momentum 0.1, biased variance to normalise, unbiased variance
+// into running_var) -- model/point_net2.py:45-53.  One thread per channel; the sums arrive as fp64 atomics.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ a, float* __restrict__ c, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, const double* __restrict__ sum,
+                                   const double* __restrict__ sumsq, const unsigned long long* __restrict__ count_dev,
+                                   long count_imm, int training) {
+    const int o = threadIdx.x;
+    if (o >= C) return;
+    const float eps = 1e-5f, mom = 0.1f;
+    float mean, invstd;
+    if (training) {
+        double n = count_dev ? (double)(*count_dev) : (double)count_imm;
+        if (n < 1.0) n = 1.0;
+        const double m = sum[o] / n;
+        double var = sumsq[o] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = 1.0f / sqrtf((float)var + eps);
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[o] = (1.f - mom) * running_mean[o] + mom * mean;
+        running_var[o] = (1.f - mom) * running_var[o] + mom * (float)unbiased;
+    } else {
+        mean = running_mean[o];
+        invstd = 1.0f / sqrtf(running_var[o] + eps);
+    }
+    const float aa = gamma[o] * invstd;
+    a[o] = aa;
+    c[o] = beta[o] - mean * aa;
+    mean_out[o] = mean;
+    invstd_out[o] = invstd;
+}
+
+int sn2_bn_finalize(const sn2_block* blk, const unsigned long long* count_dev, long count_imm, int training,
+                    hipStream_t st) {
+    if (!blk || blk->cout <= 0 || blk->cout > 64) return SN2_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
+                       blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, blk->sum, blk->sumsq, count_dev,
+                       count_imm, training);
+    SN2_RETURN_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-plot max of a*h + c over R rows -- global_max_pool, model/point_net2.py:39.  One workgroup per plot, thread =
+// (row group, channel); first row wins ties (torch_scatter CPU updates on strict '>').
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plot_max_kernel(const float* __restrict__ h, int hs, const float* __restrict__ a,
+                                                       const float* __restrict__ c, int R, int C, float* __restrict__ out,
+                                                       int* __restrict__ arg) {
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    const int b = blockIdx.x, ch = threadIdx.x % C, g = threadIdx.x / C, G = 256 / C;
+    float best = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    if (g < G) {
+        const float aa = a[ch], cc = c[ch];
+        for (int r = g; r < R; r += G) {
+            const float v = fmaf(aa, h[((size_t)b * R + r) * hs + ch], cc);
+            if (v > best) {
+                best = v;
+                bi = r;
+            }
+        }
+    }
+    s_v[threadIdx.x] = best;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        for (int k = 1; k < G; ++k) {
+            const float v = s_v[k * C + ch];
+            const int i = s_i[k * C + ch];
+            if (v > best || (v == best && i < bi)) {
+                best = v;
+                bi = i;
+            }
+        }
+        out[(size_t)b * C + ch] = best;
+        arg[(size_t)b * C + ch] = bi;
+    }
+}
+
+extern "C" int sn2_plot_max_forward(const float* h, const float* a, const float* c, int B, int R_per_plot, int C,
+                                    float* out, int* arg, void* stream) {
+    if (!h || !a || !c || !out || !arg || B <= 0 || R_per_plot <= 0 || C <= 0 || C > 256) return SN2_EINVAL;
+    const int hs = (C + 3) & ~3;
+    hipLaunchKernelGGL(plot_max_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, hs, a, c, R_per_plot, C, out, arg);
+    SN2_RETURN_LAUNCH();
+}
+
+__global__ void plot_max_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg, int B, int R, int C,
+                                    int hs, float* __restrict__ dy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, ch = i - b * C;
+    const int r = arg[i];
+    if (r >= 0 && r < R) dy[((size_t)b * R + r) * hs + ch] = dout[i];
+}
+
+extern "C" int sn2_plot_max_backward(const float* dout, const int* arg, int B, int R_per_plot, int C, float* dy,
+                                     void* stream) {
+    if (!dout || !arg || !dy || B <= 0 || R_per_plot <= 0 || C <= 0) return SN2_EINVAL;
+    const int hs = (C + 3) & ~3;
+    hipLaunchKernelGGL(plot_max_bwd_kernel, dim3(sn2_cdiv((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, dout, arg,
+                       B, R_per_plot, C, hs, dy);
+    SN2_RETURN_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// torch.optim.Adam (amsgrad=False, L2 weight decay folded into the gradient) on flat fp32 buffers.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gscale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float grad = g[i] * gscale;
+    const float pi = p[i];
+    grad = fmaf(wd, pi, grad);
+    const float mi = m[i] + (1.f - b1) * (grad - m[i]);       // lerp, as torch
+    const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+extern "C" int sn2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return SN2_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(sn2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_version(void) { return SN2_VERSION; }

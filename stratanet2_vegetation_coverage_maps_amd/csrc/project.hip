@@ -1,0 +1,252 @@
+// project.hip -- scatter-max projections of pointwise coverages onto 2D rasters.
+// Replaces /root/reference/model/project_to_2d.py: project_to_plotwise_coverages (:7-55, torch.unique + torch_scatter
+// scatter_max/scatter_mean with per-plot device<->CPU bounces) and project_to_2d_rasters (:58-113, a python loop over
+// pixels).  Both become: pixel id per point (index arithmetic operation-for-operation in fp32 -- the ids must be
+// bit-exact), a 64-bit max per (pixel, channel) over the key (ordered(value) << 32 | ~point), i.e. largest value, FIRST
+// point on ties as torch_scatter's CPU loop -- LDS atomics per workgroup slice, then one global atomic per touched
+// pixel -- and a tiny per-plot finalisation.  HBM-bound: 8 B (xy) + 16 B (coverages) read per point.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_CELLS = 2025;  // diam_pix <= 45: the D*D*3 keys of a workgroup fit the default 48 KiB dynamic LDS
+
+// project_to_2d.py:16-22   floor((xy - min) / (max - min + 0.0001) * diam_pix).int()
+__device__ __forceinline__ int p2_pix(float v, float mn, float mx, int D) {
+#pragma clang fp contract(off)
+    const float num = v - mn;
+    const float den = (mx - mn) + 0.0001f;
+    const float q = num / den;
+    const float s = q * (float)D;
+    int i = (int)floorf(s);
+    return i < 0 ? 0 : (i > D - 1 ? D - 1 : i);
+}
+
+// project_to_2d.py:68-78   clip(floor((xy + 0.0001) * scaling_factor + diam_meters // 2).int(), 0, diam_pix - 1)
+__device__ __forceinline__ int p1_pix(float v, float sf, float off, int D) {
+#pragma clang fp contract(off)
+    const float t = v + 0.0001f;
+    const float m = t * sf;
+    const float s = m + off;
+    int i = (int)floorf(s);
+    return i < 0 ? 0 : (i > D - 1 ? D - 1 : i);
+}
+
+__global__ __launch_bounds__(1024) void plot_minmax_kernel(const float* __restrict__ xy, long plot_stride, int N,
+                                                           float* __restrict__ mm) {
+    __shared__ float s[4][16];
+    const int b = blockIdx.x;
+    const float* x = xy + (size_t)b * plot_stride;
+    const float* y = x + N;
+    float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const float a = x[i], c = y[i];
+        xmn = fminf(xmn, a);
+        xmx = fmaxf(xmx, a);
+        ymn = fminf(ymn, c);
+        ymx = fmaxf(ymx, c);
+    }
+    xmn = wave_min(xmn);
+    xmx = wave_max(xmx);
+    ymn = wave_min(ymn);
+    ymx = wave_max(ymx);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s[0][w] = xmn;
+        s[1][w] = xmx;
+        s[2][w] = ymn;
+        s[3][w] = ymx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) {
+            xmn = fminf(xmn, s[0][k]);
+            xmx = fmaxf(xmx, s[1][k]);
+            ymn = fminf(ymn, s[2][k]);
+            ymx = fmaxf(ymx, s[3][k]);
+        }
+        mm[b * 4 + 0] = xmn;
+        mm[b * 4 + 1] = xmx;
+        mm[b * 4 + 2] = ymn;
+        mm[b * 4 + 3] = ymx;
+    }
+}
+
+// MODE 0: P2 grid (bbox-normalised, cell = x_pix*D + y_pix).  MODE 1: P1 grid (fixed, cell = y_pix*D + x_pix).
+template <int MODE>
+__global__ __launch_bounds__(1024) void scatter_max_kernel(const float* __restrict__ vals, const float* __restrict__ xy,
+                                                           long plot_stride, int N, int D, const float* __restrict__ mm,
+                                                           float sf, float off, unsigned long long* __restrict__ keys,
+                                                           int* __restrict__ pix) {
+    extern __shared__ unsigned long long s_keys[];  // D*D*3
+    const int b = blockIdx.y;
+    const int ncell3 = D * D * 3;
+    for (int i = threadIdx.x; i < ncell3; i += 1024) s_keys[i] = 0ull;
+    __syncthreads();
+    const float* x = xy + (size_t)b * plot_stride;
+    const float* y = x + N;
+    float xmn = 0.f, xmx = 0.f, ymn = 0.f, ymx = 0.f;
+    if (MODE == 0) {
+        xmn = mm[b * 4 + 0];
+        xmx = mm[b * 4 + 1];
+        ymn = mm[b * 4 + 2];
+        ymx = mm[b * 4 + 3];
+    }
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(N, lo + per);
+    for (int n = lo + threadIdx.x; n < hi; n += 1024) {
+        int cell;
+        if (MODE == 0) {
+            cell = p2_pix(x[n], xmn, xmx, D) * D + p2_pix(y[n], ymn, ymx, D);
+        } else {
+            cell = p1_pix(y[n], sf, off, D) * D + p1_pix(x[n], sf, off, D);
+        }
+        pix[(size_t)b * N + n] = cell;
+        const float4 v = reinterpret_cast<const float4*>(vals)[(size_t)b * N + n];
+        const unsigned long long tag = (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+        atomicMax(&s_keys[cell * 3 + 0], ((unsigned long long)f2ord(v.x) << 32) | tag);
+        atomicMax(&s_keys[cell * 3 + 1], ((unsigned long long)f2ord(v.z) << 32) | tag);
+        atomicMax(&s_keys[cell * 3 + 2], ((unsigned long long)f2ord(v.w) << 32) | tag);
+    }
+    __syncthreads();
+    unsigned long long* g = keys + (size_t)b * ncell3;
+    for (int i = threadIdx.x; i < ncell3; i += 1024) {
+        const unsigned long long k = s_keys[i];
+        if (k) atomicMax(&g[i], k);
+    }
+}
+
+// P2: pred[b] = mean over occupied pixels of [low, 1-low, med, high]   (project_to_2d.py:41-53)
+__global__ __launch_bounds__(256) void p2_finalize_kernel(const unsigned long long* __restrict__ keys, int D,
+                                                          int* __restrict__ arg, int* __restrict__ nocc,
+                                                          float* __restrict__ pred) {
+    __shared__ float s[5][4];
+    const int b = blockIdx.x;
+    const int ncell = D * D;
+    float lo = 0.f, so = 0.f, me = 0.f, hi = 0.f, cnt = 0.f;
+    for (int c = threadIdx.x; c < ncell; c += 256) {
+        const size_t base = ((size_t)b * ncell + c) * 3;
+        const unsigned long long k0 = keys[base], k1 = keys[base + 1], k2 = keys[base + 2];
+        if (k0) {
+            const float l = ord2f((uint32_t)(k0 >> 32));
+            lo += l;
+            so += 1.0f - l;
+            me += ord2f((uint32_t)(k1 >> 32));
+            hi += ord2f((uint32_t)(k2 >> 32));
+            cnt += 1.f;
+            arg[base + 0] = (int)(0xFFFFFFFFu - (uint32_t)(k0 & 0xFFFFFFFFull));
+            arg[base + 1] = (int)(0xFFFFFFFFu - (uint32_t)(k1 & 0xFFFFFFFFull));
+            arg[base + 2] = (int)(0xFFFFFFFFu - (uint32_t)(k2 & 0xFFFFFFFFull));
+        } else {
+            arg[base + 0] = arg[base + 1] = arg[base + 2] = -1;
+        }
+    }
+    lo = wave_sum(lo);
+    so = wave_sum(so);
+    me = wave_sum(me);
+    hi = wave_sum(hi);
+    cnt = wave_sum(cnt);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s[0][w] = lo;
+        s[1][w] = so;
+        s[2][w] = me;
+        s[3][w] = hi;
+        s[4][w] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[5];
+        for (int q = 0; q < 5; ++q) t[q] = (s[q][0] + s[q][1]) + (s[q][2] + s[q][3]);
+        const float n = fmaxf(t[4], 1.f);
+        pred[b * 4 + 0] = t[0] / n;
+        pred[b * 4 + 1] = t[1] / n;
+        pred[b * 4 + 2] = t[2] / n;
+        pred[b * 4 + 3] = t[3] / n;
+        nocc[b] = (int)t[4];
+    }
+}
+
+__global__ void p2_backward_kernel(const float* __restrict__ dpred, const int* __restrict__ arg,
+                                   const int* __restrict__ nocc, int B, int N, int D, float* __restrict__ dpw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per_plot = D * D * 3;
+    if (i >= B * per_plot) return;
+    const int b = i / per_plot, slot = i % 3;
+    const int n = arg[i];
+    if (n < 0 || n >= N) return;
+    const float inv = 1.0f / fmaxf((float)nocc[b], 1.f);
+    float g;
+    int ch;
+    if (slot == 0) {  // low vegetation also feeds bare soil = 1 - low
+        g = (dpred[b * 4 + 0] - dpred[b * 4 + 1]) * inv;
+        ch = 0;
+    } else {
+        ch = slot + 1;
+        g = dpred[b * 4 + ch] * inv;
+    }
+    dpw[((size_t)b * N + n) * 4 + ch] = g;
+}
+
+// P1: rasters (B,3,D,D) [low,med,high], image[y][x], NaN where empty, rows flipped (project_to_2d.py:80-113)
+__global__ void p1_finalize_kernel(const unsigned long long* __restrict__ keys, int B, int D, float* __restrict__ rasters) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ncell = D * D;
+    if (i >= B * ncell * 3) return;
+    const int b = i / (ncell * 3), rem = i - b * ncell * 3;
+    const int cell = rem / 3, slot = rem - cell * 3;
+    const int y = cell / D, x = cell - y * D;
+    const unsigned long long k = keys[i];
+    const float v = k ? ord2f((uint32_t)(k >> 32)) : __uint_as_float(0x7FC00000u);
+    rasters[(((size_t)b * 3 + slot) * D + (D - 1 - y)) * D + x] = v;
+}
+
+int grid_slices(int N) {
+    int s = sn2_cdiv(N, 4096);
+    return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
+}  // namespace
+
+extern "C" int sn2_plot_project_forward(const float* pred_pointwise, const float* cloud_xy, long plot_stride, int B, int N,
+                                        int D, unsigned long long* keys, int* pix, int* arg, int* nocc, float* pred,
+                                        void* stream) {
+    if (!pred_pointwise || !cloud_xy || !keys || !pix || !arg || !nocc || !pred || B <= 0 || N <= 0 || D <= 0)
+        return SN2_EINVAL;
+    if (D * D > MAX_CELLS || plot_stride < 2L * N) return SN2_ELIMIT;
+    hipStream_t st = (hipStream_t)stream;
+    // the first 4*B floats of `pred` double as the per-plot (xmin,xmax,ymin,ymax) scratch until the finalisation
+    float* mm = pred;
+    hipError_t e = hipMemsetAsync(keys, 0, (size_t)B * D * D * 3 * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(plot_minmax_kernel, dim3(B), dim3(1024), 0, st, cloud_xy, plot_stride, N, mm);
+    hipLaunchKernelGGL((scatter_max_kernel<0>), dim3(grid_slices(N), B), dim3(1024), (size_t)D * D * 3 * 8, st,
+                       pred_pointwise, cloud_xy, plot_stride, N, D, (const float*)mm, 0.f, 0.f, keys, pix);
+    hipLaunchKernelGGL(p2_finalize_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long*)keys, D, arg, nocc, pred);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_plot_project_backward(const float* dpred, const int* arg, const int* nocc, int B, int N, int D,
+                                         float* dpointwise, void* stream) {
+    if (!dpred || !arg || !nocc || !dpointwise || B <= 0 || N <= 0 || D <= 0) return SN2_EINVAL;
+    hipLaunchKernelGGL(p2_backward_kernel, dim3(sn2_cdiv((long)B * D * D * 3, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dpred, arg, nocc, B, N, D, dpointwise);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_raster_project(const float* coverages, const float* cloud_xy, long plot_stride, int B, int N, int D,
+                                  int diam_meters, unsigned long long* keys, int* pix, float* rasters, void* stream) {
+    if (!coverages || !cloud_xy || !keys || !pix || !rasters || B <= 0 || N <= 0 || D <= 0 || diam_meters <= 0)
+        return SN2_EINVAL;
+    if (D * D > MAX_CELLS || plot_stride < 2L * N) return SN2_ELIMIT;
+    hipStream_t st = (hipStream_t)stream;
+    const float sf = (float)(10.0 * ((double)D / (double)diam_meters));  // python: 10 * (diam_pix / diam_meters)
+    const float off = (float)(diam_meters / 2);                           // diam_meters // 2
+    hipError_t e = hipMemsetAsync(keys, 0, (size_t)B * D * D * 3 * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((scatter_max_kernel<1>), dim3(grid_slices(N), B), dim3(1024), (size_t)D * D * 3 * 8, st, coverages,
+                       cloud_xy, plot_stride, N, D, (const float*)nullptr, sf, off, keys, pix);
+    hipLaunchKernelGGL(p1_finalize_kernel, dim3(sn2_cdiv((long)B * D * D * 3, 256)), dim3(256), 0, st,
+                       (const unsigned long long*)keys, B, D, rasters);
+    SN2_RETURN_LAUNCH();
+}

@@ -1,0 +1,372 @@
+"""Host-side wrappers of the C ABI (include/strata_hip.h): PyTorch-ROCm tensors in, raw device pointers across
+`ctypes`, torch's current stream.  Every wrapper validates dtype / device / contiguity / shape on the host before a
+kernel is launched (a kernel that faults can take the whole node down) and raises on a non-zero return code.
+
+Names follow the reference's third-party call sites (model/point_net2.py:9): fps, radius -> ball_query,
+knn_interpolate -> three_nn + the interpolation inside `fp_forward`, PointConv -> `sa_forward`.
+"""
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FP, SA, Block, Head, check
+
+I32, F32, F64, I64 = torch.int32, torch.float32, torch.float64, torch.int64
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, shape=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a tensor on the HIP device")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _chk_rows(t: torch.Tensor, dtype, rows: int, cols: int, name="rows", align: int = 4) -> int:
+    """A 2-D row view (rows, >=cols) with unit inner stride; returns the row stride in elements.  Row starts must be
+    16-byte aligned when align == 4 (the kernels read rows with 16-byte loads)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != dtype or t.dim() != 2:
+        raise ValueError(f"{name}: expected a 2-D {dtype} tensor on the HIP device")
+    if t.shape[0] != rows or t.shape[1] < cols or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected ({rows}, >={cols}) with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+    st = t.stride(0) if rows > 1 else max(t.stride(0), t.shape[1])
+    if align > 1 and (st % align or (t.data_ptr() % (4 * align))):
+        raise ValueError(f"{name}: rows must be {4 * align}-byte aligned")
+    return st
+
+
+def fps_num_samples(n: int, ratio: float) -> int:
+    """ceil(fp32(n) * fp32(ratio)) -- torch-cluster 1.5.9 `fps` sample count (see oracle/primitives.py)."""
+    return int(math.ceil(float(np.float32(n) * np.float32(ratio))))
+
+
+def r2_threshold(r: float) -> float:
+    """fp32(r*r) with r*r evaluated in double: what `radius` compares squared distances with."""
+    return float(np.float32(float(r) * float(r)))
+
+
+# ---------------------------------------------------------------------------------------------- geometry
+def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor) -> torch.Tensor:
+    B, C, N = cloud.shape
+    _chk(cloud, F32, (B, C, N), "cloud")
+    _chk(xyz, F32, (B, 3, N), "xyz")
+    rows0 = torch.empty(B * N, 12, dtype=F32, device=cloud.device)
+    check(_lib.load().sn2_pack_rows(_ptr(cloud), _ptr(xyz), B, C, N, _ptr(rows0), _stream()), "sn2_pack_rows")
+    return rows0
+
+
+def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None):
+    """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4)."""
+    B, three, N = pos_soa.shape
+    _chk(pos_soa, F32, (B, 3, N), "pos_soa")
+    if not (1 <= m <= N):
+        raise ValueError(f"fps: need 1 <= m <= N, got m={m}, N={N}")
+    if start is not None:
+        _chk(start, I32, (B,), "start")
+    dev = pos_soa.device
+    idx = torch.empty(B, m, dtype=I32, device=dev)
+    cs = torch.empty(B, 3, m, dtype=F32, device=dev)
+    ca = torch.empty(B * m, 4, dtype=F32, device=dev)
+    check(_lib.load().sn2_fps(_ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _stream()), "sn2_fps")
+    return idx, cs, ca
+
+
+def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int = _lib.MAX_NEIGHBORS,
+               total: Optional[torch.Tensor] = None):
+    """-> nbr (B*M,cap) int32 (first cnt entries valid, ascending source index), cnt (B*M) int32, total (1) int64."""
+    B, _, N = src_soa.shape
+    M = cpos_soa.shape[2]
+    _chk(src_soa, F32, (B, 3, N), "src_soa")
+    _chk(cpos_soa, F32, (B, 3, M), "cpos_soa")
+    cap = min(cap, N)
+    dev = src_soa.device
+    nbr = torch.empty(B * M, cap, dtype=I32, device=dev)
+    cnt = torch.empty(B * M, dtype=I32, device=dev)
+    if total is None:
+        total = torch.zeros(1, dtype=I64, device=dev)
+    else:
+        _chk(total, I64, (1,), "total")
+    check(_lib.load().sn2_ball_query(_ptr(src_soa), B, N, _ptr(cpos_soa), M, r2_threshold(r), cap, _ptr(nbr), _ptr(cnt),
+                                     _ptr(total), _stream()), "sn2_ball_query")
+    return nbr, cnt, total
+
+
+def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int):
+    """-> idx (B*T,3) int32 local source indices, w (B*T,3) = 1/max(d2,1e-16) (0 on unused slots)."""
+    B, _, S = src_soa.shape
+    T = dst_soa.shape[2]
+    _chk(src_soa, F32, (B, 3, S), "src_soa")
+    _chk(dst_soa, F32, (B, 3, T), "dst_soa")
+    dev = src_soa.device
+    idx = torch.empty(B * T, 3, dtype=I32, device=dev)
+    w = torch.empty(B * T, 3, dtype=F32, device=dev)
+    check(_lib.load().sn2_three_nn(_ptr(src_soa), B, S, _ptr(dst_soa), T, k, _ptr(idx), _ptr(w), _stream()), "sn2_three_nn")
+    return idx, w
+
+
+# ---------------------------------------------------------------------------------------------- blocks
+class BlockBuffers:
+    """Device-side companions of one (Linear -> ReLU -> BatchNorm1d) block: affine (a, c), saved batch statistics,
+    fp64 accumulators.  `params` = (W, b, gamma, beta, running_mean, running_var) tensors of the nn modules."""
+
+    def __init__(self, lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d, aux: Optional[torch.Tensor] = None,
+                 stats: Optional[torch.Tensor] = None):
+        self.lin, self.bn = lin, bn
+        self.cin, self.cout = lin.in_features, lin.out_features
+        dev = lin.weight.device
+        # aux rows: a, c, mean, invstd (fp32);  stats rows: sum, sumsq (fp64, must be zero before a training forward)
+        self.aux = torch.empty(4, self.cout, dtype=F32, device=dev) if aux is None else aux
+        self.stats = torch.zeros(2, self.cout, dtype=F64, device=dev) if stats is None else stats
+        _chk(self.aux, F32, (4, self.cout), "aux")
+        _chk(self.stats, F64, (2, self.cout), "stats")
+        self.grads = None                                                 # (dW, db, dgamma, dbeta) views, set per backward
+
+    def fill(self, blk: Block, with_grads: bool = False):
+        for t, n in ((self.lin.weight, "weight"), (self.lin.bias, "bias"), (self.bn.weight, "bn.weight"),
+                     (self.bn.bias, "bn.bias"), (self.bn.running_mean, "running_mean"),
+                     (self.bn.running_var, "running_var")):
+            _chk(t, F32, None, n)
+        blk.cin, blk.cout = self.cin, self.cout
+        blk.W, blk.b = _ptr(self.lin.weight), _ptr(self.lin.bias)
+        blk.gamma, blk.beta = _ptr(self.bn.weight), _ptr(self.bn.bias)
+        blk.running_mean, blk.running_var = _ptr(self.bn.running_mean), _ptr(self.bn.running_var)
+        blk.a, blk.c, blk.mean, blk.invstd = (_ptr(self.aux[i]) for i in range(4))
+        blk.sum, blk.sumsq = _ptr(self.stats[0]), _ptr(self.stats[1])
+        if with_grads:
+            dW, db, dg, dbeta = self.grads
+            for t, ref in ((dW, self.lin.weight), (db, self.lin.bias), (dg, self.bn.weight), (dbeta, self.bn.bias)):
+                _chk(t, F32, ref.shape, "grad view")
+            blk.dW, blk.db, blk.dgamma, blk.dbeta = _ptr(dW), _ptr(db), _ptr(dg), _ptr(dbeta)
+        else:
+            blk.dW = blk.db = blk.dgamma = blk.dbeta = None
+
+    @property
+    def a(self):
+        return self.aux[0]
+
+    @property
+    def c(self):
+        return self.aux[1]
+
+
+def sa_desc(blocks, feat, cf, spos, cpos_aos, nbr, cnt, total, B, Nsrc, M, ext, arg, out, dout=None, dfeat=None,
+            with_grads=False) -> SA:
+    """feat: (B*Nsrc, >=cf) row view; spos: (B*Nsrc, >=4) row view holding x,y,z,."""
+    cap = nbr.shape[1]
+    cl = blocks[-1].cout
+    feat_stride = _chk_rows(feat, F32, B * Nsrc, cf, "feat")
+    spos_stride = _chk_rows(spos, F32, B * Nsrc, 4, "spos")
+    _chk(cpos_aos, F32, (B * M, 4), "cpos_aos")
+    _chk(nbr, I32, (B * M, cap), "nbr")
+    _chk(cnt, I32, (B * M,), "cnt")
+    _chk(total, I64, (1,), "total")
+    _chk(ext, F32, (B * M, cl), "ext")
+    _chk(arg, I32, (B * M, cl), "arg")
+    _chk(out, F32, (B * M, cl), "out")
+    d = SA()
+    d.B, d.Nsrc, d.M, d.cap, d.cf, d.nl = B, Nsrc, M, cap, cf, len(blocks)
+    d.feat, d.feat_stride, d.spos, d.spos_stride = _ptr(feat), feat_stride, _ptr(spos), spos_stride
+    d.cpos, d.nbr, d.cnt, d.total = _ptr(cpos_aos), _ptr(nbr), _ptr(cnt), _ptr(total)
+    for i, bb in enumerate(blocks):
+        bb.fill(d.blk[i], with_grads)
+    d.ext, d.arg, d.out = _ptr(ext), _ptr(arg), _ptr(out)
+    if dout is not None:
+        _chk(dout, F32, (B * M, cl), "dout")
+    if dfeat is not None:
+        _chk(dfeat, F32, (B * Nsrc, cf), "dfeat")
+    d.dout, d.dfeat = _ptr(dout), _ptr(dfeat)
+    return d
+
+
+def sa_forward(d: SA, training: bool):
+    check(_lib.load().sn2_sa_forward(d, int(training), _stream()), "sn2_sa_forward")
+
+
+def sa_backward(d: SA):
+    check(_lib.load().sn2_sa_backward(d, _stream()), "sn2_sa_backward")
+
+
+def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
+            dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False) -> FP:
+    """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view."""
+    R = B * R_per_plot
+    hs = (block.cout + 3) // 4 * 4
+    n_src_rows = R if knn is None else B * S_per_plot
+    src_stride = _chk_rows(src, F32, n_src_rows, ca, "src")
+    if src.shape[1] < (ca + 3) // 4 * 4 and src_stride < (ca + 3) // 4 * 4:
+        raise ValueError("fp: src rows must be padded to a multiple of 4 floats")
+    _chk(h, F32, (R, hs), "h")
+    d = FP()
+    d.B, d.R_per_plot, d.S_per_plot, d.ca, d.cb = B, R_per_plot, S_per_plot, ca, cb
+    d.src, d.src_stride = _ptr(src), src_stride
+    if src_affine is not None:
+        _chk(src_affine[0], F32, (ca,), "src_a")
+        _chk(src_affine[1], F32, (ca,), "src_c")
+        d.src_a, d.src_c = _ptr(src_affine[0]), _ptr(src_affine[1])
+    else:
+        d.src_a = d.src_c = None
+    if knn is not None:
+        _chk(knn[0], I32, (R, 3), "knn_idx")
+        _chk(knn[1], F32, (R, 3), "knn_w")
+        d.knn_idx, d.knn_w = _ptr(knn[0]), _ptr(knn[1])
+    else:
+        d.knn_idx = d.knn_w = None
+    if cb > 0:
+        d.skip_stride = _chk_rows(skip, F32, R, cb, "skip", align=4 if cb % 4 == 0 else 1)
+        d.skip = _ptr(skip)
+    else:
+        d.skip, d.skip_stride = None, 0
+    block.fill(d.blk, with_grads)
+    d.h, d.h_stride = _ptr(h), hs
+    if dy is not None:
+        _chk(dy, F32, (R, hs), "dy")
+    d.dsrc_stride = d.dskip_stride = 0
+    if dsrc is not None:
+        d.dsrc_stride = _chk_rows(dsrc, F32, n_src_rows, ca, "dsrc", align=1)
+    if dskip is not None:
+        d.dskip_stride = _chk_rows(dskip, F32, R, cb, "dskip", align=1)
+    if du_scratch is not None:
+        _chk(du_scratch, F32, (R, ca), "du_scratch")
+    d.dy, d.dsrc, d.dskip, d.du_scratch = _ptr(dy), _ptr(dsrc), _ptr(dskip), _ptr(du_scratch)
+    return d
+
+
+def fp_forward(d: FP, training: bool):
+    check(_lib.load().sn2_fp_forward(d, int(training), _stream()), "sn2_fp_forward")
+
+
+def fp_backward(d: FP):
+    check(_lib.load().sn2_fp_backward(d, _stream()), "sn2_fp_backward")
+
+
+def plot_max_forward(h, a, c, B, R_per_plot, C):
+    hs = (C + 3) // 4 * 4
+    _chk(h, F32, (B * R_per_plot, hs), "h")
+    _chk(a, F32, (C,), "a")
+    _chk(c, F32, (C,), "c")
+    out = torch.empty(B, C, dtype=F32, device=h.device)
+    arg = torch.empty(B, C, dtype=I32, device=h.device)
+    check(_lib.load().sn2_plot_max_forward(_ptr(h), _ptr(a), _ptr(c), B, R_per_plot, C, _ptr(out), _ptr(arg), _stream()),
+          "sn2_plot_max_forward")
+    return out, arg
+
+
+def plot_max_backward(dout, arg, B, R_per_plot, C, dy):
+    hs = (C + 3) // 4 * 4
+    _chk(dout, F32, (B, C), "dout")
+    _chk(arg, I32, (B, C), "arg")
+    _chk(dy, F32, (B * R_per_plot, hs), "dy")
+    check(_lib.load().sn2_plot_max_backward(_ptr(dout), _ptr(arg), B, R_per_plot, C, _ptr(dy), _stream()),
+          "sn2_plot_max_backward")
+
+
+def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dproba=None, dy=None, grads=None) -> Head:
+    R = f.shape[0]
+    _chk(f, F32, (R, 36), "f")
+    _chk(fa, F32, (34,), "fa")
+    _chk(fc, F32, (34,), "fc")
+    _chk(lin1.weight, F32, (16, 34), "lin1.weight")
+    _chk(lin1.bias, F32, (16,), "lin1.bias")
+    _chk(lin2.weight, F32, (5, 16), "lin2.weight")
+    _chk(lin2.bias, F32, (5,), "lin2.bias")
+    d = Head()
+    d.R, d.cin, d.f_stride = R, 34, 36
+    d.f, d.fa, d.fc = _ptr(f), _ptr(fa), _ptr(fc)
+    d.W1, d.b1, d.W2, d.b2 = _ptr(lin1.weight), _ptr(lin1.bias), _ptr(lin2.weight), _ptr(lin2.bias)
+    for t, n in ((coverages, "coverages"), (proba, "proba"), (dcov, "dcoverages"), (dproba, "dproba")):
+        if t is not None:
+            _chk(t, F32, (R, 4), n)
+    d.coverages, d.proba, d.dcoverages, d.dproba = _ptr(coverages), _ptr(proba), _ptr(dcov), _ptr(dproba)
+    if dy is not None:
+        _chk(dy, F32, (R, 36), "dy")
+    d.dy = _ptr(dy)
+    if grads is not None:
+        for t, ref in zip(grads, (lin1.weight, lin1.bias, lin2.weight, lin2.bias)):
+            _chk(t, F32, ref.shape, "head grad view")
+        d.dW1, d.db1, d.dW2, d.db2 = (_ptr(t) for t in grads)
+    else:
+        d.dW1 = d.db1 = d.dW2 = d.db2 = None
+    return d
+
+
+def head_forward(d: Head):
+    check(_lib.load().sn2_head_forward(d, _stream()), "sn2_head_forward")
+
+
+def head_backward(d: Head):
+    check(_lib.load().sn2_head_backward(d, _stream()), "sn2_head_backward")
+
+
+# ---------------------------------------------------------------------------------------------- projections
+def _xy_rows(clouds_dev: torch.Tensor):
+    """clouds (B,C>=2,N) on device -> (pointer tensor, plot stride in floats)."""
+    B, C, N = clouds_dev.shape
+    _chk(clouds_dev, F32, (B, C, N), "clouds")
+    if C < 2:
+        raise ValueError("clouds needs at least the x and y rows")
+    return clouds_dev, C * N
+
+
+def plot_project_forward(pred_pointwise: torch.Tensor, clouds_dev: torch.Tensor, diam_pix: int):
+    B, C, N = clouds_dev.shape
+    _chk(pred_pointwise, F32, (B * N, 4), "pred_pointwise")
+    t, stride = _xy_rows(clouds_dev)
+    dev = pred_pointwise.device
+    D = int(diam_pix)
+    keys = torch.empty(B * D * D * 3, dtype=I64, device=dev)
+    pix = torch.empty(B * N, dtype=I32, device=dev)
+    arg = torch.empty(B * D * D * 3, dtype=I32, device=dev)
+    nocc = torch.empty(B, dtype=I32, device=dev)
+    pred = torch.empty(B, 4, dtype=F32, device=dev)
+    check(_lib.load().sn2_plot_project_forward(_ptr(pred_pointwise), _ptr(t), stride, B, N, D, _ptr(keys), _ptr(pix),
+                                               _ptr(arg), _ptr(nocc), _ptr(pred), _stream()), "sn2_plot_project_forward")
+    return pred, pix, arg, nocc
+
+
+def plot_project_backward(dpred, arg, nocc, B, N, diam_pix):
+    D = int(diam_pix)
+    _chk(dpred, F32, (B, 4), "dpred")
+    _chk(arg, I32, (B * D * D * 3,), "arg")
+    _chk(nocc, I32, (B,), "nocc")
+    dpw = torch.zeros(B * N, 4, dtype=F32, device=dpred.device)
+    check(_lib.load().sn2_plot_project_backward(_ptr(dpred), _ptr(arg), _ptr(nocc), B, N, D, _ptr(dpw), _stream()),
+          "sn2_plot_project_backward")
+    return dpw
+
+
+def raster_project(coverages: torch.Tensor, clouds_dev: torch.Tensor, diam_pix: int, diam_meters: int):
+    """coverages (B*N,4), clouds (B,C,N) -> rasters (B,3,D,D) fp32 with NaN, pix (B*N) int32."""
+    B, C, N = clouds_dev.shape
+    _chk(coverages, F32, (B * N, 4), "coverages")
+    t, stride = _xy_rows(clouds_dev)
+    dev = coverages.device
+    D = int(diam_pix)
+    keys = torch.empty(B * D * D * 3, dtype=I64, device=dev)
+    pix = torch.empty(B * N, dtype=I32, device=dev)
+    rasters = torch.empty(B, 3, D, D, dtype=F32, device=dev)
+    check(_lib.load().sn2_raster_project(_ptr(coverages), _ptr(t), stride, B, N, D, int(diam_meters), _ptr(keys),
+                                         _ptr(pix), _ptr(rasters), _stream()), "sn2_raster_project")
+    return rasters, pix
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    n = param.numel()
+    for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, F32, (n,), nme)
+    check(_lib.load().sn2_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
+                                    weight_decay, int(step), grad_scale, _stream()), "sn2_adam_step")

@@ -1,0 +1,369 @@
+"""PointNet2 -- drop-in for the reference `model/point_net2.py` (IGNF/StrataNet2), MI355X-native underneath.
+
+Same public surface as the reference class (`/root/reference/model/point_net2.py:70-220`): constructor fields read
+from `args`, `forward(cloud_data) -> (coverages_pointwise, proba_pointwise)`, `get_long_form`, `get_batch_format`,
+early-stopping / checkpoint helpers, and a `state_dict()` with the reference's exact keys and shapes
+(`sa1_module.conv.local_nn.0.0.weight`, ..., `lin2.bias`), so reference checkpoints load and the reference training
+and inference drivers (`learning/train.py:53-56`, `predict.py:103-114`) can call it unchanged.
+
+Underneath, `forward` is ONE autograd node whose forward and backward are sequences of hand-written HIP kernels
+(libstrata_hip.so via ctypes, raw device pointers, torch's current stream): FPS -> ball query -> fused
+gather+MLP+BN+max (SA1, SA2) -> global SA -> 3-NN interpolation + MLP (FP3..FP1) -> head.  No torch_cluster /
+torch_scatter / torch_geometric, no per-edge tensors, no host synchronisation anywhere in a step.
+
+Additive extension: `cloud_data["fps_start"]` -- int tensor (2,B) of LOCAL start indices for the two FPS calls
+(the reference's `fps` starts at a C `rand()` point and is unseeded).  Absent: random starts
+drawn with torch's generator in training mode... the reference draws them in eval mode too, so does this class.
+"""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+from torch.nn import BatchNorm1d as BN
+from torch.nn import Linear as Lin
+from torch.nn import ReLU
+from torch.nn import Sequential as Seq
+
+from . import hip_ops as ops
+from ._lib import MAX_NEIGHBORS, StrataHipError
+
+F32, I32, I64, F64 = torch.float32, torch.int32, torch.int64, torch.float64
+
+
+def MLP(channels):
+    """(Linear -> ReLU -> BatchNorm1d) blocks with the reference's module nesting, hence its state-dict keys
+    `<i>.0.*` (Linear) and `<i>.2.*` (BatchNorm)  -- model/point_net2.py:45-53."""
+    return Seq(*[Seq(Lin(channels[i - 1], channels[i]), ReLU(), BN(channels[i])) for i in range(1, len(channels))])
+
+
+class PointConv(nn.Module):
+    """Parameter holder named like torch_geometric's PointConv (`.local_nn`); the computation is sn2_sa_forward."""
+
+    def __init__(self, local_nn):
+        super().__init__()
+        self.local_nn = local_nn
+
+
+class SAModule(nn.Module):
+    def __init__(self, ratio, r, nn_):
+        super().__init__()
+        self.ratio, self.r = ratio, r
+        self.conv = PointConv(nn_)
+
+
+class GlobalSAModule(nn.Module):
+    def __init__(self, nn_):
+        super().__init__()
+        self.nn = nn_
+
+
+class FPModule(nn.Module):
+    def __init__(self, k, nn_):
+        super().__init__()
+        self.k = k
+        self.nn = nn_
+
+
+class _Saved:
+    """Everything the backward pass needs from one forward (device tensors + sizes)."""
+    pass
+
+
+def _blocks_of(seq, aux_arena, stats_arena, cursor):
+    out = []
+    for blk in seq:
+        lin, bn = blk[0], blk[2]
+        c = lin.out_features
+        aux = aux_arena[cursor[0]:cursor[0] + 4 * c].view(4, c)
+        st = stats_arena[cursor[1]:cursor[1] + 2 * c].view(2, c)
+        cursor[0] += 4 * c
+        cursor[1] += 2 * c
+        out.append(ops.BlockBuffers(lin, bn, aux, st))
+    return out
+
+
+class _PointNet2Fn(torch.autograd.Function):
+    """forward/backward of the whole network as one autograd node; `params` are passed so autograd routes their
+    gradients, the kernels read them through the modules (same storage)."""
+
+    @staticmethod
+    def forward(ctx, model, xyz, cloud, fps_start, *params):
+        training = model.training
+        need_grad = training and torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training)
+        ctx.model = model
+        ctx.saved = saved if need_grad else None
+        ctx.n_params = len(params)
+        return cov, proba
+
+    @staticmethod
+    def backward(ctx, dcov, dproba):
+        if ctx.saved is None:
+            raise RuntimeError("PointNet2: backward through an eval-mode / no-grad forward")
+        grads = ctx.model._backward_impl(ctx.saved, dcov, dproba)
+        ctx.saved = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class PointNet2(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.cuda_device = args.cuda
+        self.subsample_size = args.subsample_size
+        self.n_class = args.n_class
+        self.drop = args.drop
+        self.n_input_feats = args.n_input_feats - 2  # x and y are not fed to the network (point_net2.py:77)
+        self.set_patience_attributes(args)
+        self.log_embeddings = args.log_embeddings
+        self.last_G_tensor = None
+        if self.n_class != 4 or self.n_input_feats != 8:
+            raise ValueError("the HIP kernels cover the reference architecture: n_class=4, 10 input features")
+        ndim = 3
+        mlp1 = [self.n_input_feats + ndim, 16, 16]
+        mlp2 = [mlp1[-1] + ndim, 32]
+        mlp3 = [mlp2[-1] + ndim, 64]
+        # construction order = the reference's (point_net2.py:84-96): same RNG stream => same default weights
+        self.sa1_module = SAModule(args.ratio1, args.r1, MLP(mlp1))
+        self.sa2_module = SAModule(args.ratio2, args.r2, MLP(mlp2))
+        self.sa3_module = GlobalSAModule(MLP(mlp3))
+        mlp3_fp = [mlp3[-1] + mlp2[-1], 64]
+        mlp2_fp = [mlp3_fp[-1] + mlp1[-1], 34]
+        mlp1_fp = [mlp2_fp[-1] + self.n_input_feats, 34]
+        self.fp3_module = FPModule(1, MLP(mlp3_fp))
+        self.fp2_module = FPModule(3, MLP(mlp2_fp))
+        self.fp1_module = FPModule(3, MLP(mlp1_fp))
+        self.lin1 = nn.Linear(mlp1_fp[-1], 16)
+        self.lin2 = nn.Linear(16, self.n_class + 1)
+        self.lin2.bias = nn.Parameter(torch.tensor([0.733, 0.266, 0.235, 0.358, 0.500]))  # point_net2.py:97-99
+        self.softmax = nn.Softmax(dim=1)
+        self.sigmoid = nn.Sigmoid()
+        if self.cuda_device is not None:
+            self.cuda(self.cuda_device)
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, cloud_data):
+        cloud, xyz = cloud_data["cloud"], cloud_data["xyz"]
+        dev = self.lin1.weight.device
+        if dev.type != "cuda":
+            raise StrataHipError("PointNet2.forward needs a HIP device (args.cuda): the product path has no CPU "
+                                 "fallback; the CPU restatement lives in oracle/ and is test infrastructure")
+        if cloud.dim() != 3 or cloud.shape[1] != self.n_input_feats + 2 or xyz.shape != (cloud.shape[0], 3, cloud.shape[2]):
+            raise ValueError(f"expected cloud (B,{self.n_input_feats + 2},N) and xyz (B,3,N), got "
+                             f"{tuple(cloud.shape)} and {tuple(xyz.shape)}")
+        if self.training and self.drop > 0:
+            raise NotImplementedError("dropout p > 0 (reference default 0.0, config.py:76) is not in the HIP head yet")
+        with torch.cuda.device(dev):
+            cloud_d = cloud.to(device=dev, dtype=F32, non_blocking=True).contiguous()
+            xyz_d = xyz.to(device=dev, dtype=F32, non_blocking=True).contiguous()
+            B, _, N = cloud_d.shape
+            fs = cloud_data.get("fps_start", None) if isinstance(cloud_data, dict) else None
+            if fs is None:
+                # reference behaviour: an independent random start per plot and per FPS call
+                m1 = ops.fps_num_samples(N, self.sa1_module.ratio)
+                fs = torch.stack([torch.randint(0, N, (B,)), torch.randint(0, m1, (B,))])
+            fs = torch.as_tensor(fs).to(device=dev, dtype=I32, non_blocking=True).contiguous()
+            if fs.shape != (2, B):
+                raise ValueError(f"fps_start must have shape (2,{B})")
+            self._last_cloud_dev = (cloud, cloud_d)  # lets project_to_plotwise_coverages skip a second H2D copy
+            params = [p for p in self.parameters()]
+            cov, proba = _PointNet2Fn.apply(self, xyz_d, cloud_d, fs, *params)
+        return cov, proba
+
+    def _sizes(self, N):
+        M1 = ops.fps_num_samples(N, self.sa1_module.ratio)
+        M2 = ops.fps_num_samples(M1, self.sa2_module.ratio)
+        return M1, M2
+
+    def _forward_impl(self, xyz, cloud, fps_start, training):
+        dev = xyz.device
+        B, _, N = xyz.shape
+        M1, M2 = self._sizes(N)
+        s = _Saved()
+        s.B, s.N, s.M1, s.M2 = B, N, M1, M2
+        # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd (fp32) and sum,sumsq (fp64)
+        widths = [16, 16, 32, 64, 64, 34, 34]
+        aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)
+        stats = torch.zeros(2 * sum(widths), dtype=F64, device=dev)
+        cur = [0, 0]
+        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur)
+        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur)
+        s.b_sa3 = _blocks_of(self.sa3_module.nn, aux, stats, cur)[0]
+        s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur)[0]
+        s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur)[0]
+        s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
+        s.aux, s.stats = aux, stats
+        totals = torch.zeros(2, dtype=I64, device=dev)
+
+        # ---- level 0 rows: [8 features | x y z 0]
+        s.rows0 = ops.pack_rows(cloud, xyz)
+        s.xyz = xyz
+        # ---- SA1: fps -> ball query -> gather + MLP[11,16,16] + BN + max      (point_net2.py:131, 21-29)
+        s.idx1, s.pos1_soa, s.pos1_aos = ops.fps(xyz, M1, fps_start[0])
+        s.nbr1, s.cnt1, s.tot1 = ops.ball_query(xyz, s.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, totals[0:1])
+        s.ext1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
+        s.arg1 = torch.empty(B * M1, 16, dtype=I32, device=dev)
+        s.x1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
+        ops.sa_forward(self._sa1_desc(s), training)
+        # ---- SA2: MLP[19,32]                                                     (:132)
+        s.idx2, s.pos2_soa, s.pos2_aos = ops.fps(s.pos1_soa, M2, fps_start[1])
+        s.nbr2, s.cnt2, s.tot2 = ops.ball_query(s.pos1_soa, s.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2])
+        s.ext2 = torch.empty(B * M2, 32, dtype=F32, device=dev)
+        s.arg2 = torch.empty(B * M2, 32, dtype=I32, device=dev)
+        s.x2 = torch.empty(B * M2, 32, dtype=F32, device=dev)
+        ops.sa_forward(self._sa2_desc(s), training)
+        # ---- SA3: MLP[35,64] on cat[x2, pos2] -> per-plot max                    (:133, 37-42)
+        s.h_sa3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
+        ops.fp_forward(self._sa3_desc(s), training)
+        s.x3, s.arg3 = ops.plot_max_forward(s.h_sa3, s.b_sa3.a, s.b_sa3.c, B, M2, 64)
+        if self.log_embeddings:
+            self.last_G_tensor = s.x3
+        # ---- FP3 (k=1 from the plot's global feature at the origin), FP2, FP1 (k=3)   (:137-139, 62-67)
+        pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)
+        s.knn3 = ops.three_nn(pos3, s.pos2_soa, 1)
+        s.h3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
+        ops.fp_forward(self._fp3_desc(s), training)
+        s.knn2 = ops.three_nn(s.pos2_soa, s.pos1_soa, 3)
+        s.h2 = torch.empty(B * M1, 36, dtype=F32, device=dev)
+        ops.fp_forward(self._fp2_desc(s), training)
+        s.knn1 = ops.three_nn(s.pos1_soa, xyz, 3)
+        s.h1 = torch.empty(B * N, 36, dtype=F32, device=dev)
+        ops.fp_forward(self._fp1_desc(s), training)
+        # ---- head                                                                  (:141-151)
+        cov = torch.empty(B * N, 4, dtype=F32, device=dev)
+        proba = torch.empty(B * N, 4, dtype=F32, device=dev)
+        ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba))
+        if training:
+            torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)], 1)
+        return cov, proba, s
+
+    # ---- descriptors (shared by forward and backward; gradient views are attached for the backward call)
+    def _sa1_desc(self, s, dout=None, g=False):
+        return ops.sa_desc(s.b_sa1, s.rows0[:, 0:8], 8, s.rows0[:, 8:12], s.pos1_aos, s.nbr1, s.cnt1, s.tot1, s.B, s.N,
+                           s.M1, s.ext1, s.arg1, s.x1, dout=dout, dfeat=None, with_grads=g)
+
+    def _sa2_desc(self, s, dout=None, dfeat=None, g=False):
+        return ops.sa_desc(s.b_sa2, s.x1, 16, s.pos1_aos, s.pos2_aos, s.nbr2, s.cnt2, s.tot2, s.B, s.M1, s.M2, s.ext2,
+                           s.arg2, s.x2, dout=dout, dfeat=dfeat, with_grads=g)
+
+    def _sa3_desc(self, s, **kw):
+        return ops.fp_desc(s.b_sa3, s.B, s.M2, s.M2, 32, 3, s.x2, s.h_sa3, skip=s.pos2_aos, **kw)
+
+    def _fp3_desc(self, s, **kw):
+        return ops.fp_desc(s.b_fp3, s.B, s.M2, 1, 64, 32, s.x3, s.h3, knn=s.knn3, skip=s.x2, **kw)
+
+    def _fp2_desc(self, s, **kw):
+        return ops.fp_desc(s.b_fp2, s.B, s.M1, s.M2, 64, 16, s.h3, s.h2, src_affine=(s.b_fp3.a, s.b_fp3.c), knn=s.knn2,
+                           skip=s.x1, **kw)
+
+    def _fp1_desc(self, s, **kw):
+        return ops.fp_desc(s.b_fp1, s.B, s.N, s.M1, 34, 8, s.h2, s.h1, src_affine=(s.b_fp2.a, s.b_fp2.c), knn=s.knn1,
+                           skip=s.rows0[:, 0:8], **kw)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _backward_impl(self, s, dcov, dproba):
+        dev = s.xyz.device
+        B, N, M1, M2 = s.B, s.N, s.M1, s.M2
+        params = list(self.parameters())
+        n_flat = sum(p.numel() for p in params)
+        # one zero-filled arena: flat parameter gradient + every accumulate-into buffer of the backward chain
+        sizes = OrderedDict(flat=n_flat, dy2=B * M1 * 36, dy3=B * M2 * 64, dx1=B * M1 * 16, dx2=B * M2 * 32,
+                            dx3=B * 64, dy_sa3=B * M2 * 64)
+        offs, tot = {}, 0
+        for k, n in sizes.items():
+            offs[k] = tot
+            tot += (n + 3) // 4 * 4
+        arena = torch.zeros(tot, dtype=F32, device=dev)
+        buf = {k: arena[offs[k]:offs[k] + n] for k, n in sizes.items()}
+        flat = buf["flat"]
+        views, o = {}, 0
+        for p in params:
+            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+
+        def attach(bb):
+            bb.grads = (views[id(bb.lin.weight)], views[id(bb.lin.bias)], views[id(bb.bn.weight)], views[id(bb.bn.bias)])
+
+        for bb in s.b_sa1 + s.b_sa2 + [s.b_sa3, s.b_fp3, s.b_fp2, s.b_fp1]:
+            attach(bb)
+        dcov = None if dcov is None else dcov.contiguous()
+        dproba = None if dproba is None else dproba.contiguous()
+        # head
+        dy1 = torch.empty(B * N, 36, dtype=F32, device=dev)
+        hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
+        ops.head_backward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1,
+                                        grads=hg))
+        # FP1 -> d(fp2 output)
+        dy2 = buf["dy2"].view(B * M1, 36)
+        ops.fp_backward(self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 34, dtype=F32, device=dev),
+                                       with_grads=True))
+        # FP2 -> d(fp3 output), d x1
+        dy3, dx1 = buf["dy3"].view(B * M2, 64), buf["dx1"].view(B * M1, 16)
+        ops.fp_backward(self._fp2_desc(s, dy=dy2, dsrc=dy3, dskip=dx1,
+                                       du_scratch=torch.empty(B * M1, 64, dtype=F32, device=dev), with_grads=True))
+        # FP3 -> d x3, d x2
+        dx3, dx2 = buf["dx3"].view(B, 64), buf["dx2"].view(B * M2, 32)
+        ops.fp_backward(self._fp3_desc(s, dy=dy3, dsrc=dx3, dskip=dx2,
+                                       du_scratch=torch.empty(B * M2, 64, dtype=F32, device=dev), with_grads=True))
+        # global max pool -> SA3 rows
+        dy_sa3 = buf["dy_sa3"].view(B * M2, 64)
+        ops.plot_max_backward(dx3, s.arg3, B, M2, 64, dy_sa3)
+        ops.fp_backward(self._sa3_desc(s, dy=dy_sa3, dsrc=dx2, with_grads=True))
+        # SA2 -> d x1 ; SA1
+        ops.sa_backward(self._sa2_desc(s, dout=dx2, dfeat=dx1, g=True))
+        ops.sa_backward(self._sa1_desc(s, dout=dx1, g=True))
+        s.flat_grad = flat
+        self._last_flat_grad = flat
+        return [views[id(p)] for p in params]
+
+    # ------------------------------------------------------------------------------------------ layout helpers
+    @staticmethod
+    def get_long_form(data):
+        """(B,f,N) -> (B*N,f), plot-major (point_net2.py:155-158)."""
+        B, f, N = data.shape
+        return data.permute(1, 0, 2).reshape(f, B * N).transpose(1, 0)
+
+    def get_batch_format(self, data):
+        """(B*N,f) -> (B,f,N) (point_net2.py:160-163)."""
+        n = self.subsample_size
+        return data.view(-1, n, data.shape[1]).transpose(1, 2)
+
+    # ------------------------------------------------------------------------------------------ early stopping / ckpt
+    def set_patience_attributes(self, args):
+        self.stopped_early = False
+        self.best_metric_value = 10 ** 6
+        self.best_metric_epoch = 1
+        self.patience_in_epochs = args.patience_in_epochs
+
+    def stop_early(self, val_metric, epoch, args):
+        """Keep the best state so far (by a metric to minimise); True once patience is exhausted
+        (point_net2.py:172-184)."""
+        if val_metric < self.best_metric_value:
+            self.best_metric_value, self.best_metric_epoch = val_metric, epoch
+            self.save_state(args)
+            return False
+        if epoch < args.epoch_to_start_early_stop:
+            return False
+        if epoch >= self.best_metric_epoch + self.patience_in_epochs:
+            self.stopped_early = True
+            return True
+        return False
+
+    @staticmethod
+    def _checkpoint_path(args):
+        tag = f"fold_n={args.current_fold_id}" if args.current_fold_id > 0 else "full"
+        return os.path.join(args.stats_path, f"PCC_model_{tag}.pt")
+
+    def save_state(self, args):
+        torch.save({"best_metric_epoch": self.best_metric_epoch, "state_dict": self.state_dict(),
+                    "best_metric_value": self.best_metric_value}, self._checkpoint_path(args))
+
+    def load_state(self, save_path):
+        checkpoint = torch.load(save_path, map_location=None if self.cuda_device is not None else torch.device("cpu"))
+        self.load_state_dict(checkpoint["state_dict"])
+        self.best_metric_epoch = checkpoint["best_metric_epoch"]
+        self.best_metric_value = checkpoint["best_metric_value"]
+        return self
+
+    def load_best_state(self, args):
+        return self.load_state(self._checkpoint_path(args))

@@ -1,0 +1,68 @@
+"""Drop-in for the reference `model/project_to_2d.py`: same two functions, same arguments, same results, but one
+scatter-max kernel sequence on the device instead of per-plot python loops with `torch.unique`, torch_scatter and
+device<->CPU bounces (`/root/reference/model/project_to_2d.py:7-55` and `:58-113`)."""
+import numpy as np
+import torch
+
+from . import hip_ops as ops
+from ._lib import StrataHipError
+
+
+class _PlotProject(torch.autograd.Function):
+    """P2 as one autograd node: forward = per-pixel max (first point wins ties) + mean over occupied pixels,
+    backward = route d pred to the arg-max point of every (pixel, channel) -- torch_scatter's scatter_max/scatter_mean
+    gradients."""
+
+    @staticmethod
+    def forward(ctx, pred_pointwise, clouds_dev, diam_pix):
+        B, _, N = clouds_dev.shape
+        pred, pix, arg, nocc = ops.plot_project_forward(pred_pointwise.contiguous(), clouds_dev, diam_pix)
+        ctx.save_for_backward(arg, nocc)
+        ctx.dims = (B, N, int(diam_pix))
+        ctx.pix = pix
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        arg, nocc = ctx.saved_tensors
+        B, N, D = ctx.dims
+        return ops.plot_project_backward(dpred.contiguous().float(), arg, nocc, B, N, D), None, None
+
+
+def _clouds_on_device(clouds, device, model_cache=None):
+    if isinstance(clouds, torch.Tensor) and clouds.is_cuda:
+        return clouds.float().contiguous()
+    if model_cache is not None and model_cache[0] is clouds:
+        return model_cache[1]
+    return clouds.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
+
+
+def project_to_plotwise_coverages(pred_pointwise, clouds, args, model=None):
+    """pred_pointwise (B*N,4) on the device, clouds (B,10,N) (CPU, as the DataLoader hands them, or device) ->
+    (B,4) [low_veg, bare_soil, med_veg, high_veg], differentiable w.r.t. pred_pointwise.
+    `model` (optional): the PointNet2 whose forward already uploaded `clouds`, to skip a second H2D copy."""
+    if not pred_pointwise.is_cuda:
+        raise StrataHipError("project_to_plotwise_coverages needs pred_pointwise on a HIP device: no CPU fallback")
+    cache = getattr(model, "_last_cloud_dev", None) if model is not None else None
+    with torch.cuda.device(pred_pointwise.device):
+        clouds_dev = _clouds_on_device(clouds, pred_pointwise.device, cache)
+        return _PlotProject.apply(pred_pointwise, clouds_dev, args.diam_pix)
+
+
+def project_to_2d_rasters(cloud, coverages_pointwise, args):
+    """cloud (>=2,N) normalised coordinates of ONE plot, coverages_pointwise (4,N) -> np.ndarray float64
+    (3, diam_pix, diam_pix) [low, med, high], image[y, x], NaN where no point falls, rows flipped."""
+    if not coverages_pointwise.is_cuda:
+        raise StrataHipError("project_to_2d_rasters needs coverages_pointwise on a HIP device: no CPU fallback")
+    dev = coverages_pointwise.device
+    with torch.cuda.device(dev):
+        cov = coverages_pointwise.detach().float().t().contiguous()                 # (N,4)
+        cl = cloud[:2].to(device=dev, dtype=torch.float32).contiguous().unsqueeze(0)   # (1,2,N)
+        rasters, _ = ops.raster_project(cov, cl, args.diam_pix, args.diam_meters)
+    return rasters[0].double().cpu().numpy()
+
+
+def project_batch_to_2d_rasters(clouds_dev, coverages_pointwise, args):
+    """Batched form for parcel inference (reference loop `predict.py:115-126`): clouds (B,C,N) on device,
+    coverages_pointwise (B*N,4) -> device tensor (B,3,D,D) fp32 with NaN, and the (B*N) pixel ids."""
+    return ops.raster_project(coverages_pointwise.detach().contiguous(), clouds_dev, args.diam_pix, args.diam_meters)

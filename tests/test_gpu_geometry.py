@@ -1,0 +1,98 @@
+"""GPU parity, geometry kernels vs the oracle (bit-exact index structures)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import primitives as P
+from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pos(B, N, first=0):
+    d = make_batch(B, N, first_plot=first)
+    return d["xyz"], d["cloud"]
+
+
+@pytest.mark.parametrize("B,N,M", [(1, 4096, 1024), (2, 2048, 256), (3, 1000, 250), (2, 200, 50), (2, 5000, 313),
+                                   (1, 32768, 256), (2, 16384, 128), (2, 1024, 256), (1, 300, 300)])
+def test_fps_matches_oracle_exactly(B, N, M):
+    xyz, _ = _pos(B, N, first=7)
+    start = torch.tensor([(13 * b + 5) % N for b in range(B)])
+    ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, start)
+    idx, cs, ca = ops.fps(xyz.to(DEV), M, start.to(DEV, torch.int32))
+    torch.cuda.synchronize()
+    assert torch.equal(idx.cpu().long(), ref)
+    g = torch.gather(xyz, 2, ref.unsqueeze(1).expand(-1, 3, -1))
+    assert torch.equal(cs.cpu(), g)
+    assert torch.equal(ca.cpu().view(B, M, 4)[..., :3], g.permute(0, 2, 1))
+
+
+def test_fps_with_duplicate_points_and_default_start():
+    """sample_cloud pads small plots by sampling with replacement (loader.py:238-244) => exact ties."""
+    xyz, _ = _pos(1, 500)
+    xyz = torch.cat([xyz, xyz[:, :, :300]], dim=2).contiguous()           # 800 points, 300 duplicates
+    ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), 700, torch.zeros(1, dtype=torch.long))
+    idx, _, _ = ops.fps(xyz.to(DEV), 700, None)
+    assert torch.equal(idx.cpu().long(), ref)
+
+
+def _oracle_lists(xyz, cpos, r, cap):
+    B, _, N = xyz.shape
+    M = cpos.shape[2]
+    pos = xyz.permute(0, 2, 1).reshape(B * N, 3)
+    cp = cpos.permute(0, 2, 1).reshape(B * M, 3)
+    bx = torch.arange(B).repeat_interleave(N)
+    by = torch.arange(B).repeat_interleave(M)
+    row, col = P.radius(pos, cp, r, bx, by, max_num_neighbors=cap)
+    return row, col - bx[col] * N
+
+
+@pytest.mark.parametrize("B,N,M,r,cap", [(1, 4096, 1024, 2 ** 0.5, 2000), (2, 2048, 256, 1.0, 2000),
+                                         (2, 1000, 100, 3.0, 64), (1, 777, 33, 2.0, 2000), (2, 256, 64, 8 ** 0.5, 2000)])
+def test_ball_query_matches_oracle_exactly(B, N, M, r, cap):
+    xyz, _ = _pos(B, N, first=3)
+    fidx = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, torch.zeros(B, dtype=torch.long))
+    cpos = torch.gather(xyz, 2, fidx.unsqueeze(1).expand(-1, 3, -1)).contiguous()
+    row, col = _oracle_lists(xyz, cpos, r, cap)
+    nbr, cnt, total = ops.ball_query(xyz.to(DEV), cpos.to(DEV), r, cap)
+    torch.cuda.synchronize()
+    cnt_ref = torch.bincount(row, minlength=B * M)
+    assert torch.equal(cnt.cpu().long(), cnt_ref)
+    assert int(total.item()) == int(cnt_ref.sum())
+    nbr, cnt = nbr.cpu(), cnt.cpu()
+    mask = torch.arange(nbr.shape[1]).unsqueeze(0) < cnt.unsqueeze(1)
+    assert torch.equal(nbr[mask].long(), col)          # row-major over (centroid, slot) == oracle's (row, ascending col)
+    if cap < 2000:
+        assert int(cnt.max()) == cap                   # the cap bites in this case: first `cap` in ascending index
+
+
+@pytest.mark.parametrize("B,S,T,k", [(1, 1024, 4096, 3), (2, 256, 1024, 3), (2, 64, 1000, 3), (3, 1, 256, 1),
+                                     (1, 2, 100, 3), (2, 1500, 700, 3)])
+def test_three_nn_matches_oracle(B, S, T, k):
+    xyz, _ = _pos(B, max(S, T), first=11)
+    src = xyz[:, :, :S].contiguous() if S > 1 else torch.zeros(B, 3, 1)
+    dst = xyz[:, :, -T:].contiguous()
+    ps = src.permute(0, 2, 1).reshape(B * S, 3)
+    pd = dst.permute(0, 2, 1).reshape(B * T, 3)
+    bs, bd = torch.arange(B).repeat_interleave(S), torch.arange(B).repeat_interleave(T)
+    yi, xi = P.knn(ps, pd, k, bs, bd)
+    kk = min(k, S)
+    ref_idx = (xi - bs[xi] * S).view(B * T, kk)
+    ref_w = 1.0 / torch.clamp(P.canonical_d2(ps[xi], pd[yi]), min=1e-16).view(B * T, kk)
+    idx, w = ops.three_nn(src.to(DEV), dst.to(DEV), k)
+    idx, w = idx.cpu().long(), w.cpu()
+    assert torch.equal(idx[:, :kk], ref_idx)
+    assert torch.equal(w[:, :kk], ref_w)               # same canonical d2, IEEE division
+    if kk < 3:
+        assert torch.all(w[:, kk:] == 0) and torch.equal(idx[:, kk:], idx[:, :1].expand(-1, 3 - kk))
+
+
+def test_pack_rows():
+    xyz, cloud = _pos(2, 777)
+    rows = ops.pack_rows(cloud.to(DEV), xyz.to(DEV)).cpu().view(2, 777, 12)
+    assert torch.equal(rows[..., :8], cloud[:, 2:].permute(0, 2, 1))
+    assert torch.equal(rows[..., 8:11], xyz.permute(0, 2, 1))
+    assert torch.all(rows[..., 11] == 0)

@@ -1,0 +1,71 @@
+"""Host-side mirror of the reference interface (CPU only): constructor, state-dict keys/shapes, layout helpers,
+checkpoint helpers, and the loud failure of the product path without a HIP device."""
+import os
+
+import pytest
+import torch
+
+from conftest import golden_state_dict, load_golden
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_plotwise_coverages
+from stratanet2_vegetation_coverage_maps_amd._lib import StrataHipError
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
+
+
+def test_state_dict_keys_shapes_and_default_init_match_reference():
+    ref = golden_state_dict(load_golden("c1_ref_defaults"))
+    torch.manual_seed(0)
+    m = PointNet2(make_args())
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in sd:
+        assert sd[k].shape == ref[k].shape, k
+        if ".0.weight" in k or ".0.bias" in k or k.startswith("lin"):
+            assert torch.equal(sd[k], ref[k]), k          # same RNG stream as the reference constructor
+    assert sum(p.numel() for p in m.parameters()) == 14997
+    m.load_state_dict(ref)                                # a reference checkpoint loads
+
+
+def test_layout_helpers():
+    m = PointNet2(make_args(subsample_size=5))
+    x = torch.arange(2 * 3 * 5, dtype=torch.float32).view(2, 3, 5)
+    lf = m.get_long_form(x)
+    assert lf.shape == (10, 3)
+    assert torch.equal(lf, torch.cat(list(x), 1).transpose(1, 0))
+    assert torch.equal(m.get_batch_format(lf), x)
+
+
+def test_checkpoint_roundtrip_and_early_stopping(tmp_path):
+    args = make_args(stats_path=str(tmp_path), patience_in_epochs=2, epoch_to_start_early_stop=1)
+    m = PointNet2(args)
+    assert m.stop_early(0.5, 1, args) is False and m.best_metric_epoch == 1
+    assert os.path.exists(os.path.join(str(tmp_path), "PCC_model_full.pt"))
+    assert m.stop_early(0.6, 2, args) is False
+    assert m.stop_early(0.7, 3, args) is True and m.stopped_early
+    m2 = PointNet2(args).load_best_state(args)
+    assert m2.best_metric_value == 0.5
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+    args.current_fold_id = 3
+    m.save_state(args)
+    assert os.path.exists(os.path.join(str(tmp_path), "PCC_model_fold_n=3.pt"))
+
+
+def test_product_path_fails_loudly_without_a_device():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    args = make_args(subsample_size=64)
+    m = PointNet2(args)
+    data = make_batch(1, 64)
+    with pytest.raises(StrataHipError):
+        m(data)
+    with pytest.raises(StrataHipError):
+        project_to_plotwise_coverages(torch.zeros(64, 4), data["cloud"], args)
+
+
+def test_no_oracle_import_in_product():
+    import stratanet2_vegetation_coverage_maps_amd as pkg
+    root = os.path.dirname(pkg.__file__)
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(root, fn)).read()
+            assert "import oracle" not in txt and "from oracle" not in txt, fn
