@@ -27,6 +27,10 @@ CASES = {
     # reference architecture defaults (config.py:77-80) at BASELINE config-1 size
     "c1_ref_defaults": dict(B=1, N=4096, ratio1=0.25, r1=math.sqrt(2.0), ratio2=0.25, r2=math.sqrt(8.0),
                             first_plot=0, starts=([0], [0])),
+    # reference defaults again, two plots: neighbour lists longer than one 64-lane step, better conditioned than the
+    # single-plot case (whose 256-row BatchNorms amplify fp32 noise: see grad64 below)
+    "b2_ref_defaults": dict(B=2, N=4096, ratio1=0.25, r1=math.sqrt(2.0), ratio2=0.25, r2=math.sqrt(8.0),
+                            first_plot=300, starts=([100, 7], [3, 250])),
     # two plots, C2-style radii (1 m / 2 m), non-zero FPS starts
     "b2_c2_style": dict(B=2, N=2048, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0,
                         first_plot=100, starts=([17, 1203], [5, 0])),
@@ -119,6 +123,23 @@ def main():
         for k, v in model.state_dict().items():
             if "running_" in k or "num_batches" in k:
                 out[f"sd_after/{k}"] = v.numpy()
+        # ---------------- the same train step with fp64 features / weights (geometry stays fp32, so the index
+        # structures are identical): the yardstick for how well conditioned each gradient is.  Tests accept an error of
+        # 1e-3 or twice the reference's own fp32-vs-fp64 discrepancy, whichever is larger.
+        torch.manual_seed(0)
+        model64 = PointNet2(args)
+        model64.load_state_dict(sd0)
+        model64 = model64.double().train()
+        P.set_fps_start_provider(provider)
+        cov64, proba64 = model64({"cloud": data["cloud"].double(), "xyz": data["xyz"]})
+        pred64 = project_to_plotwise_coverages(cov64, data["cloud"].double(), args)
+        l_abs = LF.get_absolute_loss(pred64, data["coverages"])
+        l_log, _ = LF.get_NLL_loss(proba64, data["cloud"].double(), args)
+        l_e = LF.get_entropy_loss(proba64)
+        (l_abs + args.m * l_log + args.e * l_e).backward()
+        for k, p in model64.named_parameters():
+            out[f"grad64/{k}"] = p.grad.numpy()
+        out["train64/coverages_pointwise"] = cov64.detach().numpy()
         P.set_fps_start_provider(None)
 
         path = os.path.join(OUT, f"{name}.npz")

@@ -90,7 +90,7 @@ class _PointNet2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, xyz, cloud, fps_start, *params):
         training = model.training
-        need_grad = training and torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = any(ctx.needs_input_grad[4:])   # grad mode is off inside Function.forward; this is the reliable test
         cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training)
         ctx.model = model
         ctx.saved = saved if need_grad else None
@@ -100,7 +100,7 @@ class _PointNet2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dcov, dproba):
         if ctx.saved is None:
-            raise RuntimeError("PointNet2: backward through an eval-mode / no-grad forward")
+            raise RuntimeError("PointNet2: backward through a forward that recorded no graph")
         grads = ctx.model._backward_impl(ctx.saved, dcov, dproba)
         ctx.saved = None
         return (None, None, None, None) + tuple(grads)

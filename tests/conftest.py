@@ -41,4 +41,4 @@ def golden_args(name):
     return make_args(subsample_size=c["N"], ratio1=c["ratio1"], r1=c["r1"], ratio2=c["ratio2"], r2=c["r2"])
 
 
-GOLDEN_CASES = ["c1_ref_defaults", "b2_c2_style"]
+GOLDEN_CASES = ["c1_ref_defaults", "b2_ref_defaults", "b2_c2_style"]

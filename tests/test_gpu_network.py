@@ -63,10 +63,17 @@ def test_train_step_vs_reference_golden(name):
     np.testing.assert_allclose(proba.detach().cpu().numpy(), g["train/proba_pointwise"], atol=TOL, rtol=0)
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g["train/pred_coverages"], atol=TOL, rtol=0)
     np.testing.assert_allclose([loss.item()] + [p.item() for p in parts], g["train/losses"], atol=TOL, rtol=0)
+    # gradients: against the reference run with fp64 features/weights (same fp32 geometry); accepted error per
+    # parameter = 1e-3 of its magnitude, or twice the reference's OWN fp32-vs-fp64 discrepancy where that is larger
+    # (single-plot BatchNorms over 256 rows and near-tied pixel maxima make some of these gradients ill-conditioned)
     for k, p in m.named_parameters():
-        ref = g[f"grad/{k}"]
+        ref32, ref64 = g[f"grad/{k}"], g[f"grad64/{k}"]
         assert p.grad is not None, k
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-6 + 1e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+        scale = np.abs(ref64).max()
+        self_err = np.abs(ref32 - ref64).max() / scale
+        tol = max(1e-3, 2.0 * self_err)
+        err = np.abs(p.grad.cpu().numpy() - ref64).max() / scale
+        assert err <= tol, f"{k}: rel err {err:.3e} > tol {tol:.3e} (reference fp32-vs-fp64 {self_err:.3e})"
     sd = m.state_dict()
     for k in sd:
         if "running_" in k:
