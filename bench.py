@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- plots/s of one full training step of the PointNet2 hot path on synthetic 32k-point plots.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2 ref-arch"): 16 plots per GPU x 32 768 points, the reference
+architecture with ratio1 = 1024/N, r1 = 1 m, ratio2 = 0.25, r2 = 2 m, fp32, inputs resident in HBM.
+A step = zero_grad -> PointNet2.forward -> project_to_plotwise_coverages -> loss (abs + 0.1 NLL + 0.04 entropy)
+-> backward -> [one RCCL all-reduce of the flat 60 KB gradient when N > 1] -> Adam step
+(the step of /root/reference/learning/train.py:52-66).  Plots are sharded over ranks (weak scaling), no other collective.
+
+Prints ONE JSON line on rank 0 with the contract's fields plus
+  "roofline"     for the dominant entry point of the step (HIP-event timed inside the timed region),
+  "kernels"      per-entry-point ms/step and algorithmic GB/s from one instrumented step after the timed region,
+  "cpu_baseline" the oracle (CPU restatement of the reference path) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_plotwise_coverages  # noqa: E402
+from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops  # noqa: E402
+from stratanet2_vegetation_coverage_maps_amd import losses  # noqa: E402
+from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters  # noqa: E402
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+PLOTS_PER_GPU = 16
+N_POINTS = 32768
+M1 = 1024
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def workload_args(device):
+    return make_args(cuda=device, subsample_size=N_POINTS, ratio1=M1 / N_POINTS, r1=1.0, ratio2=0.25, r2=2.0)
+
+
+def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
+    """Compulsory HBM bytes of ONE launch of an entry point (DESIGN.md 'algorithmic bytes')."""
+    t = {
+        f"sn2_fps:N={N}": 12 * N * B + 32 * m1 * B,
+        f"sn2_fps:N={m1}": 12 * m1 * B + 32 * m2 * B,
+        f"sn2_ball_query:N={N}": 12 * (N + m1) * B + 4 * e1 + 4 * m1 * B,
+        f"sn2_ball_query:N={m1}": 12 * (m1 + m2) * B + 4 * e2 + 4 * m2 * B,
+        f"sn2_three_nn:T={N}": 12 * (m1 + N) * B + 24 * N * B,
+        f"sn2_three_nn:T={m1}": 12 * (m2 + m1) * B + 24 * m1 * B,
+        f"sn2_three_nn:T={m2}": 12 * (1 + m2) * B + 24 * m2 * B,
+        "sn2_pack_rows": (44 + 48) * N * B,
+        # SA1: per pass 4 B index + 48 B gathered row per message (the gather is L2 traffic once the 1.5 MB/plot
+        # table is resident; counted here as the algorithmic upper bound), 2 forward passes / 2 backward passes
+        "sn2_sa_forward:cf=8": 2 * 52 * e1 + 3 * 64 * m1 * B,
+        "sn2_sa_backward:cf=8": 2 * 52 * e1 + 2 * 64 * m1 * B,
+        "sn2_sa_forward:cf=16": 84 * e2 + 3 * 128 * m2 * B,
+        "sn2_sa_backward:cf=16": 84 * e2 + 64 * e2 + 2 * 128 * m2 * B,
+        # FP1: 24 B knn + 32 B skip + 3 x 144 B gathered rows (L2) read, 144 B written per point
+        "sn2_fp_forward:34+8->34": (24 + 32 + 144) * N * B,
+        "sn2_fp_backward:34+8->34": (2 * 288 + 24 + 32 + 136 + 136 + 24 + 136) * N * B,
+        "sn2_head_forward": (144 + 32) * N * B,
+        "sn2_head_backward": (144 + 32 + 144) * N * B,
+        "sn2_plot_project_forward": (8 + 8 + 16 + 4) * N * B + 24 * D * D * B,
+        "sn2_plot_project_backward": 16 * D * D * 3 * B,
+    }
+    return t.get(key)
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference path, kd-tree neighbour search, all host cores) on a bounded
+    sample of the same workload: 2 plots of 32 768 points, 1 warm-up + 2 timed steps."""
+    from oracle import losses as olosses, network, projection
+    # the GPU box gives one GPU's job a share of 16 cores whatever os.cpu_count() says: more OpenMP threads than that
+    # only spin against each other
+    ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    torch.set_num_threads(ncores)
+    B = 2
+    args = workload_args(None)
+    d = make_batch(B, N_POINTS)
+    sd = network.init_state_dict(0)
+    keys = network.param_keys(sd)
+    params = [sd[k].requires_grad_(True) for k in keys]
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-3)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        cov, proba, _ = network.forward(sd, d["cloud"], d["xyz"], args, training=True, use_kdtree=True)
+        pred = projection.project_to_plotwise_coverages(cov, d["cloud"], args)
+        loss, _ = olosses.total_loss(pred, proba, d["coverages"], d["pdf_all"], args.m, args.e)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        log(f"cpu_baseline step {it}: {times[-1]:.2f} s")
+        if times[-1] > 60 and it >= 1:
+            break
+    t = sum(times[1:]) / len(times[1:])
+    return {"value": round(B / t, 3), "unit": "plots/s", "cores": ncores, "kind": "port",
+            "sample": f"{B} plots x {N_POINTS} pts, same step (fwd+P2+loss+bwd+Adam), mean of 2 steps after 1 warm-up, "
+                      f"torch {torch.get_num_threads()} threads + scipy cKDTree"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    B = PLOTS_PER_GPU
+    args = workload_args(local_rank)
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    model = PointNet2(args).train()
+    flatten_parameters(model)
+    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
+    host = make_batch(B, N_POINTS, first_plot=rank * B)                       # this rank's shard of the plot batch
+    data = {"cloud": host["cloud"].to(dev), "xyz": host["xyz"].to(dev),
+            "fps_start": torch.zeros(2, B, dtype=torch.int32, device=dev)}
+    gt, pdf = host["coverages"].to(dev), host["pdf_all"].to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        cov, proba = model(data)
+        pred = project_to_plotwise_coverages(cov, data["cloud"], args)
+        loss, _ = losses.total_loss(pred, proba, gt, pdf, args.m, args.e)
+        loss.backward()
+        opt.step()
+        return loss
+
+    # ---- warm-up; the first warm-up step is instrumented to find the dominant entry point
+    log("inputs resident; first (instrumented) step")
+    with ops.timing() as t0:
+        step()
+    prof = t0.summary()
+    log("first step done: " + ", ".join(f"{k} {v[1]:.3f} ms" for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:6]))
+    dominant = max(prof, key=lambda k: prof[k][1]) if prof else None
+    for _ in range(max(0, a.warmup - 1)):
+        step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t_start = time.perf_counter()
+    with ops.timing({dominant}) as tdom:       # 2 event records per step on the dominant entry point only
+        for _ in range(a.steps):
+            loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    barrier()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el.item())
+    dom = tdom.summary()
+    log(f"timed region: {elapsed / a.steps * 1e3:.3f} ms/step")
+
+    # ---- one fully instrumented step for the per-entry-point table (after the timed region)
+    with ops.timing() as tall:
+        step()
+    table = tall.summary()
+    s = model  # sizes for the byte model
+    e1 = e2 = 0
+    with torch.no_grad():
+        _, _, saved = model._forward_impl(data["xyz"], data["cloud"], data["fps_start"], False)
+        e1, e2 = int(saved.tot1.item()), int(saved.tot2.item())
+        m1, m2 = saved.M1, saved.M2
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        kernels = []
+        for k, (c, tms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+            by = algorithmic_bytes(k, B, N_POINTS, m1, m2, e1, e2)
+            kernels.append({"entry": k, "ms": round(tms, 4),
+                            "alg_GBps": None if by is None else round(by / (tms * 1e-3) / 1e9, 1)})
+        roof = None
+        if dominant and dominant in dom:
+            c, tms = dom[dominant]
+            avg_ms = tms / c
+            by = algorithmic_bytes(dominant, B, N_POINTS, m1, m2, e1, e2)
+            ach = None if by is None else by / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": dominant, "bound": "hbm", "achieved": None if ach is None else round(ach, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6),
+                    "traffic": None, "avg_ms": round(avg_ms, 4), "algorithmic_bytes": by,
+                    "note": ("fps is latency/VALU-bound by construction (M strictly sequential argmax rounds, one "
+                             "workgroup per plot); its HBM traffic is 12 B/point once" if dominant.startswith("sn2_fps")
+                             else "")}
+        out = {"metric": "plots/s fwd+bwd, 32k-pt synthetic plots, batch 16/GPU", "value": round(world * B / (ms * 1e-3), 2),
+               "unit": "plots/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "C2 ref-arch: 16 plots/GPU x 32768 pts, SA npoint 1024/256 + global, r 1/2 m, "
+                                      "train step fwd+P2+loss+bwd+Adam, inputs resident in HBM",
+                          "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
+                          "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
+               "loss": round(float(loss.item()), 6), "roofline": roof, "kernels": kernels}
+        if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (oracle on the host cores)")
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,7 @@ extern "C" {
 #define SN2_ELIMIT (-2) /* size outside what the kernels cover */
 
 #define SN2_MAX_NEIGHBORS 2000 /* model/point_net2.py:24  max_num_neighbors */
+#define SN2_STAT_SLOTS 512     /* workgroups (= partial-sum slots) of a kernel that produces BatchNorm statistics */
 
 int sn2_version(void);
 
@@ -41,7 +42,8 @@ typedef struct sn2_block {
     float *running_mean, *running_var; /* (cout) updated in place when training (momentum 0.1, unbiased var)    */
     float *a, *c;                  /* out (cout): the block's output is  a*relu(W u + b) + c                    */
     float *mean, *invstd;          /* out (cout): batch statistics saved for backward (training)                */
-    double *sum, *sumsq;           /* workspace (cout each), must be ZERO on entry of a training forward        */
+    float *stat_slots;             /* workspace, SN2_STAT_SLOTS * 2 * cout floats (per-workgroup batch-statistics
+                                      partials; no initialisation needed)                                       */
     float *dW, *db, *dgamma, *dbeta; /* backward outputs, ACCUMULATED; must be ZERO on entry of the backward call
                                         (dgamma/dbeta are read back inside it)                                   */
 } sn2_block;

@@ -9,12 +9,13 @@ LIB_PATH = os.path.join(HERE, "csrc", "libstrata_hip.so")
 
 SN2_VERSION = 100
 MAX_NEIGHBORS = 2000  # model/point_net2.py:24
+STAT_SLOTS = 512      # SN2_STAT_SLOTS
 
 
 class Block(Structure):  # sn2_block
     _fields_ = [("cin", c_int), ("cout", c_int), ("W", c_void_p), ("b", c_void_p), ("gamma", c_void_p),
                 ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("a", c_void_p),
-                ("c", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("sum", c_void_p), ("sumsq", c_void_p),
+                ("c", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("stat_slots", c_void_p),
                 ("dW", c_void_p), ("db", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
 
 

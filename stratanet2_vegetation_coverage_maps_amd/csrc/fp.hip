@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) void fp_fwd_kernel(int R, int R_per_plot, int 
                                                      const int* __restrict__ knn_idx, const float* __restrict__ knn_w,
                                                      const float* __restrict__ skip, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ h,
-                                                     double* __restrict__ sum, double* __restrict__ sumsq) {
+                                                     float* __restrict__ slots) {
     constexpr int CI = CA + CB;
+    __shared__ float s_red[2 * CO];
     float ssum[CO], ssq[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) ssum[o] = ssq[o] = 0.f;
@@ -109,10 +110,7 @@ __global__ __launch_bounds__(256) void fp_fwd_kernel(int R, int R_per_plot, int 
             *reinterpret_cast<float4*>(hr + o4) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
-    if (sum) {
-        flush_sums_f64<CO>(ssum, sum);
-        flush_sums_f64<CO>(ssq, sumsq);
-    }
+    if (slots) stats_to_slot<CO>(ssum, ssq, s_red, slots);
 }
 
 // ---------------------------------------------------------------------------------------------- backward (1)
@@ -142,8 +140,16 @@ __global__ __launch_bounds__(256) void fp_bwd_bn_kernel(int R, int h_stride, con
             }
         }
     }
-    flush_sums<CO>(sb, dbeta);
-    flush_sums<CO>(sg, dgamma);
+    __shared__ float s_red[2 * CO];
+    for (int i = threadIdx.x; i < 2 * CO; i += 256) s_red[i] = 0.f;
+    __syncthreads();
+    sums_to_lds<CO>(sb, s_red);
+    sums_to_lds<CO>(sg, s_red + CO);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * CO; i += 256) {
+        const float v = s_red[i];
+        if (v != 0.f) atomicAdd(i < CO ? &dbeta[i] : &dgamma[i - CO], v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- backward (2)
@@ -235,7 +241,20 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
             }
         }
     }
-    acc.flush_with_bias(dW, CI, db, CO);
+    // workgroup-level reduction of the [dW | db] image, then one global atomic per element and workgroup
+    float* red = smem;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CO * (CI + 1); i += WAVES * 64) red[i] = 0.f;
+    __syncthreads();
+    acc.flush_lds(red);
+    __syncthreads();
+    for (int i = threadIdx.x; i < CO * (CI + 1); i += WAVES * 64) {
+        const float v = red[i];
+        if (v == 0.f) continue;
+        const int o = i / (CI + 1), k = i - o * (CI + 1);
+        if (k < CI) atomicAdd(&dW[o * CI + k], v);
+        else atomicAdd(&db[o], v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- backward (3)
@@ -288,13 +307,14 @@ int pick_grid(long R, int threads, int rows_per_lane) {
 template <int CA, int CB, int CO, bool KNN>
 int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     const int R = p->B * p->R_per_plot;
-    hipLaunchKernelGGL((fp_fwd_kernel<CA, CB, CO, KNN>), dim3(pick_grid(R, 256, 4)), dim3(256), 0, st, R, p->R_per_plot,
+    int grid = pick_grid(R, 256, 4);
+    if (grid > SN2_STAT_SLOTS) grid = SN2_STAT_SLOTS;
+    hipLaunchKernelGGL((fp_fwd_kernel<CA, CB, CO, KNN>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot,
                        p->S_per_plot, p->src_stride, p->skip_stride, p->h_stride, p->src, p->src_a, p->src_c, p->knn_idx,
-                       p->knn_w, p->skip, p->blk.W, p->blk.b, p->h, training ? p->blk.sum : (double*)nullptr,
-                       training ? p->blk.sumsq : (double*)nullptr);
+                       p->knn_w, p->skip, p->blk.W, p->blk.b, p->h, training ? p->blk.stat_slots : (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    return sn2_bn_finalize(&p->blk, nullptr, R, training, st);
+    return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
 }
 
 template <int CA, int CB, int CO, bool KNN>
@@ -303,7 +323,9 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     using Acc = OuterAcc<CO, CI + 1>;
     constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : ((Acc::LDS_FLOATS * 4 * 2 <= 150 * 1024) ? 2 : 1);
     const int R = p->B * p->R_per_plot;
-    hipLaunchKernelGGL((fp_bwd_bn_kernel<CO>), dim3(pick_grid(R, 256, 8)), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
+    int g1 = pick_grid(R, 256, 8);
+    if (g1 > 256) g1 = 256;
+    hipLaunchKernelGGL((fp_bwd_bn_kernel<CO>), dim3(g1), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
                        p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -316,7 +338,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     if (KNN && p->dsrc && !p->du_scratch) return SN2_EINVAL;
     if (KNN && !p->dsrc) du_out = nullptr;
     int grid = pick_grid(R, WAVES * 64, 4);
-    if (grid > 512) grid = 512;
+    if (grid > 256) grid = 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,
                        p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src, p->src_a, p->src_c,
                        p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma, (const float*)p->blk.mean,
@@ -519,8 +541,26 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int R, int f_stride, cons
             }
         }
     }
-    acc2.flush_with_bias(dW2, 16, db2, 5);
-    acc1.flush_with_bias(dW1, 34, db1, 16);
+    // workgroup-level reduction, then one global atomic per element and workgroup
+    float* red = smem;
+    constexpr int N2 = 16 * 17, N1 = 16 * 35;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N2 + N1; i += 256) red[i] = 0.f;
+    __syncthreads();
+    acc2.flush_lds(red);
+    acc1.flush_lds(red + N2);
+    __syncthreads();
+    for (int i = threadIdx.x; i < N2 + N1; i += 256) {
+        const float v = red[i];
+        if (v == 0.f) continue;
+        if (i < N2) {
+            const int o = i / 17, k = i - o * 17;
+            if (o < 5) atomicAdd(k < 16 ? &dW2[o * 16 + k] : &db2[o], v);
+        } else {
+            const int j = i - N2, o = j / 35, k = j - o * 35;
+            atomicAdd(k < 34 ? &dW1[o * 34 + k] : &db1[o], v);
+        }
+    }
 }
 
 int check_head(const sn2_head* p) {
@@ -546,7 +586,7 @@ extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
     int grid = pick_grid(p->R, 256, 4);
-    if (grid > 512) grid = 512;
+    if (grid > 256) grid = 256;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
                        p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
                        p->db2);

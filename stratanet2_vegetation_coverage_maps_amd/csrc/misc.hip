@@ -8,9 +8,8 @@
 __global__ void bn_finalize_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ a, float* __restrict__ c, float* __restrict__ mean_out,
-                                   float* __restrict__ invstd_out, const double* __restrict__ sum,
-                                   const double* __restrict__ sumsq, const unsigned long long* __restrict__ count_dev,
-                                   long count_imm, int training) {
+                                   float* __restrict__ invstd_out, const float* __restrict__ slots, int nslots,
+                                   const unsigned long long* __restrict__ count_dev, long count_imm, int training) {
     const int o = threadIdx.x;
     if (o >= C) return;
     const float eps = 1e-5f, mom = 0.1f;
@@ -18,8 +17,13 @@ __global__ void bn_finalize_kernel(int C, const float* __restrict__ gamma, const
     if (training) {
         double n = count_dev ? (double)(*count_dev) : (double)count_imm;
         if (n < 1.0) n = 1.0;
-        const double m = sum[o] / n;
-        double var = sumsq[o] / n - m * m;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nslots; ++k) {  // fixed order: deterministic statistics
+            s1 += (double)slots[(size_t)k * 2 * C + o];
+            s2 += (double)slots[(size_t)k * 2 * C + C + o];
+        }
+        const double m = s1 / n;
+        double var = s2 / n - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         invstd = 1.0f / sqrtf((float)var + eps);
@@ -37,12 +41,13 @@ __global__ void bn_finalize_kernel(int C, const float* __restrict__ gamma, const
     invstd_out[o] = invstd;
 }
 
-int sn2_bn_finalize(const sn2_block* blk, const unsigned long long* count_dev, long count_imm, int training,
+int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm, int training,
                     hipStream_t st) {
-    if (!blk || blk->cout <= 0 || blk->cout > 64) return SN2_EINVAL;
+    if (!blk || blk->cout <= 0 || blk->cout > 64 || nslots < 0 || nslots > SN2_STAT_SLOTS) return SN2_EINVAL;
+    if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
-                       blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, blk->sum, blk->sumsq, count_dev,
-                       count_imm, training);
+                       blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
+                       count_dev, count_imm, training);
     SN2_RETURN_LAUNCH();
 }
 

@@ -89,8 +89,9 @@ struct OuterAcc {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // variant for Q = [input | 1]: columns < CK-1 go to dW (CO, ld), the last column is the bias gradient
-    __device__ __forceinline__ void flush_with_bias(float* __restrict__ dW, int ld, float* __restrict__ db, int co_used) {
+    // add this wave's tile sums into a block-shared LDS image red[CO][CK] (LDS float atomics; the image must be zeroed
+    // and the workgroup synchronised before, and synchronised again before it is read)
+    __device__ __forceinline__ void flush_lds(float* red) {
         const int lane = threadIdx.x & 63;
         const int r4 = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -100,46 +101,38 @@ struct OuterAcc {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = a * 16 + r4 * 4 + r, k = b * 16 + c;
-                    if (o < co_used && k < CK - 1) atomicAdd(&dW[o * ld + k], acc[a][b][r]);
-                    if (o < co_used && k == CK - 1) atomicAdd(&db[o], acc[a][b][r]);
-                }
-    }
-
-    // dW (CO, ld) row-major, ACCUMULATED with float atomics
-    __device__ __forceinline__ void flush(float* __restrict__ dW, int ld) {
-        const int lane = threadIdx.x & 63;
-        const int r4 = lane >> 4, c = lane & 15;
-#pragma unroll
-        for (int a = 0; a < TO; ++a)
-#pragma unroll
-            for (int b = 0; b < TK; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = a * 16 + r4 * 4 + r, k = b * 16 + c;
-                    if (o < CO && k < CK) atomicAdd(&dW[o * ld + k], acc[a][b][r]);
+                    if (o < CO && k < CK) atomicAdd(&red[o * CK + k], acc[a][b][r]);
                 }
     }
 };
 
-// wave-reduce an array of per-lane partial sums and add it to global fp32 / fp64 accumulators (lane 0 issues the adds)
+// Every reduction that leaves a kernel goes through the workgroup first: thousands of waves adding to the same few
+// addresses serialise in the memory-side atomic units (a first version that let every wave issue its own global
+// atomics spent 1.5 ms per pass there).  Per-lane partials -> wave sum -> LDS float atomic on a block-shared image.
 template <int C>
-__device__ __forceinline__ void flush_sums(const float (&v)[C], float* __restrict__ dst) {
+__device__ __forceinline__ void sums_to_lds(const float (&v)[C], float* red) {
 #pragma unroll
     for (int o = 0; o < C; ++o) {
         const float s = wave_sum(v[o]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&dst[o], s);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[o], s);
     }
 }
+
+// BatchNorm batch statistics leave a kernel as one slot per workgroup: slot[blockIdx.x] = [sum(C) | sumsq(C)] (fp32
+// partials, every workgroup writes its slot, so no zeroing and no atomics; bn_finalize adds the slots in fp64 in a
+// fixed order => run-to-run identical statistics).  `red` = block-shared scratch of 2*C floats.
 template <int C>
-__device__ __forceinline__ void flush_sums_f64(const float (&v)[C], double* __restrict__ dst) {
-#pragma unroll
-    for (int o = 0; o < C; ++o) {
-        const float s = wave_sum(v[o]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&dst[o], (double)s);
-    }
+__device__ __forceinline__ void stats_to_slot(const float (&ssum)[C], const float (&ssq)[C], float* red,
+                                              float* __restrict__ slots) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    sums_to_lds<C>(ssum, red);
+    sums_to_lds<C>(ssq, red + C);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) slots[(size_t)blockIdx.x * 2 * C + i] = red[i];
 }
 
 // launcher of the BatchNorm finalisation kernel (misc.hip): from (sum, sumsq, count) or the running statistics to the
 // affine (a, c), the saved (mean, invstd) and the running-statistics update.
-int sn2_bn_finalize(const sn2_block* blk, const unsigned long long* count_dev, long count_imm, int training,
-                    hipStream_t st);
+int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm,
+                    int training, hipStream_t st);

@@ -27,7 +27,7 @@ struct BlkRO {
 };
 // writable side (atomics)
 struct BlkDev {
-    double *sum, *sumsq;
+    float* slots;  // per-workgroup batch-statistics partials or nullptr
     float *dW, *db, *dgamma, *dbeta;
 };
 #define BLK_RO_PARAMS(n)                                                                                              \
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
     const BlkRO& rl = NL == 2 ? r1 : r0;  // last block, read-only side
     constexpr int CL = NL == 2 ? C2 : C1;  // width of the last block
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float s_red[128];  // block-level reduction of the batch statistics (2 x up to 64 channels)
     const int lane = threadIdx.x & 63;
     const int wave_in_blk = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave_in_blk));
@@ -263,27 +264,37 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
         }
     }
 
-    if constexpr (PASS == PASS_STATS0) {
-        flush_sums_f64<C1>(ssum, p.k0.sum);
-        flush_sums_f64<C1>(ssq, p.k0.sumsq);
-    }
+    // ---- everything that leaves the kernel is first reduced over the workgroup (see mlp.h)
+    if constexpr (PASS == PASS_STATS0) stats_to_slot<C1>(ssum, ssq, s_red, p.k0.slots);
     if constexpr (PASS == PASS_MAIN) {
-        if (kl.sum) {
-            flush_sums_f64<CL>(ssum, kl.sum);
-            flush_sums_f64<CL>(ssq, kl.sumsq);
+        if (kl.slots) stats_to_slot<CL>(ssum, ssq, s_red, kl.slots);
+    }
+    if constexpr (PASS == PASS_BWD_C || PASS == PASS_BWD_D) {
+        constexpr int CKL = NL == 2 ? C1 : CIN;                  // columns of the last block's dW
+        constexpr int NW = BWD_LAST ? CL * CKL : C1 * CIN;       // dW image
+        constexpr int NB = BWD_LAST ? CL : C1;                   // bias gradient
+        constexpr int NG = (PASS == PASS_BWD_C && NL == 2) ? 2 * C1 : 0;  // first BN's dbeta | dgamma
+        float* red = smem;                                       // the wave-private staging regions are free now
+        __syncthreads();
+        for (int i = threadIdx.x; i < NW + NB + NG; i += 256) red[i] = 0.f;
+        __syncthreads();
+        if constexpr (BWD_LAST) accL.flush_lds(red);
+        if constexpr (BWD_FIRST2) accF.flush_lds(red);
+        sums_to_lds<NB>(dbias, red + NW);
+        if constexpr (NG > 0) {
+            sums_to_lds<C1>(dbeta0, red + NW + NB);
+            sums_to_lds<C1>(dgamma0, red + NW + NB + C1);
         }
-    }
-    if constexpr (BWD_LAST) {
-        accL.flush(kl.dW, NL == 2 ? C1 : CIN);
-        flush_sums<CL>(dbias, kl.db);
-    }
-    if constexpr (PASS == PASS_BWD_C && NL == 2) {
-        flush_sums<C1>(dbeta0, p.k0.dbeta);
-        flush_sums<C1>(dgamma0, p.k0.dgamma);
-    }
-    if constexpr (BWD_FIRST2) {
-        accF.flush(p.k0.dW, CIN);
-        flush_sums<C1>(dbias, p.k0.db);
+        __syncthreads();
+        const BlkDev& kw = BWD_LAST ? kl : p.k0;
+        for (int i = threadIdx.x; i < NW + NB + NG; i += 256) {
+            const float v = red[i];
+            if (v == 0.f) continue;
+            if (i < NW) atomicAdd(&kw.dW[i], v);
+            else if (i < NW + NB) atomicAdd(&kw.db[i - NW], v);
+            else if (i < NW + NB + C1) atomicAdd(&p.k0.dbeta[i - NW - NB], v);
+            else atomicAdd(&p.k0.dgamma[i - NW - NB - C1], v);
+        }
     }
 }
 
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(256) void sa_bwd_prep_kernel(const float* __restric
 
 BlkDev to_dev(const sn2_block& k) {
     BlkDev d;
-    d.sum = k.sum; d.sumsq = k.sumsq; d.dW = k.dW; d.db = k.db; d.dgamma = k.dgamma; d.dbeta = k.dbeta;
+    d.slots = k.stat_slots; d.dW = k.dW; d.db = k.db; d.dgamma = k.dgamma; d.dbeta = k.dbeta;
     return d;
 }
 
@@ -345,7 +356,7 @@ int check(const sn2_sa* p) {
 }
 
 template <int CF, int NL, int C1, int C2, int PASS>
-int launch_pass(const sn2_sa* p, int training, hipStream_t st) {
+int launch_pass(const sn2_sa* p, int training, hipStream_t st, int* nblocks_out = nullptr) {
     constexpr int CIN = CF + 3, CL = NL == 2 ? C2 : C1;
     constexpr bool BWD = PASS == PASS_BWD_C || PASS == PASS_BWD_D;
     constexpr bool BWD_LAST = (PASS == PASS_BWD_C && NL == 2) || (PASS == PASS_BWD_D && NL == 1);
@@ -353,13 +364,16 @@ int launch_pass(const sn2_sa* p, int training, hipStream_t st) {
     constexpr int LDS_PER_WAVE = BWD_LAST ? OuterAcc<CL, NL == 2 ? C1 : CIN>::LDS_FLOATS
                                           : (BWD_FIRST2 ? OuterAcc<C1, CIN>::LDS_FLOATS : 0);
     SaDev d = to_dev(p);
-    if (PASS == PASS_MAIN && !training) (NL == 2 ? d.k1 : d.k0).sum = nullptr;  // eval: no batch statistics
+    if (PASS == PASS_MAIN && !training) (NL == 2 ? d.k1 : d.k0).slots = nullptr;  // eval: no batch statistics
     const long ncent = (long)d.B * d.M;
     // forward passes: as many waves as centroids (up to 8 waves per SIMD worth); backward passes keep MFMA accumulators
     // per wave for the whole kernel, so use a fixed persistent grid and let each wave walk many centroids.
+    // forward: one statistics slot per workgroup (<= SN2_STAT_SLOTS); backward: one workgroup per CU, each wave walks
+    // many centroids and keeps its MFMA accumulators in registers for the whole kernel
     int blocks = sn2_cdiv(ncent, 4);
-    const int cap_blocks = BWD ? 256 * 4 : 256 * 8;
+    const int cap_blocks = BWD ? 256 : SN2_STAT_SLOTS;
     if (blocks > cap_blocks) blocks = cap_blocks;
+    if (nblocks_out) *nblocks_out = blocks;
     constexpr size_t lds_bytes = (size_t)LDS_PER_WAVE * 4 * sizeof(float);
     if (lds_bytes > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_pass_kernel<CF, NL, C1, C2, PASS>),
@@ -385,12 +399,13 @@ int launch_pass(const sn2_sa* p, int training, hipStream_t st) {
 template <int CF, int NL, int C1, int C2>
 int forward_t(const sn2_sa* p, int training, hipStream_t st) {
     const sn2_block* last = &p->blk[NL - 1];
+    int nb = 0;
     if (NL == 2) {
-        if (training) SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_STATS0>(p, training, st)));
-        SN2_TRY(sn2_bn_finalize(&p->blk[0], p->total, 0, training, st));
+        if (training) SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_STATS0>(p, training, st, &nb)));
+        SN2_TRY(sn2_bn_finalize(&p->blk[0], nb, p->total, 0, training, st));
     }
-    SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_MAIN>(p, training, st)));
-    SN2_TRY(sn2_bn_finalize(last, p->total, 0, training, st));
+    SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_MAIN>(p, training, st, &nb)));
+    SN2_TRY(sn2_bn_finalize(last, nb, p->total, 0, training, st));
     const int rows = p->B * p->M, C = last->cout;
     hipLaunchKernelGGL(sa_finalize_kernel, dim3(sn2_cdiv((long)rows * C, 256)), dim3(256), 0, st, p->ext, p->arg, last->a,
                        last->c, rows, C, p->out);
@@ -405,7 +420,7 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
     if (pb > 128) pb = 128;
     hipLaunchKernelGGL(sa_bwd_prep_kernel, dim3(pb), dim3(256), 0, st, p->dout, p->ext, p->arg, last->mean, last->invstd,
                        rows, C, last->dgamma, last->dbeta);
-    if (NL == 2) SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_BWD_C>(p, 1, st)));
+    if constexpr (NL == 2) SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_BWD_C>(p, 1, st)));
     SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_BWD_D>(p, 1, st)));
     return 0;
 }

@@ -17,6 +17,54 @@ from ._lib import FP, SA, Block, Head, check
 I32, F32, F64, I64 = torch.int32, torch.float32, torch.float64, torch.int64
 
 
+# ---- optional per-entry-point timing with HIP events on torch's current stream (the stream every kernel is launched
+# on).  bench.py switches it on for the entry points whose roofline it reports; None = off (no overhead).
+_timing = None
+
+
+class timing:
+    """with timing({"sn2_fps", ...}) as t: ... ; t.summary() -> {name: (calls, total_ms)} after a device sync."""
+
+    def __init__(self, names=None):
+        self.names = None if names is None else set(names)
+        self.events = []
+
+    def __enter__(self):
+        global _timing
+        self._prev, _timing = _timing, self
+        return self
+
+    def __exit__(self, *exc):
+        global _timing
+        _timing = self._prev
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.events:
+            c, t = out.get(name, (0, 0.0))
+            out[name] = (c + 1, t + a.elapsed_time(b))
+        return out
+
+
+def _call(name, *args, tag=None):
+    fn = getattr(_lib.load(), name)
+    t = _timing
+    if tag is not None:
+        key = f"{name}:{tag}"
+    else:
+        key = name
+    if t is not None and (t.names is None or key in t.names):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        t.events.append((key, a, b))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -66,7 +114,7 @@ def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor) -> torch.Tensor:
     _chk(cloud, F32, (B, C, N), "cloud")
     _chk(xyz, F32, (B, 3, N), "xyz")
     rows0 = torch.empty(B * N, 12, dtype=F32, device=cloud.device)
-    check(_lib.load().sn2_pack_rows(_ptr(cloud), _ptr(xyz), B, C, N, _ptr(rows0), _stream()), "sn2_pack_rows")
+    _call("sn2_pack_rows", _ptr(cloud), _ptr(xyz), B, C, N, _ptr(rows0), _stream())
     return rows0
 
 
@@ -82,7 +130,7 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None):
     idx = torch.empty(B, m, dtype=I32, device=dev)
     cs = torch.empty(B, 3, m, dtype=F32, device=dev)
     ca = torch.empty(B * m, 4, dtype=F32, device=dev)
-    check(_lib.load().sn2_fps(_ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _stream()), "sn2_fps")
+    _call("sn2_fps", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _stream(), tag=f"N={N}")
     return idx, cs, ca
 
 
@@ -101,8 +149,8 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
         total = torch.zeros(1, dtype=I64, device=dev)
     else:
         _chk(total, I64, (1,), "total")
-    check(_lib.load().sn2_ball_query(_ptr(src_soa), B, N, _ptr(cpos_soa), M, r2_threshold(r), cap, _ptr(nbr), _ptr(cnt),
-                                     _ptr(total), _stream()), "sn2_ball_query")
+    _call("sn2_ball_query", _ptr(src_soa), B, N, _ptr(cpos_soa), M, r2_threshold(r), cap, _ptr(nbr), _ptr(cnt),
+                                     _ptr(total), _stream(), tag=f"N={N}")
     return nbr, cnt, total
 
 
@@ -115,7 +163,7 @@ def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int):
     dev = src_soa.device
     idx = torch.empty(B * T, 3, dtype=I32, device=dev)
     w = torch.empty(B * T, 3, dtype=F32, device=dev)
-    check(_lib.load().sn2_three_nn(_ptr(src_soa), B, S, _ptr(dst_soa), T, k, _ptr(idx), _ptr(w), _stream()), "sn2_three_nn")
+    _call("sn2_three_nn", _ptr(src_soa), B, S, _ptr(dst_soa), T, k, _ptr(idx), _ptr(w), _stream(), tag=f"T={T}")
     return idx, w
 
 
@@ -129,11 +177,11 @@ class BlockBuffers:
         self.lin, self.bn = lin, bn
         self.cin, self.cout = lin.in_features, lin.out_features
         dev = lin.weight.device
-        # aux rows: a, c, mean, invstd (fp32);  stats rows: sum, sumsq (fp64, must be zero before a training forward)
+        # aux rows: a, c, mean, invstd (fp32);  stats: per-workgroup batch-statistics slots (no initialisation needed)
         self.aux = torch.empty(4, self.cout, dtype=F32, device=dev) if aux is None else aux
-        self.stats = torch.zeros(2, self.cout, dtype=F64, device=dev) if stats is None else stats
+        self.stats = torch.empty(_lib.STAT_SLOTS * 2 * self.cout, dtype=F32, device=dev) if stats is None else stats
         _chk(self.aux, F32, (4, self.cout), "aux")
-        _chk(self.stats, F64, (2, self.cout), "stats")
+        _chk(self.stats, F32, (_lib.STAT_SLOTS * 2 * self.cout,), "stat_slots")
         self.grads = None                                                 # (dW, db, dgamma, dbeta) views, set per backward
 
     def fill(self, blk: Block, with_grads: bool = False):
@@ -146,7 +194,7 @@ class BlockBuffers:
         blk.gamma, blk.beta = _ptr(self.bn.weight), _ptr(self.bn.bias)
         blk.running_mean, blk.running_var = _ptr(self.bn.running_mean), _ptr(self.bn.running_var)
         blk.a, blk.c, blk.mean, blk.invstd = (_ptr(self.aux[i]) for i in range(4))
-        blk.sum, blk.sumsq = _ptr(self.stats[0]), _ptr(self.stats[1])
+        blk.stat_slots = _ptr(self.stats)
         if with_grads:
             dW, db, dg, dbeta = self.grads
             for t, ref in ((dW, self.lin.weight), (db, self.lin.bias), (dg, self.bn.weight), (dbeta, self.bn.bias)):
@@ -194,11 +242,11 @@ def sa_desc(blocks, feat, cf, spos, cpos_aos, nbr, cnt, total, B, Nsrc, M, ext, 
 
 
 def sa_forward(d: SA, training: bool):
-    check(_lib.load().sn2_sa_forward(d, int(training), _stream()), "sn2_sa_forward")
+    _call("sn2_sa_forward", d, int(training), _stream(), tag=f"cf={d.cf}")
 
 
 def sa_backward(d: SA):
-    check(_lib.load().sn2_sa_backward(d, _stream()), "sn2_sa_backward")
+    _call("sn2_sa_backward", d, _stream(), tag=f"cf={d.cf}")
 
 
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
@@ -247,11 +295,11 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
 
 
 def fp_forward(d: FP, training: bool):
-    check(_lib.load().sn2_fp_forward(d, int(training), _stream()), "sn2_fp_forward")
+    _call("sn2_fp_forward", d, int(training), _stream(), tag=f"{d.ca}+{d.cb}->{d.blk.cout}")
 
 
 def fp_backward(d: FP):
-    check(_lib.load().sn2_fp_backward(d, _stream()), "sn2_fp_backward")
+    _call("sn2_fp_backward", d, _stream(), tag=f"{d.ca}+{d.cb}->{d.blk.cout}")
 
 
 def plot_max_forward(h, a, c, B, R_per_plot, C):
@@ -261,8 +309,7 @@ def plot_max_forward(h, a, c, B, R_per_plot, C):
     _chk(c, F32, (C,), "c")
     out = torch.empty(B, C, dtype=F32, device=h.device)
     arg = torch.empty(B, C, dtype=I32, device=h.device)
-    check(_lib.load().sn2_plot_max_forward(_ptr(h), _ptr(a), _ptr(c), B, R_per_plot, C, _ptr(out), _ptr(arg), _stream()),
-          "sn2_plot_max_forward")
+    _call("sn2_plot_max_forward", _ptr(h), _ptr(a), _ptr(c), B, R_per_plot, C, _ptr(out), _ptr(arg), _stream())
     return out, arg
 
 
@@ -271,8 +318,7 @@ def plot_max_backward(dout, arg, B, R_per_plot, C, dy):
     _chk(dout, F32, (B, C), "dout")
     _chk(arg, I32, (B, C), "arg")
     _chk(dy, F32, (B * R_per_plot, hs), "dy")
-    check(_lib.load().sn2_plot_max_backward(_ptr(dout), _ptr(arg), B, R_per_plot, C, _ptr(dy), _stream()),
-          "sn2_plot_max_backward")
+    _call("sn2_plot_max_backward", _ptr(dout), _ptr(arg), B, R_per_plot, C, _ptr(dy), _stream())
 
 
 def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dproba=None, dy=None, grads=None) -> Head:
@@ -305,11 +351,11 @@ def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dpro
 
 
 def head_forward(d: Head):
-    check(_lib.load().sn2_head_forward(d, _stream()), "sn2_head_forward")
+    _call("sn2_head_forward", d, _stream())
 
 
 def head_backward(d: Head):
-    check(_lib.load().sn2_head_backward(d, _stream()), "sn2_head_backward")
+    _call("sn2_head_backward", d, _stream())
 
 
 # ---------------------------------------------------------------------------------------------- projections
@@ -333,8 +379,8 @@ def plot_project_forward(pred_pointwise: torch.Tensor, clouds_dev: torch.Tensor,
     arg = torch.empty(B * D * D * 3, dtype=I32, device=dev)
     nocc = torch.empty(B, dtype=I32, device=dev)
     pred = torch.empty(B, 4, dtype=F32, device=dev)
-    check(_lib.load().sn2_plot_project_forward(_ptr(pred_pointwise), _ptr(t), stride, B, N, D, _ptr(keys), _ptr(pix),
-                                               _ptr(arg), _ptr(nocc), _ptr(pred), _stream()), "sn2_plot_project_forward")
+    _call("sn2_plot_project_forward", _ptr(pred_pointwise), _ptr(t), stride, B, N, D, _ptr(keys), _ptr(pix),
+                                               _ptr(arg), _ptr(nocc), _ptr(pred), _stream())
     return pred, pix, arg, nocc
 
 
@@ -344,8 +390,7 @@ def plot_project_backward(dpred, arg, nocc, B, N, diam_pix):
     _chk(arg, I32, (B * D * D * 3,), "arg")
     _chk(nocc, I32, (B,), "nocc")
     dpw = torch.zeros(B * N, 4, dtype=F32, device=dpred.device)
-    check(_lib.load().sn2_plot_project_backward(_ptr(dpred), _ptr(arg), _ptr(nocc), B, N, D, _ptr(dpw), _stream()),
-          "sn2_plot_project_backward")
+    _call("sn2_plot_project_backward", _ptr(dpred), _ptr(arg), _ptr(nocc), B, N, D, _ptr(dpw), _stream())
     return dpw
 
 
@@ -359,8 +404,8 @@ def raster_project(coverages: torch.Tensor, clouds_dev: torch.Tensor, diam_pix: 
     keys = torch.empty(B * D * D * 3, dtype=I64, device=dev)
     pix = torch.empty(B * N, dtype=I32, device=dev)
     rasters = torch.empty(B, 3, D, D, dtype=F32, device=dev)
-    check(_lib.load().sn2_raster_project(_ptr(coverages), _ptr(t), stride, B, N, D, int(diam_meters), _ptr(keys),
-                                         _ptr(pix), _ptr(rasters), _stream()), "sn2_raster_project")
+    _call("sn2_raster_project", _ptr(coverages), _ptr(t), stride, B, N, D, int(diam_meters), _ptr(keys),
+                                         _ptr(pix), _ptr(rasters), _stream())
     return rasters, pix
 
 
@@ -368,5 +413,5 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
     n = param.numel()
     for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(t, F32, (n,), nme)
-    check(_lib.load().sn2_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
-                                    weight_decay, int(step), grad_scale, _stream()), "sn2_adam_step")
+    _call("sn2_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
+                                    weight_decay, int(step), grad_scale, _stream())

@@ -1,0 +1,56 @@
+"""Flat-buffer optimiser and data-parallel gradient exchange for the timed training step.
+
+The reference's harness builds `optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd)`
+(`/root/reference/learning/train.py:180-185`).  `FlatAdam` is the same update rule (amsgrad off, L2 decay folded into
+the gradient, bias correction) as ONE kernel over the model's 14 997 parameters, which `flatten_parameters` re-homes
+into a single contiguous buffer (every nn.Parameter becomes a view of it, so `state_dict()` / `load_state_dict()` and
+any torch optimiser keep working).  The backward pass already writes all gradients into one flat buffer
+(`PointNet2._last_flat_grad`), so data parallelism is exactly one `all_reduce` of 60 KB per step.
+"""
+import torch
+
+from . import hip_ops as ops
+
+
+def flatten_parameters(model) -> torch.Tensor:
+    params = list(model.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.data = flat[o:o + n].view(p.shape)
+        o += n
+    model._flat_params = flat
+    return flat
+
+
+class FlatAdam:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None,
+                 world_size=1):
+        self.model = model
+        self.flat = getattr(model, "_flat_params", None)
+        if self.flat is None:
+            self.flat = flatten_parameters(model)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.world_size = world_size
+        self.process_group = process_group
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.parameters():
+            p.grad = None
+        self.model._last_flat_grad = None
+
+    def step(self):
+        g = self.model._last_flat_grad
+        if g is None:
+            raise RuntimeError("FlatAdam.step: no gradient (run backward through PointNet2 first)")
+        if self.world_size > 1:
+            # the only exchange step of the data-parallel path: one 60 KB sum over RCCL/xGMI; the 1/world scale is
+            # applied inside the Adam kernel
+            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+        self.step_count += 1
+        ops.adam_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                      self.weight_decay, self.step_count, 1.0 / self.world_size)

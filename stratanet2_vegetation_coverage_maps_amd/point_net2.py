@@ -26,7 +26,7 @@ from torch.nn import ReLU
 from torch.nn import Sequential as Seq
 
 from . import hip_ops as ops
-from ._lib import MAX_NEIGHBORS, StrataHipError
+from ._lib import MAX_NEIGHBORS, STAT_SLOTS, StrataHipError
 
 F32, I32, I64, F64 = torch.float32, torch.int32, torch.int64, torch.float64
 
@@ -76,9 +76,10 @@ def _blocks_of(seq, aux_arena, stats_arena, cursor):
         lin, bn = blk[0], blk[2]
         c = lin.out_features
         aux = aux_arena[cursor[0]:cursor[0] + 4 * c].view(4, c)
-        st = stats_arena[cursor[1]:cursor[1] + 2 * c].view(2, c)
+        ns = STAT_SLOTS * 2 * c
+        st = stats_arena[cursor[1]:cursor[1] + ns]
         cursor[0] += 4 * c
-        cursor[1] += 2 * c
+        cursor[1] += ns
         out.append(ops.BlockBuffers(lin, bn, aux, st))
     return out
 
@@ -117,6 +118,8 @@ class PointNet2(nn.Module):
         self.set_patience_attributes(args)
         self.log_embeddings = args.log_embeddings
         self.last_G_tensor = None
+        self._last_flat_grad = None
+        self._last_cloud_dev = None
         if self.n_class != 4 or self.n_input_feats != 8:
             raise ValueError("the HIP kernels cover the reference architecture: n_class=4, 10 input features")
         ndim = 3
@@ -181,10 +184,11 @@ class PointNet2(nn.Module):
         M1, M2 = self._sizes(N)
         s = _Saved()
         s.B, s.N, s.M1, s.M2 = B, N, M1, M2
-        # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd (fp32) and sum,sumsq (fp64)
+        # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd and the per-workgroup statistics
+        # slots (written before they are read: no zero fill)
         widths = [16, 16, 32, 64, 64, 34, 34]
         aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)
-        stats = torch.zeros(2 * sum(widths), dtype=F64, device=dev)
+        stats = torch.empty(STAT_SLOTS * 2 * sum(widths), dtype=F32, device=dev)
         cur = [0, 0]
         s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur)
         s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur)
