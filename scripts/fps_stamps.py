@@ -1,0 +1,32 @@
+"""Diagnostic: per-phase cycle shares of the bucketed FPS round loop (build with -DSN2_FPS_STAMPS; never shipped)."""
+import ctypes, subprocess, sys, os, time
+import torch
+sys.path.insert(0, ".")
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_batch
+csrc = "stratanet2_vegetation_coverage_maps_amd/csrc"
+so = "gpurun_out/libfps_dbg.so"
+extra = sys.argv[1:]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-DSN2_FPS_STAMPS"] + extra +
+                      [f"{csrc}/geometry.hip", "-o", so])
+lib = ctypes.CDLL(so)
+B, N, M = 16, 32768, 1024
+xyz = make_batch(B, N)["xyz"].cuda()
+idx = torch.empty(B, M, dtype=torch.int32, device="cuda"); cs = torch.empty(B, 3, M, device="cuda"); ca = torch.empty(B * M, 4, device="cuda")
+ws = torch.empty(5 * B * N, dtype=torch.int32, device="cuda")
+lib.sn2_fps.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
+def run():
+    rc = lib.sn2_fps(xyz.data_ptr(), B, N, M, None, idx.data_ptr(), cs.data_ptr(), ca.data_ptr(), ws.data_ptr(), None)
+    assert rc == 0, rc
+run(); torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 8)()
+lib.sn2_debug_fps_stamps(out); base = list(out)
+t = time.perf_counter(); run(); torch.cuda.synchronize(); el = time.perf_counter() - t
+lib.sn2_debug_fps_stamps(out)
+d = [out[i] - base[i] for i in range(8)]
+rounds = d[6]
+names = ["(a) tests", "(b) dirty loop", "(c) wave reduce+publish", "barrier wait", "(d) select/next sample"]
+tot = sum(d[:5])
+print(f"wall {el*1e3:.3f} ms for {rounds} rounds (stamped build); wave0: dirty buckets/round {d[5]/rounds:.2f}, tie rounds {d[7]}")
+for n, v in zip(names, d[:5]):
+    print(f"  {n:28s} {v/rounds:8.1f} ticks/round  {100*v/tot:5.1f}%")
+print(f"  total {tot/rounds:.1f} ticks/round (s_memtime ticks: 100 MHz? see guide) ")

@@ -60,6 +60,28 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+// ---- wave64 reductions on the DPP network (6 VALU ops, no LDS round trip; __shfl_xor lowers to ds_bpermute, whose
+// ~64-cycle latency per step dominated the sequential rounds of the FPS kernel).  Result is wave-uniform.
+#define SN2_DPP(x, ctrl, rmask) __builtin_amdgcn_update_dpp((x), (x), (ctrl), (rmask), 0xF, false)
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0xB1, 0xF)));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x4E, 0xF)));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x141, 0xF)));  // row_half_mirror
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x140, 0xF)));  // row_mirror: every lane = its row's max
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x142, 0xA)));  // row_bcast15 into rows 1,3
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x143, 0xC)));  // row_bcast31 into rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
+    v = min(v, (unsigned)SN2_DPP((int)v, 0xB1, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x4E, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x141, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x140, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x142, 0xA));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x143, 0xC));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // order-preserving map float -> uint32 (any non-NaN float maps to a value > 0)

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(1024) void interp_scatter_kernel(int R_per_plot, in
     // a group of 4 consecutive lanes... keep it simple: one lane per (row, channel) pair, channel fastest, so the 3 adds
     // of a wave-instruction land on contiguous LDS words of at most a few source rows.
     const long total = (long)(r_hi - r_lo) * CA;
+#pragma unroll 4
     for (long t = threadIdx.x; t < total; t += 1024) {
         const int rl = (int)(t / CA), k = (int)(t - (long)rl * CA);
         const size_t r = (size_t)b * R_per_plot + r_lo + rl;
@@ -323,7 +324,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     using Acc = OuterAcc<CO, CI + 1>;
     constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : ((Acc::LDS_FLOATS * 4 * 2 <= 150 * 1024) ? 2 : 1);
     const int R = p->B * p->R_per_plot;
-    int g1 = pick_grid(R, 256, 8);
+    int g1 = pick_grid(R, 256, R >= (1 << 18) ? 8 : 1);
     if (g1 > 256) g1 = 256;
     hipLaunchKernelGGL((fp_bwd_bn_kernel<CO>), dim3(g1), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
                        p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta);

@@ -112,10 +112,343 @@ static int launch_fps(const float* pos, int B, int N, int M, const int* start, i
     SN2_RETURN_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Bucketed FPS (exact).  The brute-force kernel above touches all N points in each of the M sequential rounds
+// (4.1 ms for 16 x 32768 -> 1024 on MI355X: 40 % of a training step).  But a new sample s only lowers the running
+// distance of points closer to s than their current distance, i.e. points near s.  So:
+//   * spatial_order_kernel sorts a plot's points by the Morton code of a 32x32x8 cell grid (LDS counting sort);
+//   * consecutive runs of 64 sorted points form a BUCKET = one VGPR slot of one wave (bucket b -> wave b % 16, slot
+//     b / 16, so spatially adjacent buckets sit in different waves and a round's work spreads over the 16 waves);
+//   * per bucket LDS keeps the bounding box and the maximum running distance; per round each wave tests its <= 32
+//     buckets (one lane each): a bucket can only change if  boxdist2(s) < bucket_max.  The test is EXACT, not a
+//     heuristic: boxdist2 is evaluated with the same canonical fp32 operations as sn2_d2, and fp32 rounding is
+//     monotone, so boxdist2(s) <= d2(p, s) for every point p of the box, bit for bit; if boxdist2(s) >= bucket_max
+//     then min(dist_p, d2(p,s)) == dist_p for all its points and skipping the bucket changes nothing.
+//   * dirty buckets are updated by their wave (x, y, z in VGPRs, running distance in LDS) and get a new maximum;
+//   * the next sample is the point of maximal running distance; exact ties are resolved towards the lowest ORIGINAL
+//     index, as torch.argmax does on the unsorted array (candidates = lanes whose distance equals the global maximum).
+// Result: bit-identical indices to the brute-force kernel, with ~20x fewer distance evaluations after the first rounds.
+// ------------------------------------------------------------------------------------------------------------
+// 16 x 16 x 16 cells over the plot's bounding box, full 3-D Morton order.  (Measured on the synthetic plots: 19.6 of 512
+// buckets change per FPS round on average, against 27.7 for a 32 x 32 x 8 grid whose two top levels split x,y only.)
+constexpr int ORDER_GX = 16, ORDER_GZ = 16, ORDER_CELLS = ORDER_GX * ORDER_GX * ORDER_GZ;
+
+__device__ __forceinline__ unsigned morton_cell(unsigned cx, unsigned cy, unsigned cz) {
+    unsigned c = 0;
+#pragma unroll
+    for (int bit = 3; bit >= 0; --bit) c = (c << 3) | (((cx >> bit) & 1u) << 2) | (((cy >> bit) & 1u) << 1) | ((cz >> bit) & 1u);
+    return c;
+}
+
+__global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
+                                                             float4* __restrict__ sorted) {
+    __shared__ int s_hist[ORDER_CELLS];
+    __shared__ float s_mm[6][16];
+    __shared__ int s_wsum[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* px = pos + (size_t)b * 3 * N;
+    const float* py = px + N;
+    const float* pz = py + N;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < N; i += 1024) {
+        const float v[3] = {px[i], py[i], pz[i]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], v[a]);
+            mx[a] = fmaxf(mx[a], v[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_min(mn[a]);
+        mx[a] = wave_max(mx[a]);
+        if (lane == 0) {
+            s_mm[a][wave] = mn[a];
+            s_mm[3 + a][wave] = mx[a];
+        }
+    }
+    for (int i = tid; i < ORDER_CELLS; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    float lo[3], sc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = s_mm[a][0], h = s_mm[3 + a][0];
+        for (int k = 1; k < 16; ++k) {
+            l = fminf(l, s_mm[a][k]);
+            h = fmaxf(h, s_mm[3 + a][k]);
+        }
+        lo[a] = l;
+        const float ext = fmaxf(h - l, 1e-6f);
+        sc[a] = (a < 2 ? (float)ORDER_GX : (float)ORDER_GZ) / ext;
+    }
+    auto cell_of = [&](int i) -> unsigned {
+        int cx = (int)((px[i] - lo[0]) * sc[0]), cy = (int)((py[i] - lo[1]) * sc[1]), cz = (int)((pz[i] - lo[2]) * sc[2]);
+        cx = cx < 0 ? 0 : (cx > ORDER_GX - 1 ? ORDER_GX - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > ORDER_GX - 1 ? ORDER_GX - 1 : cy);
+        cz = cz < 0 ? 0 : (cz > ORDER_GZ - 1 ? ORDER_GZ - 1 : cz);
+        return morton_cell((unsigned)cx, (unsigned)cy, (unsigned)cz);
+    };
+    for (int i = tid; i < N; i += 1024) atomicAdd(&s_hist[cell_of(i)], 1);
+    __syncthreads();
+    // exclusive scan over the cells: PER consecutive cells per thread, wave scan, 16 wave totals
+    constexpr int PER = ORDER_CELLS / 1024;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        loc[k] = s_hist[tid * PER + k];
+        sum += loc[k];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += s_wsum[k];
+    int run = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        s_hist[tid * PER + k] = run;
+        run += loc[k];
+    }
+    __syncthreads();
+    int* ob = order + (size_t)b * N;
+    float4* sb = sorted + (size_t)b * N;
+    for (int i = tid; i < N; i += 1024) {
+        const int p = atomicAdd(&s_hist[cell_of(i)], 1);
+        ob[p] = i;
+        sb[p] = make_float4(px[i], py[i], pz[i], 0.f);
+    }
+}
+
+// canonical, monotone lower bound of sn2_d2(p, c) over all p inside the box [lo, hi]
+__device__ __forceinline__ float sn2_box_d2(float lx, float ly, float lz, float hx, float hy, float hz, float cx, float cy,
+                                            float cz) {
+#pragma clang fp contract(off)
+    const float dx = fmaxf(fmaxf(lx - cx, cx - hx), 0.f);
+    const float dy = fmaxf(fmaxf(ly - cy, cy - hy), 0.f);
+    const float dz = fmaxf(fmaxf(lz - cz, cz - hz), 0.f);
+    const float xx = dx * dx;
+    const float yy = dy * dy;
+    const float zz = dz * dz;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+// SPW = bucket slots per wave (bucket b lives in wave b % 16, slot b / 16); 16 waves.  The sorted points stay in
+// global memory (an L2-resident 16 B x N table, one dwordx4 per lane fetches a whole bucket); LDS holds the running
+// distances, the bucket boxes and each bucket's current farthest point; registers hold no per-point state, so the
+// round loop is a short body executed only for the buckets that can change (no 32-way unrolled branch chain: that
+// version was instruction-fetch bound).
+#ifdef SN2_FPS_STAMPS
+// diagnostic build only (never shipped): per-phase cycle totals of wave 0 of workgroup 0
+__device__ unsigned long long g_fps_dbg[8];
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+extern "C" int sn2_debug_fps_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fps_dbg), sizeof(g_fps_dbg));
+}
+#else
+#define STAMP(var)
+#endif
+
+template <int SPW, int NW>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __restrict__ pos, int N, int M,
+                                                          const int* __restrict__ start, const int* __restrict__ order,
+                                                          const float4* __restrict__ sorted, int* __restrict__ idx_out,
+                                                          float* __restrict__ cpos_soa, float* __restrict__ cpos_aos) {
+    constexpr int NBK = SPW * NW;
+    static_assert(SPW <= 64 && NW <= 16, "one lane per bucket slot of the wave");
+    __shared__ float s_dist[SPW * NW * 64];            // running min distance, [wave][slot][lane]
+    __shared__ float s_box[6 * NBK];                   // bucket boxes, [component][wave][slot]: lane j reads word j of its
+                                                       // wave's row => conflict-free (an AoS box layout cost 32-way conflicts)
+    __shared__ float4 s_xchg[2][2][NW];                // per wave: (max distance, tie flag, -, -) and (x, y, z, sorted position)
+    __shared__ unsigned s_win;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* px = pos + (size_t)b * 3 * N;
+    const float* py = px + N;
+    const float* pz = py + N;
+    const int* ord = order + (size_t)b * N;
+    const float4* pts = sorted + (size_t)b * N;
+    float* my_dist = s_dist + wave * SPW * 64 + lane;
+    float* my_box = s_box + wave * SPW;                // + component * NBK + slot
+    for (int k = 0; k < SPW; ++k) {
+        const int p = (k * NW + wave) * 64 + lane;     // position in the sorted order (bucket k*NW + wave)
+        const bool v = p < N;
+        const float4 q = v ? pts[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        my_dist[k * 64] = v ? INFINITY : -1.f;
+        const float lx = -wave_max_dpp(v ? -q.x : -INFINITY), ly = -wave_max_dpp(v ? -q.y : -INFINITY),
+                    lz = -wave_max_dpp(v ? -q.z : -INFINITY);
+        const float hx = wave_max_dpp(v ? q.x : -INFINITY), hy = wave_max_dpp(v ? q.y : -INFINITY),
+                    hz = wave_max_dpp(v ? q.z : -INFINITY);
+        if (lane == 0) {
+            my_box[0 * NBK + k] = lx; my_box[1 * NBK + k] = ly; my_box[2 * NBK + k] = lz;
+            my_box[3 * NBK + k] = hx; my_box[4 * NBK + k] = hy; my_box[5 * NBK + k] = hz;
+        }
+    }
+    // lane j < SPW keeps the state of bucket slot j of this wave in registers: its maximal running distance, the point
+    // attaining it (lowest lane on ties) and whether several points share the maximum (then the lowest ORIGINAL index must
+    // be found the slow way)
+    float mine = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+    int bpos = 0;
+    bool tiej = false;
+    if (lane < SPW && (lane * NW + wave) * 64 < N) mine = INFINITY;
+    int cur = start ? start[b] : 0;
+    cur = cur < 0 ? 0 : (cur >= N ? N - 1 : cur);
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    float cx = px[cur], cy = py[cur], cz = pz[cur];
+    int cur_pos = -1;                                   // >= 0: the sample is sorted point cur_pos (index = ord[cur_pos])
+    __syncthreads();
+
+    // one dirty bucket: new distances, bucket maximum, its point -> the registers of lane k
+    auto update = [&](int k, int p, const float4& q) {
+        const float d = my_dist[k * 64];
+        const float dd = sn2_d2(q.x, q.y, q.z, cx, cy, cz);
+        const float nd = d < 0.f ? d : fminf(d, dd);   // padding lanes stay at -1
+        my_dist[k * 64] = nd;
+        const float m = wave_max_dpp(nd);
+        const unsigned long long bal = __ballot(nd == m);
+        const int first = __ffsll((long long)bal) - 1;
+        const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), first));
+        const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), first));
+        const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), first));
+        if (lane == k) {
+            mine = m;
+            tiej = __popcll(bal) > 1;
+            bx = fx;
+            by = fy;
+            bz = fz;
+            bpos = p - lane + first;
+        }
+    };
+
+    for (int i = 0; i < M; ++i) {
+        if (tid == 0) {
+            const int oi = cur_pos >= 0 ? ord[cur_pos] : cur;
+            idx_out[(size_t)b * M + i] = oi;
+            cpos_soa[((size_t)b * 3 + 0) * M + i] = cx;
+            cpos_soa[((size_t)b * 3 + 1) * M + i] = cy;
+            cpos_soa[((size_t)b * 3 + 2) * M + i] = cz;
+            reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M + i] = make_float4(cx, cy, cz, 0.f);
+        }
+        if (i == M - 1) break;
+        STAMP(t0);
+        // (a) which of this wave's buckets can change?  lane j tests slot j
+        bool dirty = false;
+        if (lane < SPW) {
+            dirty = sn2_box_d2(my_box[0 * NBK + lane], my_box[1 * NBK + lane], my_box[2 * NBK + lane], my_box[3 * NBK + lane],
+                               my_box[4 * NBK + lane], my_box[5 * NBK + lane], cx, cy, cz) < mine;
+        }
+        unsigned long long mask = __ballot(dirty);
+        STAMP(t1);
+#ifdef SN2_FPS_STAMPS
+        const int ndirty = __popcll(mask);
+#endif
+        // (b) update the dirty buckets, four at a time so that their L2 loads overlap
+        while (mask) {
+            int k[4], p[4];
+            bool on[4];
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                on[u] = mask != 0;
+                k[u] = on[u] ? __ffsll((long long)mask) - 1 : 0;
+                mask &= mask - 1;   // no-op when mask == 0
+                p[u] = (k[u] * NW + wave) * 64 + lane;
+                q[u] = pts[p[u] < N ? p[u] : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (on[u]) update(k[u], p[u], q[u]);   // the round loop is VALU-issue bound: no duplicated work
+        }
+        STAMP(t2);
+        // (c) this wave's best bucket, then ONE barrier and the best of the 16 waves
+        const float wm = wave_max_dpp(lane < SPW ? mine : -1.f);
+        const unsigned long long balw = __ballot(lane < SPW && mine == wm);
+        const int slot = __ffsll((long long)balw) - 1;
+        if (lane == slot) {
+            const int wtie = (__popcll(balw) > 1) || tiej;
+            s_xchg[i & 1][0][wave] = make_float4(wm, __int_as_float(wtie), 0.f, 0.f);
+            s_xchg[i & 1][1][wave] = make_float4(bx, by, bz, __int_as_float(bpos));
+        }
+        STAMP(t3);
+        __syncthreads();
+        STAMP(t4);
+        const float4 e = s_xchg[i & 1][0][lane & (NW - 1)];
+        const float4 r = s_xchg[i & 1][1][lane & (NW - 1)];
+        const float V = wave_max_dpp(e.x);
+        const unsigned balv = (unsigned)__ballot(e.x == V) & ((1u << NW) - 1u);
+        const int ww = __ffs(balv) - 1;
+        const bool gtie = (__popc(balv) > 1) || (__builtin_amdgcn_readlane(__float_as_int(e.y), ww) != 0);
+        if (!gtie) {
+            cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.x), ww));
+            cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.y), ww));
+            cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.z), ww));
+            cur_pos = __builtin_amdgcn_readlane(__float_as_int(r.w), ww);
+        } else {
+            // rare exact tie of the maximal distance (duplicated points): lowest ORIGINAL index among all candidates
+            if (tid == 0) s_win = 0xFFFFFFFFu;
+            __syncthreads();
+            unsigned long long cand = __ballot(lane < SPW && mine == V);
+            while (cand) {
+                const int kk = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const float d = my_dist[kk * 64];
+                unsigned oi = 0xFFFFFFFFu;
+                if (d == V) oi = (unsigned)ord[(kk * NW + wave) * 64 + lane];
+                oi = wave_min_u32_dpp(oi);
+                if (lane == 0) atomicMin(&s_win, oi);
+            }
+            __syncthreads();
+            cur = __builtin_amdgcn_readfirstlane((int)s_win);
+            cur_pos = -1;
+            cx = px[cur];
+            cy = py[cur];
+            cz = pz[cur];
+        }
+#ifdef SN2_FPS_STAMPS
+        STAMP(t5);
+        if (b == 0 && tid == 0) {
+            g_fps_dbg[0] += t1 - t0;
+            g_fps_dbg[1] += t2 - t1;
+            g_fps_dbg[2] += t3 - t2;
+            g_fps_dbg[3] += t4 - t3;
+            g_fps_dbg[4] += t5 - t4;
+            g_fps_dbg[5] += (unsigned long long)ndirty;
+            g_fps_dbg[6] += 1;
+            g_fps_dbg[7] += gtie ? 1 : 0;
+        }
+#endif
+    }
+}
+
+template <int SPW, int NW = 16>
+static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* start, int* ws, int* idx, float* cs,
+                             float* ca, hipStream_t st) {
+    int* order = ws;                                               // B*N ints
+    float4* sorted = reinterpret_cast<float4*>(ws + (size_t)B * N);   // B*N float4 (16-byte aligned: B*N*4 bytes offset
+                                                                   // from a 16-byte aligned base with B*N % 4 == 0)
+    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), 0, st, pos, N, order, sorted);
+    hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), 0, st, pos, N, M, start, (const int*)order,
+                       (const float4*)sorted, idx, cs, ca);
+    SN2_RETURN_LAUNCH();
+}
+
 extern "C" int sn2_fps(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
-                       float* cpos_aos, void* stream) {
+                       float* cpos_aos, int* order_ws, void* stream) {
     if (!pos_soa || !idx || !cpos_soa || !cpos_aos || B <= 0 || N <= 0 || M <= 0 || M > N) return SN2_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (order_ws && N > 2048 && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
+        // bucketed path (exact, see above); the running distances of a plot must fit LDS: N <= 32768
+        if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 32768) return launch_fps_bucket<32>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        return SN2_ELIMIT;
+    }
     if (N <= 256) return launch_fps<1, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 512) return launch_fps<2, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 1024) return launch_fps<4, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);

@@ -3,25 +3,35 @@
 
 // ------------------------------------------------------------------------------------------------------------
 // BatchNorm1d finalisation (torch defaults: eps 1e-5, momentum 0.1, biased variance to normalise, unbiased variance
-// into running_var) -- model/point_net2.py:45-53.  One thread per channel; the sums arrive as fp64 atomics.
+// into running_var) -- model/point_net2.py:45-53.  The sums arrive as per-workgroup fp32 slots.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ a, float* __restrict__ c, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, const float* __restrict__ slots, int nslots,
                                    const unsigned long long* __restrict__ count_dev, long count_imm, int training) {
-    const int o = threadIdx.x;
-    if (o >= C) return;
+    // 16 lanes per channel: lane j adds slots j, j+16, ... in fp64 (independent loads, fixed order), then a fixed-shape
+    // 16-lane tree: the statistics are identical from run to run.
+    const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const bool live = o < C;
     const float eps = 1e-5f, mom = 0.1f;
+    double s1 = 0.0, s2 = 0.0;
+    if (training && live) {
+        for (int k = j; k < nslots; k += 16) {
+            s1 += (double)slots[(size_t)k * 2 * C + o];
+            s2 += (double)slots[(size_t)k * 2 * C + C + o];
+        }
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1) {
+        s1 += __shfl_xor(s1, w);
+        s2 += __shfl_xor(s2, w);
+    }
+    if (!live || j != 0) return;
     float mean, invstd;
     if (training) {
         double n = count_dev ? (double)(*count_dev) : (double)count_imm;
         if (n < 1.0) n = 1.0;
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nslots; ++k) {  // fixed order: deterministic statistics
-            s1 += (double)slots[(size_t)k * 2 * C + o];
-            s2 += (double)slots[(size_t)k * 2 * C + C + o];
-        }
         const double m = s1 / n;
         double var = s2 / n - m * m;
         if (var < 0.0) var = 0.0;
@@ -45,7 +55,7 @@ int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* 
                     hipStream_t st) {
     if (!blk || blk->cout <= 0 || blk->cout > 64 || nslots < 0 || nslots > SN2_STAT_SLOTS) return SN2_EINVAL;
     if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
                        blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
                        count_dev, count_imm, training);
     SN2_RETURN_LAUNCH();

@@ -313,10 +313,9 @@ __global__ __launch_bounds__(256) void sa_bwd_prep_kernel(const float* __restric
                                                           const float* __restrict__ invstd, int rows, int C,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int o = threadIdx.x % C, g = threadIdx.x / C, G = 256 / C;
-    if (g >= G) return;
     float sb = 0.f, sg = 0.f;
     const float mu = mean[o], is = invstd[o];
-    for (int r = blockIdx.x * G + g; r < rows; r += gridDim.x * G) {
+    for (int r = blockIdx.x * G + g; g < G && r < rows; r += gridDim.x * G) {
         const size_t i = (size_t)r * C + o;
         if (arg[i] >= 0) {
             const float gch = dout[i];
@@ -324,8 +323,19 @@ __global__ __launch_bounds__(256) void sa_bwd_prep_kernel(const float* __restric
             sg = fmaf(gch, (ext[i] - mu) * is, sg);
         }
     }
-    atomicAdd(&dbeta[o], sb);
-    atomicAdd(&dgamma[o], sg);
+    // workgroup-level reduction first (256 threads -> 2*C values), then one global atomic per value
+    __shared__ float s_red[128];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.f;
+    __syncthreads();
+    if (g < G) {
+        atomicAdd(&s_red[o], sb);
+        atomicAdd(&s_red[C + o], sg);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        const float v = s_red[threadIdx.x];
+        if (v != 0.f) atomicAdd(threadIdx.x < C ? &dbeta[threadIdx.x] : &dgamma[threadIdx.x - C], v);
+    }
 }
 
 BlkDev to_dev(const sn2_block& k) {
@@ -371,7 +381,7 @@ int launch_pass(const sn2_sa* p, int training, hipStream_t st, int* nblocks_out 
     // forward: one statistics slot per workgroup (<= SN2_STAT_SLOTS); backward: one workgroup per CU, each wave walks
     // many centroids and keeps its MFMA accumulators in registers for the whole kernel
     int blocks = sn2_cdiv(ncent, 4);
-    const int cap_blocks = BWD ? 256 : SN2_STAT_SLOTS;
+    const int cap_blocks = SN2_STAT_SLOTS;
     if (blocks > cap_blocks) blocks = cap_blocks;
     if (nblocks_out) *nblocks_out = blocks;
     constexpr size_t lds_bytes = (size_t)LDS_PER_WAVE * 4 * sizeof(float);
@@ -417,7 +427,7 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
     const sn2_block* last = &p->blk[NL - 1];
     const int rows = p->B * p->M, C = last->cout;
     int pb = sn2_cdiv(rows, 256 / C);
-    if (pb > 128) pb = 128;
+    if (pb > 256) pb = 256;
     hipLaunchKernelGGL(sa_bwd_prep_kernel, dim3(pb), dim3(256), 0, st, p->dout, p->ext, p->arg, last->mean, last->invstd,
                        rows, C, last->dgamma, last->dbeta);
     if constexpr (NL == 2) SN2_TRY((launch_pass<CF, NL, C1, C2, PASS_BWD_C>(p, 1, st)));

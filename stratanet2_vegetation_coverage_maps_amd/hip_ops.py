@@ -118,8 +118,9 @@ def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor) -> torch.Tensor:
     return rows0
 
 
-def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None):
-    """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4)."""
+def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True):
+    """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
+    bucketed=False forces the brute-force kernel (same result; kept for cross-checks)."""
     B, three, N = pos_soa.shape
     _chk(pos_soa, F32, (B, 3, N), "pos_soa")
     if not (1 <= m <= N):
@@ -130,7 +131,9 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None):
     idx = torch.empty(B, m, dtype=I32, device=dev)
     cs = torch.empty(B, 3, m, dtype=F32, device=dev)
     ca = torch.empty(B * m, 4, dtype=F32, device=dev)
-    _call("sn2_fps", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _stream(), tag=f"N={N}")
+    order = torch.empty(5 * B * N, dtype=I32, device=dev) if (bucketed and N > 2048) else None
+    _call("sn2_fps", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), _stream(),
+          tag=f"N={N}")
     return idx, cs, ca
 
 

@@ -26,7 +26,9 @@ from torch.nn import ReLU
 from torch.nn import Sequential as Seq
 
 from . import hip_ops as ops
-from ._lib import MAX_NEIGHBORS, STAT_SLOTS, StrataHipError
+from ._lib import MAX_NEIGHBORS as _MAXN, STAT_SLOTS, StrataHipError
+
+MAX_NEIGHBORS = int(os.environ.get('SN2_DEBUG_CAP', _MAXN))  # debug knob only; the reference value is 2000
 
 F32, I32, I64, F64 = torch.float32, torch.int32, torch.int64, torch.float64
 

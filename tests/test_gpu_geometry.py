@@ -30,6 +30,22 @@ def test_fps_matches_oracle_exactly(B, N, M):
     assert torch.equal(ca.cpu().view(B, M, 4)[..., :3], g.permute(0, 2, 1))
 
 
+@pytest.mark.parametrize("B,N,M", [(2, 32768, 1024), (3, 5000, 1250), (2, 20000, 700), (1, 2049, 100)])
+def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
+    """The bucketed kernel prunes work with an exact bound: indices must be identical to the brute-force kernel and to
+    the oracle, including on exact distance ties (a quarter of the points are duplicated here)."""
+    xyz, _ = _pos(B, N, first=21)
+    q = N // 4
+    xyz[:, :, N - q:] = xyz[:, :, :q]                                     # duplicates far apart in index
+    start = torch.tensor([(977 * b + 13) % N for b in range(B)])
+    dev = xyz.to(DEV)
+    i_b, cs_b, _ = ops.fps(dev, M, start.to(DEV, torch.int32), bucketed=True)
+    i_f, cs_f, _ = ops.fps(dev, M, start.to(DEV, torch.int32), bucketed=False)
+    assert torch.equal(i_b, i_f) and torch.equal(cs_b, cs_f)
+    ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, start)
+    assert torch.equal(i_b.cpu().long(), ref)
+
+
 def test_fps_with_duplicate_points_and_default_start():
     """sample_cloud pads small plots by sampling with replacement (loader.py:238-244) => exact ties."""
     xyz, _ = _pos(1, 500)
