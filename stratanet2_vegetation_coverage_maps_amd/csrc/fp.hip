@@ -275,19 +275,35 @@ __global__ __launch_bounds__(1024) void interp_scatter_kernel(int R_per_plot, in
     const int rows_per_slice = (R_per_plot + gridDim.x - 1) / gridDim.x;
     const int r_lo = blockIdx.x * rows_per_slice;
     const int r_hi = min(R_per_plot, r_lo + rows_per_slice);
-    // a group of 4 consecutive lanes... keep it simple: one lane per (row, channel) pair, channel fastest, so the 3 adds
-    // of a wave-instruction land on contiguous LDS words of at most a few source rows.
-    const long total = (long)(r_hi - r_lo) * CA;
-#pragma unroll 4
-    for (long t = threadIdx.x; t < total; t += 1024) {
-        const int rl = (int)(t / CA), k = (int)(t - (long)rl * CA);
-        const size_t r = (size_t)b * R_per_plot + r_lo + rl;
-        const float w0 = knn_w[r * 3 + 0], w1 = knn_w[r * 3 + 1], w2 = knn_w[r * 3 + 2];
-        const float g = du[r * CA + k] / ((w0 + w1) + w2);
-        const int i0 = knn_idx[r * 3 + 0], i1 = knn_idx[r * 3 + 1], i2 = knn_idx[r * 3 + 2];
-        if (i0 >= s_lo && i0 < s_hi) atomicAdd(&tile[(i0 - s_lo) * CA + k], g * w0);
-        if (w1 != 0.f && i1 >= s_lo && i1 < s_hi) atomicAdd(&tile[(i1 - s_lo) * CA + k], g * w1);
-        if (w2 != 0.f && i2 >= s_lo && i2 < s_hi) atomicAdd(&tile[(i2 - s_lo) * CA + k], g * w2);
+    // one wave per target row, lane = channel: the row's 3 neighbour indices / weights are wave-uniform (scalar loads),
+    // its du row is one coalesced load and the three LDS float atomics of a wave-instruction hit consecutive words.
+    // Four rows in flight per wave hide the load latency (the first version, one (row, channel) pair per lane with
+    // dependent loads, was latency-bound at 300 us for FP1).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r0 = r_lo + wave * 4; r0 < r_hi; r0 += 16 * 4) {
+        float g[4], w[4][3];
+        int id[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rl = min(r0 + u, r_hi - 1);
+            const size_t r = (size_t)b * R_per_plot + rl;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                w[u][j] = knn_w[r * 3 + j];
+                id[u][j] = knn_idx[r * 3 + j];
+            }
+            g[u] = (lane < CA && r0 + u < r_hi) ? du[r * CA + lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u >= r_hi || lane >= CA) continue;
+            const float gs = g[u] / ((w[u][0] + w[u][1]) + w[u][2]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int i = id[u][j];
+                if ((j == 0 || w[u][j] != 0.f) && i >= s_lo && i < s_hi) atomicAdd(&tile[(i - s_lo) * CA + lane], gs * w[u][j]);
+            }
+        }
     }
     __syncthreads();
     float* dst = dsrc + ((size_t)b * S_per_plot + s_lo) * dsrc_stride;
@@ -295,6 +311,161 @@ __global__ __launch_bounds__(1024) void interp_scatter_kernel(int R_per_plot, in
         const float v = tile[i];
         const int sr = i / CA, k = i - sr * CA;
         if (v != 0.f) atomicAdd(&dst[(size_t)sr * dsrc_stride + k], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- small layers
+// Layers with few rows (SA3, FP3, FP2: 4k-16k rows, up to 96 -> 64 channels) gain nothing from one long FMA stream per
+// lane: 4096 rows are only 64 waves on a 1024-SIMD chip and each wave would issue >6000 dependent FMAs (the first
+// version ran 0.3-0.7 ms per kernel at ~1 % of the chip).  Here one workgroup = 64 rows x 4 waves and wave g owns the
+// output channels [g*COG, (g+1)*COG): 4x the waves, 4x shorter streams, the same weights-in-SGPR inner loops.
+template <int CA, int CB, int CO, bool KNN>
+__global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot, int S_per_plot, int src_stride,
+                                                           int skip_stride, int h_stride, const float* __restrict__ src,
+                                                           const float* __restrict__ src_a, const float* __restrict__ src_c,
+                                                           const int* __restrict__ knn_idx, const float* __restrict__ knn_w,
+                                                           const float* __restrict__ skip, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ h,
+                                                           float* __restrict__ slots) {
+    constexpr int CI = CA + CB, COG = (CO + 3) / 4;
+    __shared__ float s_red[2 * CO];
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long r = (long)blockIdx.x * 64 + lane;
+    const bool valid = r < R;
+    const size_t rr = valid ? (size_t)r : (size_t)(R - 1);
+    float u[CI + 1];
+    build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, rr,
+                             (rr / R_per_plot) * S_per_plot, u);
+    float* hr = h + rr * h_stride;
+#pragma unroll
+    for (int t = 0; t < COG; ++t) {
+        const int o = g * COG + t;
+        if (o < CO) {
+            float acc = bias[o];
+#pragma unroll
+            for (int k = 0; k < CI; ++k) acc = fmaf(W[o * CI + k], u[k], acc);
+            acc = fmaxf(acc, 0.f);
+            if (valid) hr[o] = acc;
+            if (slots) {
+                const float v = valid ? acc : 0.f;
+                const float s1 = wave_sum(v), s2 = wave_sum(v * v);
+                if (lane == 0) {
+                    s_red[o] = s1;
+                    s_red[CO + o] = s2;
+                }
+            }
+        }
+    }
+    if (g == 3 && valid) {
+#pragma unroll
+        for (int o = CO; o < ((CO + 3) & ~3); ++o) hr[o] = 0.f;
+    }
+    if (slots) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * CO; i += 256) slots[(size_t)blockIdx.x * 2 * CO + i] = s_red[i];
+    }
+}
+
+template <int CA, int CB, int CO, bool KNN>
+__global__ __launch_bounds__(256) void fp_bwd_split_kernel(
+    int R, int R_per_plot, int S_per_plot, int src_stride, int skip_stride, int h_stride, int dskip_stride, int du_stride,
+    float invR, const float* __restrict__ src, const float* __restrict__ src_a, const float* __restrict__ src_c,
+    const int* __restrict__ knn_idx, const float* __restrict__ knn_w, const float* __restrict__ skip,
+    const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+    const float* __restrict__ h, const float* __restrict__ dy, float* __restrict__ dW, float* __restrict__ db,
+    float* __restrict__ du_out, float* __restrict__ dskip) {
+    constexpr int CI = CA + CB, COG = (CO + 3) / 4;
+    using Acc = OuterAcc<16, CI + 1>;
+    constexpr int QS = Acc::QS, TK = Acc::TK, CIP = CI | 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_q = smem;                       // [64][QS]  the rows' inputs | 1, shared by the four waves
+    float* s_p = s_q + 64 * QS;              // [4][64][16] per-wave d pre-activation of its channel group
+    float* s_du = s_p + 4 * 64 * 16;         // [64][CIP] input gradient, summed over the four channel groups
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long r = (long)blockIdx.x * 64 + lane;
+    const bool valid = r < R;
+    const size_t rr = valid ? (size_t)r : (size_t)(R - 1);
+    for (int i = threadIdx.x; i < 64 * QS + 4 * 64 * 16 + 64 * CIP; i += 256) smem[i] = 0.f;
+    __syncthreads();
+    if (g == 0) {
+        float u[CI + 1];
+        build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, rr,
+                                 (rr / R_per_plot) * S_per_plot, u);
+#pragma unroll
+        for (int k = 0; k <= CI; ++k) s_q[lane * QS + k] = u[k];
+    }
+    float dp[COG];
+#pragma unroll
+    for (int t = 0; t < COG; ++t) {
+        const int o = g * COG + t;
+        dp[t] = 0.f;
+        if (o < CO) {
+            const float hh = h[rr * h_stride + o], dd = dy[rr * h_stride + o];
+            const float is = invstd[o];
+            const float xh = (hh - mean[o]) * is;
+            const float dh = gamma[o] * is * (dd - dbeta[o] * invR - xh * dgamma[o] * invR);
+            dp[t] = (valid && hh > 0.f) ? dh : 0.f;
+        }
+        s_p[(g * 64 + lane) * 16 + t] = dp[t];
+    }
+    __syncthreads();
+    // dW|db rows of this channel group: rows of the block are the MFMA K dimension
+    f32x4 acc[TK];
+#pragma unroll
+    for (int c = 0; c < TK; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const int r4 = lane >> 4, c16 = lane & 15;
+        const float* rp = s_p + (g * 64 + r4) * 16 + c16;
+        const float* rq = s_q + r4 * QS + c16;
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {
+            const float av = rp[st * 4 * 16];
+#pragma unroll
+            for (int c = 0; c < TK; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, rq[st * 4 * QS + c * 16], acc[c], 0, 0, 0);
+        }
+    }
+    // partial input gradient of this channel group
+#pragma unroll
+    for (int k = 0; k < CI; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < COG; ++t)
+            if (g * COG + t < CO) a = fmaf(W[(g * COG + t) * CI + k], dp[t], a);
+        atomicAdd(&s_du[lane * CIP + k], a);
+    }
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * 64;
+    if (du_out) {
+        for (int i = threadIdx.x; i < 64 * CA; i += 256) {
+            const int row = i / CA, k = i - row * CA;
+            if (r0 + row < R) {
+                float* dst = du_out + (size_t)(r0 + row) * du_stride + k;
+                if (KNN) *dst = s_du[row * CIP + k];
+                else *dst += s_du[row * CIP + k];
+            }
+        }
+    }
+    if (CB > 0 && dskip) {
+        for (int i = threadIdx.x; i < 64 * CB; i += 256) {
+            const int row = i / CB, k = i - row * CB;
+            if (r0 + row < R) dskip[(size_t)(r0 + row) * dskip_stride + k] += s_du[row * CIP + CA + k];
+        }
+    }
+    {
+        const int r4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+        for (int c = 0; c < TK; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = r4 * 4 + q, o = g * COG + t, k = c * 16 + c16;
+                if (t < COG && o < CO) {
+                    if (k < CI) atomicAdd(&dW[o * CI + k], acc[c][q]);
+                    else if (k == CI) atomicAdd(&db[o], acc[c][q]);
+                }
+            }
     }
 }
 
@@ -308,6 +479,15 @@ int pick_grid(long R, int threads, int rows_per_lane) {
 template <int CA, int CB, int CO, bool KNN>
 int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     const int R = p->B * p->R_per_plot;
+    if (sn2_cdiv(R, 64) <= SN2_STAT_SLOTS) {   // small layer: 64 rows x 4 channel groups per workgroup
+        const int grid = sn2_cdiv(R, 64);
+        hipLaunchKernelGGL((fp_fwd_split_kernel<CA, CB, CO, KNN>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot,
+                           p->S_per_plot, p->src_stride, p->skip_stride, p->h_stride, p->src, p->src_a, p->src_c, p->knn_idx,
+                           p->knn_w, p->skip, p->blk.W, p->blk.b, p->h, training ? p->blk.stat_slots : (float*)nullptr);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return (int)e0;
+        return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
+    }
     int grid = pick_grid(R, 256, 4);
     if (grid > SN2_STAT_SLOTS) grid = SN2_STAT_SLOTS;
     hipLaunchKernelGGL((fp_fwd_kernel<CA, CB, CO, KNN>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot,
@@ -330,6 +510,24 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
                        p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    float* du_out0 = KNN ? p->du_scratch : p->dsrc;
+    if (KNN && p->dsrc && !p->du_scratch) return SN2_EINVAL;
+    if (KNN && !p->dsrc) du_out0 = nullptr;
+    const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS;
+    if (small) {
+        using AccS = OuterAcc<16, CI + 1>;
+        constexpr size_t lb = (size_t)(64 * AccS::QS + 4 * 64 * 16 + 64 * (CI | 1)) * 4;
+        auto ks = &fp_bwd_split_kernel<CA, CB, CO, KNN>;
+        if (lb > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        hipLaunchKernelGGL(ks, dim3(sn2_cdiv(R, 64)), dim3(256), lb, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,
+                           p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src,
+                           p->src_a, p->src_c, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma,
+                           (const float*)p->blk.mean, (const float*)p->blk.invstd, (const float*)p->blk.dgamma,
+                           (const float*)p->blk.dbeta, (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out0, p->dskip);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
     constexpr size_t lds_bytes = (size_t)Acc::LDS_FLOATS * 4 * WAVES;
     auto kern = &fp_bwd_main_kernel<CA, CB, CO, KNN, WAVES>;
     if (lds_bytes > 48 * 1024)
@@ -340,7 +538,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     if (KNN && !p->dsrc) du_out = nullptr;
     int grid = pick_grid(R, WAVES * 64, 4);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,
+    if (!small) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,
                        p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src, p->src_a, p->src_c,
                        p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma, (const float*)p->blk.mean,
                        (const float*)p->blk.invstd, (const float*)p->blk.dgamma, (const float*)p->blk.dbeta,
