@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,11 +165,43 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # ---- the step is ~100 short kernels with no host synchronisation: capture it once into a hipGraph and replay it
+    # (the single-GPU step is launch-bound otherwise: ~1 ms of host gaps per 6.6 ms step).  Every replay does the full
+    # work of a step on the resident inputs: FPS, ball query, forward, projection, loss, backward, Adam.
+    launch = "eager"
+    graph, loss_static = None, None
+    if not a.eager and world == 1:
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                   # allocator warm-up on the capture stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss_static = step()
+            graph.replay()
+            torch.cuda.synchronize()
+            launch = "hipGraph"
+        except Exception as exc:                         # noqa: BLE001 - fall back loudly, never silently change the work
+            log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eager")
+            graph = None
+            torch.cuda.synchronize()
+    log(f"launch mode: {launch}")
+
     barrier()
     t_start = time.perf_counter()
-    with ops.timing({dominant}) as tdom:       # 2 event records per step on the dominant entry point only
+    if graph is not None:
         for _ in range(a.steps):
-            loss = step()
+            graph.replay()
+        loss = loss_static
+        tdom = None
+    else:
+        with ops.timing({dominant}) as tdom:   # 2 event records per step on the dominant entry point only
+            for _ in range(a.steps):
+                loss = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     barrier()
@@ -176,8 +209,13 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el.item())
-    dom = tdom.summary()
     log(f"timed region: {elapsed / a.steps * 1e3:.3f} ms/step")
+    if tdom is None:
+        # graph replays cannot carry event records: time the dominant entry point over 5 eager steps right after
+        with ops.timing({dominant}) as tdom:
+            for _ in range(5):
+                step()
+    dom = tdom.summary()
 
     # ---- one fully instrumented step for the per-entry-point table (after the timed region)
     with ops.timing() as tall:
@@ -206,6 +244,8 @@ def main():
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None if ach is None else round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6),
                     "traffic": None, "avg_ms": round(avg_ms, 4), "algorithmic_bytes": by,
+                    "timing": ("HIP events inside the timed region" if launch == "eager" else
+                               "HIP events over 5 eager steps right after the hipGraph-replayed timed region"),
                     "note": ("fps is latency/VALU-bound by construction (M strictly sequential argmax rounds, one "
                              "workgroup per plot); its HBM traffic is 12 B/point once" if dominant.startswith("sn2_fps")
                              else "")}
@@ -214,7 +254,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "C2 ref-arch: 16 plots/GPU x 32768 pts, SA npoint 1024/256 + global, r 1/2 m, "
                                       "train step fwd+P2+loss+bwd+Adam, inputs resident in HBM",
-                          "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
+                          "launch": launch, "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
                "loss": round(float(loss.item()), 6), "roofline": roof, "kernels": kernels}
         if world == 1 and not a.no_cpu_baseline:

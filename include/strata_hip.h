@@ -110,6 +110,7 @@ typedef struct sn2_fp {
     float *dsrc; int dsrc_stride;   /* backward out: ACCUMULATED d loss / d (sa*src+sc) (B*S,dsrc_stride) or NULL */
     float *dskip; int dskip_stride; /* backward out: ACCUMULATED (B*R, >=cb) or NULL                             */
     float *du_scratch;              /* backward workspace (B*R,ca) when knn_idx and dsrc are given               */
+    float *scatter_ws;              /* backward workspace 16*B*S*ca floats when knn_idx and dsrc are given        */
 } sn2_fp;
 int sn2_fp_forward(const sn2_fp *p, int training, void *stream);
 int sn2_fp_backward(const sn2_fp *p, void *stream);
@@ -157,7 +158,8 @@ int sn2_raster_project(const float *coverages, const float *cloud_xy, long plot_
 /* ---- optimiser step of the timed training step -- torch.optim.Adam as configured in learning/train.py:180-185
  * (L2 weight decay added to the gradient), on flat buffers; grad_scale multiplies the gradient first (1/world). */
 int sn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream);
+                  float beta2, float eps, float weight_decay, int *step_dev /* device counter, incremented here */,
+                  float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,8 @@ class FP(Structure):  # sn2_fp
                 ("src", c_void_p), ("src_stride", c_int), ("src_a", c_void_p), ("src_c", c_void_p),
                 ("knn_idx", c_void_p), ("knn_w", c_void_p), ("skip", c_void_p), ("skip_stride", c_int),
                 ("blk", Block), ("h", c_void_p), ("h_stride", c_int), ("dy", c_void_p), ("dsrc", c_void_p),
-                ("dsrc_stride", c_int), ("dskip", c_void_p), ("dskip_stride", c_int), ("du_scratch", c_void_p)]
+                ("dsrc_stride", c_int), ("dskip", c_void_p), ("dskip_stride", c_int), ("du_scratch", c_void_p),
+                ("scatter_ws", c_void_p)]
 
 
 class Head(Structure):  # sn2_head
@@ -62,7 +63,7 @@ SIGNATURES = {
     "sn2_raster_project": [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                            c_void_p],
     "sn2_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
-                      c_int, c_float, c_void_p],
+                      c_void_p, c_float, c_void_p],
 }
 
 _lib = None

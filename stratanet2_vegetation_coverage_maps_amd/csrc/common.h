@@ -36,21 +36,6 @@ __device__ __forceinline__ float sn2_d2(float ax, float ay, float az, float bx, 
     return s + zz;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -72,6 +57,20 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x143, 0xC)));  // row_bcast31 into rows 2,3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ float wave_min_dpp(float v) { return -wave_max_dpp(-v); }
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0xB1, 0xF));   // pairs
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x4E, 0xF));   // quads
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x141, 0xF));  // halves of a row
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x140, 0xF));  // rows of 16
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x142, 0xA));  // row 1 += row 0, row 3 += row 2
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x143, 0xC));  // rows 2,3 += rows 0+1
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// the names used throughout the kernels
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
+__device__ __forceinline__ float wave_min(float v) { return wave_min_dpp(v); }
 __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
     v = min(v, (unsigned)SN2_DPP((int)v, 0xB1, 0xF));
     v = min(v, (unsigned)SN2_DPP((int)v, 0x4E, 0xF));

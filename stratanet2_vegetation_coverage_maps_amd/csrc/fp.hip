@@ -264,7 +264,7 @@ template <int CA>
 __global__ __launch_bounds__(1024) void interp_scatter_kernel(int R_per_plot, int S_per_plot, int TS, int dsrc_stride,
                                                               const int* __restrict__ knn_idx,
                                                               const float* __restrict__ knn_w,
-                                                              const float* __restrict__ du, float* __restrict__ dsrc) {
+                                                              const float* __restrict__ du, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int b = blockIdx.z;
     const int s_lo = blockIdx.y * TS;
@@ -306,11 +306,22 @@ __global__ __launch_bounds__(1024) void interp_scatter_kernel(int R_per_plot, in
         }
     }
     __syncthreads();
-    float* dst = dsrc + ((size_t)b * S_per_plot + s_lo) * dsrc_stride;
-    for (int i = threadIdx.x; i < nt; i += 1024) {
-        const float v = tile[i];
-        const int sr = i / CA, k = i - sr * CA;
-        if (v != 0.f) atomicAdd(&dst[(size_t)sr * dsrc_stride + k], v);
+    // this slice's partial sums leave as plain coalesced stores (slice-major); interp_reduce_kernel adds the slices.
+    // (Flushing every slice with global float atomics -- 9 M of them for FP1 -- cost 0.3 ms.)
+    float* dst = part + (((size_t)blockIdx.x * gridDim.z + b) * S_per_plot + s_lo) * CA;
+    for (int i = threadIdx.x; i < nt; i += 1024) dst[i] = tile[i];
+}
+
+// dsrc[row][k] += sum over slices of part[slice][row][k]
+__global__ __launch_bounds__(256) void interp_reduce_kernel(const float* __restrict__ part, int slices, long n_rows, int CA,
+                                                            int dsrc_stride, float* __restrict__ dsrc) {
+    const long total = n_rows * CA;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int sl = 0; sl < slices; ++sl) a += part[(size_t)sl * total + i];
+        const long row = i / CA;
+        const int k = (int)(i - row * CA);
+        dsrc[(size_t)row * dsrc_stride + k] += a;
     }
 }
 
@@ -556,8 +567,13 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
         if (tb > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&interp_scatter_kernel<CA>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
+        if (!p->scatter_ws) return SN2_EINVAL;
         hipLaunchKernelGGL((interp_scatter_kernel<CA>), dim3(slices, tiles, p->B), dim3(1024), tb, st, p->R_per_plot,
-                           p->S_per_plot, TS, p->dsrc_stride, p->knn_idx, p->knn_w, (const float*)p->du_scratch, p->dsrc);
+                           p->S_per_plot, TS, p->dsrc_stride, p->knn_idx, p->knn_w, (const float*)p->du_scratch,
+                           p->scatter_ws);
+        const long n_rows = (long)p->B * p->S_per_plot;
+        hipLaunchKernelGGL(interp_reduce_kernel, dim3(pick_grid(n_rows * CA, 256, 1)), dim3(256), 0, st,
+                           (const float*)p->scatter_ws, slices, n_rows, CA, p->dsrc_stride, p->dsrc);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }

@@ -129,11 +129,18 @@ extern "C" int sn2_plot_max_backward(const float* dout, const int* arg, int B, i
 // ------------------------------------------------------------------------------------------------------------
 // torch.optim.Adam (amsgrad=False, L2 weight decay folded into the gradient) on flat fp32 buffers.
 // ------------------------------------------------------------------------------------------------------------
+// The step counter lives on the device (adam_tick_kernel increments it, adam_kernel reads it), so a captured hipGraph
+// of the whole training step replays with the right bias corrections.
+__global__ void adam_tick_kernel(int* __restrict__ step) { *step += 1; }
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float gscale) {
+                            const int* __restrict__ step, float gscale) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const float t = (float)(*step);
+    const float bc1 = 1.f - powf(b1, t);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
     float grad = g[i] * gscale;
     const float pi = p[i];
     grad = fmaf(wd, pi, grad);
@@ -146,13 +153,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 extern "C" int sn2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             float beta1, float beta2, float eps, float weight_decay, int* step_dev, float grad_scale,
                              void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return SN2_EINVAL;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || n <= 0) return SN2_EINVAL;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     hipLaunchKernelGGL(adam_kernel, dim3(sn2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (const int*)step_dev, grad_scale);
     SN2_RETURN_LAUNCH();
 }
 

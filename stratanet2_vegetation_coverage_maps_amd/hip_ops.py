@@ -291,8 +291,13 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
         d.dsrc_stride = _chk_rows(dsrc, F32, n_src_rows, ca, "dsrc", align=1)
     if dskip is not None:
         d.dskip_stride = _chk_rows(dskip, F32, R, cb, "dskip", align=1)
+    d.scatter_ws = None
     if du_scratch is not None:
         _chk(du_scratch, F32, (R, ca), "du_scratch")
+        if knn is not None and dsrc is not None:
+            # per-slice partial sums of the interpolation transpose (no initialisation needed)
+            d._scatter_ws = torch.empty(16 * n_src_rows * ca, dtype=F32, device=src.device)
+            d.scatter_ws = _ptr(d._scatter_ws)
     d.dy, d.dsrc, d.dskip, d.du_scratch = _ptr(dy), _ptr(dsrc), _ptr(dskip), _ptr(du_scratch)
     return d
 
@@ -412,9 +417,11 @@ def raster_project(coverages: torch.Tensor, clouds_dev: torch.Tensor, diam_pix: 
     return rasters, pix
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):
+    """step_dev: int32 device tensor (1,) holding the number of steps taken so far; incremented by the call."""
     n = param.numel()
     for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(t, F32, (n,), nme)
+    _chk(step_dev, I32, (1,), "step_dev")
     _call("sn2_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
-                                    weight_decay, int(step), grad_scale, _stream())
+          weight_decay, _ptr(step_dev), grad_scale, _stream())

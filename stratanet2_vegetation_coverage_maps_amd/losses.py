@@ -13,7 +13,9 @@ EPS = 0.0001
 
 
 def get_absolute_loss(pred_pl, gt):
-    d = pred_pl[:, [0, 2, 3]] - gt[:, [0, 2, 3]]
+    # strata [low, med, high] = columns 0, 2, 3; sliced (not list-indexed: a python index list costs a host-to-device
+    # copy per step and cannot be captured into a hipGraph)
+    d = torch.cat((pred_pl[:, 0:1], pred_pl[:, 2:4]), 1) - torch.cat((gt[:, 0:1], gt[:, 2:4]), 1)
     return (d.pow(2) + EPS).pow(0.5).mean(0).mean()
 
 

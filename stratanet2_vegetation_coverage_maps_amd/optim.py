@@ -34,7 +34,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.flat.device)   # on the device: graph-replay safe
         self.world_size = world_size
         self.process_group = process_group
 
@@ -51,6 +51,5 @@ class FlatAdam:
             # the only exchange step of the data-parallel path: one 60 KB sum over RCCL/xGMI; the 1/world scale is
             # applied inside the Adam kernel
             torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
-        self.step_count += 1
         ops.adam_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                      self.weight_decay, self.step_count, 1.0 / self.world_size)
+                      self.weight_decay, self.step_dev, 1.0 / self.world_size)

@@ -158,3 +158,44 @@ def test_eval_is_batch_independent_and_deterministic():
         cov_1, _ = m({"cloud": d["cloud"][1:2], "xyz": d["xyz"][1:2], "fps_start": fs[:, :1]})
     assert torch.equal(cov_all, cov_again)
     assert torch.equal(cov_all.view(3, N, 4)[1], cov_1.view(N, 4))
+
+
+def test_flat_adam_matches_torch_adam():
+    """FlatAdam (one HIP kernel over the flat parameter buffer, device-side step counter) against torch.optim.Adam with
+    the reference's settings (learning/train.py:180-185: lr, weight_decay as L2), identical gradients, three steps."""
+    from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters
+    args = make_args(cuda=0, subsample_size=1024)
+    torch.manual_seed(0)
+    m1, m2 = PointNet2(args), PointNet2(args)
+    m2.load_state_dict(m1.state_dict())
+    flat = flatten_parameters(m1)
+    o1 = FlatAdam(m1, lr=1e-3, weight_decay=1e-3)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=1e-3)
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(3):
+        g = (torch.randn(flat.numel(), generator=gen) * 10 ** torch.randint(-6, 1, (flat.numel(),), generator=gen).float()).cuda()
+        m1._last_flat_grad = g.clone()
+        o1.step()
+        o = 0
+        for p in m2.parameters():
+            p.grad = g[o:o + p.numel()].view(p.shape).clone()
+            o += p.numel()
+        o2.step()
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        if a.is_floating_point():
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=1e-5, err_msg=k)
+
+
+def test_losses_match_oracle():
+    """Device loss block (product, hipGraph-capturable) vs the oracle's restatement of learning/loss_functions.py."""
+    from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
+    g = torch.Generator().manual_seed(0)
+    pred = torch.rand(6, 4, generator=g)
+    proba = torch.softmax(torch.randn(3000, 4, generator=g), 1)
+    gt = torch.rand(6, 4, generator=g, dtype=torch.float64)
+    pdf = torch.rand(3000, 3, generator=g, dtype=torch.float64) + 0.05
+    a, pa = dev_losses.total_loss(pred.cuda(), proba.cuda(), gt.cuda(), pdf.cuda())
+    b, pb = losses.total_loss(pred, proba, gt, pdf)
+    assert abs(a.item() - b.item()) < 1e-6
+    for x, y in zip(pa, pb):
+        assert abs(x.item() - y.item()) < 1e-6
