@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_plotwise_coverages  # noqa: E402
 from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops  # noqa: E402
 from stratanet2_vegetation_coverage_maps_amd import losses  # noqa: E402
-from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters  # noqa: E402
+from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters, shard_of_rank  # noqa: E402
 from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
@@ -74,6 +74,30 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
         "sn2_plot_project_backward": 16 * D * D * 3 * B,
     }
     return t.get(key)
+
+
+# entry point -> the kernel that dominates it (names as rocprofv3 prints them, see profiles/*_pmc_traffic.json)
+DOMINANT_KERNEL = {
+    "sn2_fps:N=32768": "fps_bucket_kernel<32, 16>", "sn2_ball_query:N=32768": "ball_query_kernel<8>",
+    "sn2_sa_forward:cf=8": "sa_pass_kernel<8, 2, 16, 16, 1>", "sn2_sa_backward:cf=8": "sa_pass_kernel<8, 2, 16, 16, 3>",
+    "sn2_fp_forward:34+8->34": "fp_fwd_kernel<34, 8, 34, true>",
+    "sn2_fp_backward:34+8->34": "fp_bwd_main_kernel<34, 8, 34, true, 4>",
+    "sn2_head_forward": "head_fwd_kernel", "sn2_head_backward": "head_bwd_kernel",
+    "sn2_three_nn:T=32768": "three_nn_kernel", "sn2_pack_rows": "pack_rows_kernel",
+}
+
+
+def pmc_traffic(entry):
+    """HBM bytes per launch of the entry point's dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs; FETCH doubled per the gfx950 correction).  bench.py cannot collect
+    counters itself; None when no profile is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    k = DOMINANT_KERNEL.get(entry)
+    if not files or k is None:
+        return None, None
+    d = json.load(open(files[-1]))
+    return (d[k]["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])) if k in d else (None, None)
 
 
 def cpu_baseline():
@@ -136,7 +160,7 @@ def main():
     model = PointNet2(args).train()
     flatten_parameters(model)
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
-    host = make_batch(B, N_POINTS, first_plot=rank * B)                       # this rank's shard of the plot batch
+    host = make_batch(B, N_POINTS, first_plot=shard_of_rank(rank, B)[0])       # this rank's shard of the plot batch
     data = {"cloud": host["cloud"].to(dev), "xyz": host["xyz"].to(dev),
             "fps_start": torch.zeros(2, B, dtype=torch.int32, device=dev)}
     gt, pdf = host["coverages"].to(dev), host["pdf_all"].to(dev)
@@ -241,9 +265,10 @@ def main():
             avg_ms = tms / c
             by = algorithmic_bytes(dominant, B, N_POINTS, m1, m2, e1, e2)
             ach = None if by is None else by / (avg_ms * 1e-3) / 1e9
+            traffic, tsrc = pmc_traffic(dominant)
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None if ach is None else round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6),
-                    "traffic": None, "avg_ms": round(avg_ms, 4), "algorithmic_bytes": by,
+                    "traffic": traffic, "traffic_source": tsrc, "avg_ms": round(avg_ms, 4), "algorithmic_bytes": by,
                     "timing": ("HIP events inside the timed region" if launch == "eager" else
                                "HIP events over 5 eager steps right after the hipGraph-replayed timed region"),
                     "note": ("fps is latency/VALU-bound by construction (M strictly sequential argmax rounds, one "
