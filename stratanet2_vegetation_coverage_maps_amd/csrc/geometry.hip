@@ -90,18 +90,16 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ pos, i
             // keep the scheduler from hoisting all 32 LDS reads at once (that spills at the 128-VGPR budget)
             if constexpr (ZLDS) { if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
         }
-        unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) |
-                                 (unsigned long long)(0xFFFFFFFFu - (unsigned)(bk * T + tid));
-        key = wave_max_u64(key);
-        if (lane == 0) s_key[i & 1][wave] = key;
+        // wave level: maximal distance by DPP, then the lowest index among the lanes attaining it (two 6-step DPP
+        // reductions instead of a 64-bit ds_bpermute butterfly)
+        const float wm = wave_max_dpp(best);
+        const unsigned wi = wave_min_u32_dpp(best == wm ? (unsigned)(bk * T + tid) : 0xFFFFFFFFu);
+        if (lane == 0) s_key[i & 1][wave] = ((unsigned long long)__float_as_uint(wm) << 32) | (unsigned long long)wi;
         __syncthreads();
-        unsigned long long k2 = s_key[i & 1][lane % NW];
-#pragma unroll
-        for (int o = NW / 2; o > 0; o >>= 1) {
-            unsigned long long t = __shfl_xor(k2, o);
-            k2 = t > k2 ? t : k2;
-        }
-        cur = (int)(0xFFFFFFFFu - (unsigned)(k2 & 0xFFFFFFFFull));
+        const unsigned long long k2 = s_key[i & 1][lane % NW];
+        const float gv = wave_max_dpp(__uint_as_float((unsigned)(k2 >> 32)));
+        const unsigned gi = wave_min_u32_dpp(__uint_as_float((unsigned)(k2 >> 32)) == gv ? (unsigned)(k2 & 0xFFFFFFFFull) : 0xFFFFFFFFu);
+        cur = (int)gi;
     }
 }
 

@@ -91,10 +91,10 @@ class _PointNet2Fn(torch.autograd.Function):
     gradients, the kernels read them through the modules (same storage)."""
 
     @staticmethod
-    def forward(ctx, model, xyz, cloud, fps_start, *params):
+    def forward(ctx, model, xyz, cloud, fps_start, geo, *params):
         training = model.training
-        need_grad = any(ctx.needs_input_grad[4:])   # grad mode is off inside Function.forward; this is the reliable test
-        cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training)
+        need_grad = any(ctx.needs_input_grad[5:])   # grad mode is off inside Function.forward; this is the reliable test
+        cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training, geo)
         ctx.model = model
         ctx.saved = saved if need_grad else None
         ctx.n_params = len(params)
@@ -106,7 +106,7 @@ class _PointNet2Fn(torch.autograd.Function):
             raise RuntimeError("PointNet2: backward through a forward that recorded no graph")
         grads = ctx.model._backward_impl(ctx.saved, dcov, dproba)
         ctx.saved = None
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class PointNet2(nn.Module):
@@ -160,19 +160,21 @@ class PointNet2(nn.Module):
             raise NotImplementedError("dropout p > 0 (reference default 0.0, config.py:76) is not in the HIP head yet")
         with torch.cuda.device(dev):
             cloud_d = cloud.to(device=dev, dtype=F32, non_blocking=True).contiguous()
-            xyz_d = xyz.to(device=dev, dtype=F32, non_blocking=True).contiguous()
-            B, _, N = cloud_d.shape
-            fs = cloud_data.get("fps_start", None) if isinstance(cloud_data, dict) else None
-            if fs is None:
-                # reference behaviour: an independent random start per plot and per FPS call
-                m1 = ops.fps_num_samples(N, self.sa1_module.ratio)
-                fs = torch.stack([torch.randint(0, N, (B,)), torch.randint(0, m1, (B,))])
-            fs = torch.as_tensor(fs).to(device=dev, dtype=I32, non_blocking=True).contiguous()
-            if fs.shape != (2, B):
-                raise ValueError(f"fps_start must have shape (2,{B})")
+            geo = cloud_data.get("geometry", None) if isinstance(cloud_data, dict) else None
+            if geo is not None:
+                # position-only kernels already ran (or are running) on the side stream: wait for them here
+                cs = torch.cuda.current_stream()
+                cs.wait_event(geo.ready)
+                for v in geo.__dict__.values():          # allocated on the side stream, consumed on this one
+                    for t in (v if isinstance(v, tuple) else (v,)):
+                        if isinstance(t, torch.Tensor):
+                            t.record_stream(cs)
+                xyz_d, fs = geo.xyz, None
+            else:
+                xyz_d, fs = self._stage_positions(cloud_data, dev)
             self._last_cloud_dev = (cloud, cloud_d)  # lets project_to_plotwise_coverages skip a second H2D copy
             params = [p for p in self.parameters()]
-            cov, proba = _PointNet2Fn.apply(self, xyz_d, cloud_d, fs, *params)
+            cov, proba = _PointNet2Fn.apply(self, xyz_d, cloud_d, fs, geo, *params)
         return cov, proba
 
     def _sizes(self, N):
@@ -180,12 +182,73 @@ class PointNet2(nn.Module):
         M2 = ops.fps_num_samples(M1, self.sa2_module.ratio)
         return M1, M2
 
-    def _forward_impl(self, xyz, cloud, fps_start, training):
+    # ------------------------------------------------------------------------------------------ geometry
+    def _geometry(self, xyz, fps_start):
+        """Everything that depends on the point POSITIONS only (no weights, no features): both FPS levels, both ball
+        queries, the three 3-NN tables.  In the reference these are the torch_cluster calls inside SAModule / FPModule
+        (point_net2.py:22-25, 63).  Because they need no parameters they can run ahead of the feature kernels: see
+        `prefetch_geometry`."""
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
+        g = _Saved()
+        g.B, g.N, g.M1, g.M2, g.xyz = B, N, M1, M2, xyz
+        totals = torch.zeros(2, dtype=I64, device=dev)
+        g.idx1, g.pos1_soa, g.pos1_aos = ops.fps(xyz, M1, fps_start[0])
+        g.nbr1, g.cnt1, g.tot1 = ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, totals[0:1])
+        g.idx2, g.pos2_soa, g.pos2_aos = ops.fps(g.pos1_soa, M2, fps_start[1])
+        g.nbr2, g.cnt2, g.tot2 = ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2])
+        pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)      # GlobalSAModule: pos = zeros (point_net2.py:40)
+        g.knn3 = ops.three_nn(pos3, g.pos2_soa, 1)
+        g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3)
+        g.knn1 = ops.three_nn(g.pos1_soa, xyz, 3)
+        return g
+
+    def prefetch_geometry(self, cloud_data):
+        """Run the position-only kernels of a batch on a side stream, ahead of time (typically for batch k+1 while
+        batch k is in its backward pass: the FPS rounds are sequential and occupy one CU per plot, the feature kernels
+        fill the rest of the chip).  Returns a handle to put into `cloud_data["geometry"]` for the forward call."""
+        dev = self.lin1.weight.device
+        if dev.type != "cuda":
+            raise StrataHipError("prefetch_geometry needs a HIP device")
+        with torch.cuda.device(dev):
+            if getattr(self, "_geo_stream", None) is None:
+                self._geo_stream = torch.cuda.Stream(device=dev)
+            xyz_d, fs = self._stage_positions(cloud_data, dev)
+            side = self._geo_stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g = self._geometry(xyz_d, fs)
+                g.ready = torch.cuda.Event()
+                g.ready.record(side)
+            g.stream = side
+        return g
+
+    def _stage_positions(self, cloud_data, dev):
+        xyz = cloud_data["xyz"]
+        xyz_d = xyz.to(device=dev, dtype=F32, non_blocking=True).contiguous()
+        B, _, N = xyz_d.shape
+        fs = cloud_data.get("fps_start", None) if isinstance(cloud_data, dict) else None
+        if fs is None:
+            # reference behaviour: an independent random start per plot and per FPS call
+            m1 = ops.fps_num_samples(N, self.sa1_module.ratio)
+            fs = torch.stack([torch.randint(0, N, (B,)), torch.randint(0, m1, (B,))])
+        fs = torch.as_tensor(fs).to(device=dev, dtype=I32, non_blocking=True).contiguous()
+        if fs.shape != (2, B):
+            raise ValueError(f"fps_start must have shape (2,{B})")
+        return xyz_d, fs
+
+    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None):
+        dev = xyz.device
+        B, _, N = xyz.shape
+        M1, M2 = self._sizes(N)
+        if geo is None:
+            geo = self._geometry(xyz, fps_start)
+        elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
+            raise ValueError("prefetched geometry does not match this batch")
         s = _Saved()
-        s.B, s.N, s.M1, s.M2 = B, N, M1, M2
+        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream")})
+        s.xyz = xyz
         # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd and the per-workgroup statistics
         # slots (written before they are read: no zero fill)
         widths = [16, 16, 32, 64, 64, 34, 34]
@@ -199,21 +262,15 @@ class PointNet2(nn.Module):
         s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur)[0]
         s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
         s.aux, s.stats = aux, stats
-        totals = torch.zeros(2, dtype=I64, device=dev)
 
         # ---- level 0 rows: [8 features | x y z 0]
         s.rows0 = ops.pack_rows(cloud, xyz)
-        s.xyz = xyz
-        # ---- SA1: fps -> ball query -> gather + MLP[11,16,16] + BN + max      (point_net2.py:131, 21-29)
-        s.idx1, s.pos1_soa, s.pos1_aos = ops.fps(xyz, M1, fps_start[0])
-        s.nbr1, s.cnt1, s.tot1 = ops.ball_query(xyz, s.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, totals[0:1])
+        # ---- SA1: gather + MLP[11,16,16] + BN + max over the ball-query lists     (point_net2.py:131, 21-29)
         s.ext1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
         s.arg1 = torch.empty(B * M1, 16, dtype=I32, device=dev)
         s.x1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
         ops.sa_forward(self._sa1_desc(s), training)
         # ---- SA2: MLP[19,32]                                                     (:132)
-        s.idx2, s.pos2_soa, s.pos2_aos = ops.fps(s.pos1_soa, M2, fps_start[1])
-        s.nbr2, s.cnt2, s.tot2 = ops.ball_query(s.pos1_soa, s.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2])
         s.ext2 = torch.empty(B * M2, 32, dtype=F32, device=dev)
         s.arg2 = torch.empty(B * M2, 32, dtype=I32, device=dev)
         s.x2 = torch.empty(B * M2, 32, dtype=F32, device=dev)
@@ -225,14 +282,10 @@ class PointNet2(nn.Module):
         if self.log_embeddings:
             self.last_G_tensor = s.x3
         # ---- FP3 (k=1 from the plot's global feature at the origin), FP2, FP1 (k=3)   (:137-139, 62-67)
-        pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)
-        s.knn3 = ops.three_nn(pos3, s.pos2_soa, 1)
         s.h3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
         ops.fp_forward(self._fp3_desc(s), training)
-        s.knn2 = ops.three_nn(s.pos2_soa, s.pos1_soa, 3)
         s.h2 = torch.empty(B * M1, 36, dtype=F32, device=dev)
         ops.fp_forward(self._fp2_desc(s), training)
-        s.knn1 = ops.three_nn(s.pos1_soa, xyz, 3)
         s.h1 = torch.empty(B * N, 36, dtype=F32, device=dev)
         ops.fp_forward(self._fp1_desc(s), training)
         # ---- head                                                                  (:141-151)

@@ -199,3 +199,17 @@ def test_losses_match_oracle():
     assert abs(a.item() - b.item()) < 1e-6
     for x, y in zip(pa, pb):
         assert abs(x.item() - y.item()) < 1e-6
+
+
+def test_prefetched_geometry_gives_identical_results():
+    """`prefetch_geometry` (position-only kernels on a side stream) + forward == plain forward, bit for bit in eval."""
+    N = 4096
+    args = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(2, N, first_plot=9)
+    d["fps_start"] = torch.tensor([[5, 77], [3, 1]])
+    m = _model(args, network.init_state_dict(2)).eval()
+    with torch.no_grad():
+        cov_a, proba_a = m(d)
+        geo = m.prefetch_geometry(d)
+        cov_b, proba_b = m({"cloud": d["cloud"], "xyz": d["xyz"], "geometry": geo})
+    assert torch.equal(cov_a, cov_b) and torch.equal(proba_a, proba_b)
