@@ -30,7 +30,7 @@ extern "C" {
 #define SN2_ELIMIT (-2) /* size outside what the kernels cover */
 
 #define SN2_MAX_NEIGHBORS 2000 /* model/point_net2.py:24  max_num_neighbors */
-#define SN2_STAT_SLOTS 512     /* workgroups (= partial-sum slots) of a kernel that produces BatchNorm statistics */
+#define SN2_STAT_SLOTS 1024    /* workgroups (= partial-sum slots) of a kernel that produces BatchNorm statistics */
 
 int sn2_version(void);
 

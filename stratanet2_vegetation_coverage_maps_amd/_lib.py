@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libstrata_hip.so")
 
 SN2_VERSION = 100
 MAX_NEIGHBORS = 2000  # model/point_net2.py:24
-STAT_SLOTS = 512      # SN2_STAT_SLOTS
+STAT_SLOTS = 1024     # SN2_STAT_SLOTS
 
 
 class Block(Structure):  # sn2_block

@@ -21,6 +21,21 @@
 
 static inline int sn2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- wave-uniform read-only tables (weights, BN constants) -------------------------------------------------------
+// `cfp` = the same global memory viewed through the CONSTANT address space: uniform loads from it always become
+// s_load (the memory is not written while the kernel runs).  `opaque()` hides a pointer's provenance from the
+// optimiser for one loop iteration: without it LICM hoists the 400-1400 weight loads of an MLP out of the row loop into
+// SGPRs, of which there are ~100 -- the rest is spilled to VGPR lanes and every FMA then pays two v_readlane
+// (head_fwd: 6355 v_readlane for 698 FMAs; the SA passes 2300-2800).  With it the weights stream through s_load_dwordx16
+// inside the loop (scalar-cache hits) and no SGPR is spilled.
+typedef const float __attribute__((address_space(4)))* cfp;
+__device__ __forceinline__ cfp as_const(const float* p) { return (cfp)(uintptr_t)p; }
+__device__ __forceinline__ cfp opaque(cfp p) {
+    uint64_t v = (uint64_t)p;
+    asm volatile("" : "+s"(v));
+    return (cfp)v;
+}
+
 // ---- canonical squared distance: (dx*dx + dy*dy) + dz*dz, every operation rounded to fp32 on its
 // own.  The pragma removes the `contract` flag from these operations so the backend cannot fuse them into FMAs even
 // after inlining into a kernel compiled with the default -ffp-contract=fast.

@@ -15,8 +15,8 @@
 namespace {
 
 template <int CA, int CB, bool KNN>
-__device__ __forceinline__ void build_input(const float* __restrict__ src, int src_stride, const float* __restrict__ src_a,
-                                            const float* __restrict__ src_c, const int* __restrict__ knn_idx,
+__device__ __forceinline__ void build_input(const float* __restrict__ src, int src_stride, cfp src_a, cfp src_c,
+                                            const int* __restrict__ knn_idx,
                                             const float* __restrict__ knn_w, const float* __restrict__ skip,
                                             int skip_stride, size_t r, size_t src_plot_base, float (&u)[CA + CB + 1]) {
     constexpr int Q = (CA + 3) / 4;
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void fp_fwd_kernel(int R, int R_per_plot, int 
                                                      int h_stride, const float* __restrict__ src,
                                                      const float* __restrict__ src_a, const float* __restrict__ src_c,
                                                      const int* __restrict__ knn_idx, const float* __restrict__ knn_w,
-                                                     const float* __restrict__ skip, const float* __restrict__ W,
-                                                     const float* __restrict__ bias, float* __restrict__ h,
+                                                     const float* __restrict__ skip, const float* __restrict__ Wg,
+                                                     const float* __restrict__ biasg, float* __restrict__ h,
                                                      float* __restrict__ slots) {
     constexpr int CI = CA + CB;
     __shared__ float s_red[2 * CO];
@@ -85,10 +85,11 @@ __global__ __launch_bounds__(256) void fp_fwd_kernel(int R, int R_per_plot, int 
 #pragma unroll
     for (int o = 0; o < CO; ++o) ssum[o] = ssq[o] = 0.f;
     for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
+        const cfp W = opaque(as_const(Wg)), bias = opaque(as_const(biasg));   // stream the weights inside the loop
         float u[CI + 1];
         const size_t plot = (size_t)(r / R_per_plot);
-        build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, (size_t)r,
-                                 plot * S_per_plot, u);
+        build_input<CA, CB, KNN>(src, src_stride, opaque(as_const(src_a)), opaque(as_const(src_c)), knn_idx, knn_w, skip,
+                                 skip_stride, (size_t)r, plot * S_per_plot, u);
         float* hr = h + (size_t)r * h_stride;
 #pragma unroll
         for (int o4 = 0; o4 < CO; o4 += 4) {
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
     int du_stride, float invR,
     const float* __restrict__ src, const float* __restrict__ src_a, const float* __restrict__ src_c,
     const int* __restrict__ knn_idx, const float* __restrict__ knn_w, const float* __restrict__ skip,
-    const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+    const float* __restrict__ Wg, const float* __restrict__ gammag, const float* __restrict__ meang,
+    const float* __restrict__ invstdg, const float* __restrict__ dgammag, const float* __restrict__ dbetag,
     const float* __restrict__ h, const float* __restrict__ dy, float* __restrict__ dW, float* __restrict__ db,
     float* __restrict__ du_out /* KNN: (R,CA) scratch; else ACCUMULATED rows (R,du_stride) */,
     float* __restrict__ dskip) {
@@ -176,9 +177,11 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
         const long r = it * nthreads + (long)blockIdx.x * WAVES * 64 + threadIdx.x;
         const bool valid = r < R;
         const size_t rr = valid ? (size_t)r : 0;
+        const cfp W = opaque(as_const(Wg)), gamma = opaque(as_const(gammag)), mean = opaque(as_const(meang)),
+                  invstd = opaque(as_const(invstdg)), dgamma = opaque(as_const(dgammag)), dbeta = opaque(as_const(dbetag));
         float u[CI + 1];
-        build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, rr,
-                                 (rr / R_per_plot) * S_per_plot, u);
+        build_input<CA, CB, KNN>(src, src_stride, opaque(as_const(src_a)), opaque(as_const(src_c)), knn_idx, knn_w, skip,
+                                 skip_stride, rr, (rr / R_per_plot) * S_per_plot, u);
         float dp[CO];
         const float4* hr = reinterpret_cast<const float4*>(h + rr * h_stride);
         const float4* dr = reinterpret_cast<const float4*>(dy + rr * h_stride);
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot
     const bool valid = r < R;
     const size_t rr = valid ? (size_t)r : (size_t)(R - 1);
     float u[CI + 1];
-    build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, rr,
+    build_input<CA, CB, KNN>(src, src_stride, as_const(src_a), as_const(src_c), knn_idx, knn_w, skip, skip_stride, rr,
                              (rr / R_per_plot) * S_per_plot, u);
     float* hr = h + rr * h_stride;
 #pragma unroll
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     __syncthreads();
     if (g == 0) {
         float u[CI + 1];
-        build_input<CA, CB, KNN>(src, src_stride, src_a, src_c, knn_idx, knn_w, skip, skip_stride, rr,
+        build_input<CA, CB, KNN>(src, src_stride, as_const(src_a), as_const(src_c), knn_idx, knn_w, skip, skip_stride, rr,
                                  (rr / R_per_plot) * S_per_plot, u);
 #pragma unroll
         for (int k = 0; k <= CI; ++k) s_q[lane * QS + k] = u[k];
@@ -626,10 +629,8 @@ struct HeadOut {
     float dens;
 };
 
-__device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, const float* __restrict__ fa,
-                                         const float* __restrict__ fc, const float* __restrict__ W1,
-                                         const float* __restrict__ b1, const float* __restrict__ W2,
-                                         const float* __restrict__ b2, size_t r, HeadOut& o) {
+__device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, cfp fa, cfp fc, cfp W1, cfp b1, cfp W2,
+                                         cfp b2, size_t r, HeadOut& o) {
     const float4* fr = reinterpret_cast<const float4*>(f + r * f_stride);
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
@@ -675,7 +676,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int R, int f_stride, cons
                                                        float* __restrict__ cov, float* __restrict__ proba) {
     for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
         HeadOut o;
-        head_row(f, f_stride, fa, fc, W1, b1, W2, b2, (size_t)r, o);
+        head_row(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), opaque(as_const(W1)), opaque(as_const(b1)),
+                 opaque(as_const(W2)), opaque(as_const(b2)), (size_t)r, o);
         reinterpret_cast<float4*>(proba)[r] = make_float4(o.p[0], o.p[1], o.p[2], o.p[3]);
         reinterpret_cast<float4*>(cov)[r] = make_float4(o.p[0] * o.dens, o.p[1] * o.dens, o.p[2] * o.dens, o.p[3] * o.dens);
     }
@@ -683,8 +685,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int R, int f_stride, cons
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(int R, int f_stride, const float* __restrict__ f,
                                                        const float* __restrict__ fa, const float* __restrict__ fc,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ W2, const float* __restrict__ b2,
+                                                       const float* __restrict__ W1g, const float* __restrict__ b1,
+                                                       const float* __restrict__ W2g, const float* __restrict__ b2,
                                                        const float* __restrict__ dcov, const float* __restrict__ dproba,
                                                        float* __restrict__ dy, float* __restrict__ dW1,
                                                        float* __restrict__ db1, float* __restrict__ dW2,
@@ -704,8 +706,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int R, int f_stride, cons
         const long r = it * nthreads + (long)blockIdx.x * 256 + threadIdx.x;
         const bool valid = r < R;
         const size_t rr = valid ? (size_t)r : 0;
+        const cfp W1 = opaque(as_const(W1g)), W2 = opaque(as_const(W2g));
         HeadOut o;
-        head_row(f, f_stride, fa, fc, W1, b1, W2, b2, rr, o);
+        head_row(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), W1, opaque(as_const(b1)), W2,
+                 opaque(as_const(b2)), rr, o);
         float gc[4] = {0.f, 0.f, 0.f, 0.f}, gp[4] = {0.f, 0.f, 0.f, 0.f};
         if (dcov) {
             const float4 v = reinterpret_cast<const float4*>(dcov)[rr];

@@ -5,11 +5,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// out[o] = (relu) ( b[o] + sum_k W[o*CI+k] * in[k] ).  W, b are wave-uniform global pointers: the compiler turns the
-// loads into s_load_dwordx* and feeds the FMAs SGPR operands.
+// out[o] = (relu) ( b[o] + sum_k W[o*CI+k] * in[k] ).  W, b are wave-uniform constant-address-space pointers (common.h):
+// the loads are s_load_dwordx* and the FMAs take SGPR operands.
 template <int CI, int CO, bool RELU>
-__device__ __forceinline__ void dense(const float* __restrict__ W, const float* __restrict__ b, const float (&in)[CI],
-                                      float (&out)[CO]) {
+__device__ __forceinline__ void dense(cfp W, cfp b, const float (&in)[CI], float (&out)[CO]) {
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
         float acc = b[o];
@@ -21,7 +20,7 @@ __device__ __forceinline__ void dense(const float* __restrict__ W, const float* 
 
 // out[k] = sum_o W[o*CI+k] * g[o]   (transpose product: input gradient)
 template <int CI, int CO, int CI_USED>
-__device__ __forceinline__ void dense_t(const float* __restrict__ W, const float (&g)[CO], float (&out)[CI_USED]) {
+__device__ __forceinline__ void dense_t(cfp W, const float (&g)[CO], float (&out)[CI_USED]) {
 #pragma unroll
     for (int k = 0; k < CI_USED; ++k) {
         float acc = 0.f;

@@ -23,8 +23,13 @@ namespace {
 // across the kernel's own stores; as members of a by-value struct they would be re-read with vector loads after
 // every store (256 VGPRs + scratch in a first version of this kernel).
 struct BlkRO {
-    const float *W, *b, *gamma, *a, *c, *mean, *invstd, *dgamma, *dbeta;
+    cfp W, b, gamma, a, c, mean, invstd, dgamma, dbeta;
 };
+// fresh provenance for one loop iteration (see common.h: opaque)
+__device__ __forceinline__ BlkRO launder(const BlkRO& k) {
+    return BlkRO{opaque(k.W), opaque(k.b), opaque(k.gamma), opaque(k.a), opaque(k.c), opaque(k.mean), opaque(k.invstd),
+                 opaque(k.dgamma), opaque(k.dbeta)};
+}
 // writable side (atomics)
 struct BlkDev {
     float* slots;  // per-workgroup batch-statistics partials or nullptr
@@ -34,7 +39,9 @@ struct BlkDev {
     const float *__restrict__ W##n, const float *__restrict__ b##n, const float *__restrict__ g##n,                  \
         const float *__restrict__ a##n, const float *__restrict__ c##n, const float *__restrict__ mean##n,           \
         const float *__restrict__ invstd##n, const float *__restrict__ dgam##n, const float *__restrict__ dbet##n
-#define BLK_RO_MAKE(n) BlkRO{W##n, b##n, g##n, a##n, c##n, mean##n, invstd##n, dgam##n, dbet##n}
+#define BLK_RO_MAKE(n)                                                                                               \
+    BlkRO{as_const(W##n), as_const(b##n), as_const(g##n), as_const(a##n), as_const(c##n), as_const(mean##n),         \
+          as_const(invstd##n), as_const(dgam##n), as_const(dbet##n)}
 
 struct SaDev {
     int B, Nsrc, M, cap, feat_stride, spos_stride;
@@ -43,6 +50,30 @@ struct SaDev {
     int* arg;
     float* dfeat;
 };
+
+// The single by-value kernel argument.  The kernel does NOT keep its ~40 pointers live in SGPRs (that alone is 80 of the
+// ~100 SGPRs and forced thousands of v_readlane spill reloads per iteration in the backward passes): it re-reads what it
+// needs from the kernarg segment -- constant memory -- inside the loops, behind `opaque()` (common.h).
+struct SaK {
+    SaDev p;
+    const float *feat, *spos, *cpos;
+    const int *nbr, *cnt;
+    const unsigned long long* total;
+    const float* ro0[9];   // W, b, gamma, a, c, mean, invstd, dgamma, dbeta of block 0 (read-only in this pass)
+    const float* ro1[9];   // ... of block 1 (= block 0 when nl == 1)
+    const float* dout;
+    const int* arg_in;
+};
+typedef const SaK __attribute__((address_space(4)))* SaKp;
+__device__ __forceinline__ SaKp opaque_k(SaKp k) {
+    uint64_t v = (uint64_t)k;
+    asm volatile("" : "+s"(v));
+    return (SaKp)v;
+}
+__device__ __forceinline__ BlkRO make_ro(const float* const __attribute__((address_space(4)))* t) {
+    return BlkRO{as_const(t[0]), as_const(t[1]), as_const(t[2]), as_const(t[3]), as_const(t[4]), as_const(t[5]),
+                 as_const(t[6]), as_const(t[7]), as_const(t[8])};
+}
 
 enum { PASS_STATS0 = 0, PASS_MAIN = 1, PASS_BWD_C = 2, PASS_BWD_D = 3 };
 
@@ -66,8 +97,7 @@ __device__ __forceinline__ void load_msg(const float* __restrict__ feat, int fea
 }
 
 template <int C>
-__device__ __forceinline__ void affine(const float* __restrict__ a, const float* __restrict__ c, const float (&h)[C],
-                                       float (&y)[C]) {
+__device__ __forceinline__ void affine(cfp a, cfp c, const float (&h)[C], float (&y)[C]) {
 #pragma unroll
     for (int o = 0; o < C; ++o) y[o] = fmaf(a[o], h[o], c[o]);
 }
@@ -87,15 +117,14 @@ __device__ __forceinline__ void bn_relu_bwd(const BlkRO& k, const float (&h)[C],
 }
 
 template <int CF, int NL, int C1, int C2, int PASS>
-__global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float* __restrict__ feat,
-                                                      const float* __restrict__ spos, const float* __restrict__ cpos,
-                                                      const int* __restrict__ nbr, const int* __restrict__ cnt,
-                                                      const unsigned long long* __restrict__ total, BLK_RO_PARAMS(0),
-                                                      BLK_RO_PARAMS(1), const float* __restrict__ dout,
-                                                      const int* __restrict__ arg_in) {
+__global__ __launch_bounds__(256) void sa_pass_kernel(const SaK karg) {
+    (void)karg;
+    const SaKp kbase = (SaKp)__builtin_amdgcn_kernarg_segment_ptr();
+    struct { int B, Nsrc, M, cap, feat_stride, spos_stride; } p;   // the sizes; pointers are fetched where they are used
+    p.B = kbase->p.B; p.Nsrc = kbase->p.Nsrc; p.M = kbase->p.M; p.cap = kbase->p.cap;
+    p.feat_stride = kbase->p.feat_stride; p.spos_stride = kbase->p.spos_stride;
     constexpr int CIN = CF + 3;
-    const BlkRO r0 = BLK_RO_MAKE(0), r1 = BLK_RO_MAKE(1);
-    const BlkRO& rl = NL == 2 ? r1 : r0;  // last block, read-only side
+
     constexpr int CL = NL == 2 ? C2 : C1;  // width of the last block
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float s_red[128];  // block-level reduction of the batch statistics (2 x up to 64 channels)
@@ -104,11 +133,10 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave_in_blk));
     const int nwaves = gridDim.x * 4;
     const int ncent = p.B * p.M;
-    const BlkDev& kl = NL == 2 ? p.k1 : p.k0;  // last block
 
     float invE = 0.f;
     if constexpr (PASS == PASS_BWD_C || PASS == PASS_BWD_D) {
-        const unsigned long long e = *total;
+        const unsigned long long e = *kbase->total;
         invE = e > 0 ? (float)(1.0 / (double)e) : 0.f;
     }
 
@@ -136,10 +164,11 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
     for (int o = 0; o < ((PASS == PASS_BWD_C && NL == 2) ? C1 : 1); ++o) dbeta0[o] = dgamma0[o] = 0.f;
 
     for (int ci = wave; ci < ncent; ci += nwaves) {
+        const SaKp kc = opaque_k(kbase);
         const int b = ci / p.M;
-        const int n = cnt[ci];
-        const float4 cp = reinterpret_cast<const float4*>(cpos)[ci];
-        const int* nl = nbr + (size_t)ci * p.cap;
+        const int n = kc->cnt[ci];
+        const float4 cp = reinterpret_cast<const float4*>(kc->cpos)[ci];
+        const int* nl = kc->nbr + (size_t)ci * p.cap;
         float best[CL];
         int barg[CL];
 #pragma unroll
@@ -148,6 +177,13 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
             barg[o] = -1;
         }
         for (int e0 = 0; e0 < n; e0 += 64) {
+            const SaKp k = opaque_k(kbase);                     // pointers and weights are re-read inside the loop
+            const BlkRO r0 = make_ro(k->ro0), r1 = make_ro(k->ro1);
+            const BlkRO& rl = NL == 2 ? r1 : r0;                // last block, read-only side
+            const float* feat = k->feat;
+            const float* spos = k->spos;
+            const float* dout = k->dout;
+            const int* arg_in = k->arg_in;
             const int e = e0 + lane;
             const bool valid = e < n;
             const int j = nl[valid ? e : 0];
@@ -216,12 +252,13 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
                     accF.add(lds, dp1, u);
 #pragma unroll
                     for (int k = 0; k < C1; ++k) dbias[k] += dp1[k];
-                    if (p.dfeat) {
+                    float* dfeat = k->p.dfeat;
+                    if (dfeat) {
                         float du[CF];
                         dense_t<CIN, C1, CF>(r0.W, dp1, du);
                         if (valid) {
 #pragma unroll
-                            for (int q = 0; q < CF; ++q) atomicAdd(&p.dfeat[src_row * CF + q], du[q]);
+                            for (int q = 0; q < CF; ++q) atomicAdd(&dfeat[src_row * CF + q], du[q]);
                         }
                     }
                 }
@@ -229,12 +266,13 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
                 accL.add(lds, dpl, u);
 #pragma unroll
                 for (int o = 0; o < CL; ++o) dbias[o] += dpl[o];
-                if (p.dfeat) {
+                float* dfeat = k->p.dfeat;
+                if (dfeat) {
                     float du[CF];
                     dense_t<CIN, C1, CF>(r0.W, dpl, du);
                     if (valid) {
 #pragma unroll
-                        for (int q = 0; q < CF; ++q) atomicAdd(&p.dfeat[src_row * CF + q], du[q]);
+                        for (int q = 0; q < CF; ++q) atomicAdd(&dfeat[src_row * CF + q], du[q]);
                     }
                 }
             }
@@ -244,6 +282,7 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
 
         if constexpr (PASS == PASS_MAIN) {
             // cross-lane extremum: value by wave max, slot = that of the lowest lane attaining it
+            const BlkRO rl = make_ro(NL == 2 ? kc->ro1 : kc->ro0);
             float my_ext = 0.f;
             int my_arg = -1;
 #pragma unroll
@@ -258,16 +297,18 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
                 }
             }
             if (lane < CL) {
-                p.ext[(size_t)ci * CL + lane] = n > 0 ? my_ext : 0.f;
-                p.arg[(size_t)ci * CL + lane] = n > 0 ? my_arg : -1;
+                kc->p.ext[(size_t)ci * CL + lane] = n > 0 ? my_ext : 0.f;
+                kc->p.arg[(size_t)ci * CL + lane] = n > 0 ? my_arg : -1;
             }
         }
     }
 
     // ---- everything that leaves the kernel is first reduced over the workgroup (see mlp.h)
-    if constexpr (PASS == PASS_STATS0) stats_to_slot<C1>(ssum, ssq, s_red, p.k0.slots);
+    const SaKp ke = opaque_k(kbase);   // the write-side pointers are only needed now
+    if constexpr (PASS == PASS_STATS0) stats_to_slot<C1>(ssum, ssq, s_red, ke->p.k0.slots);
     if constexpr (PASS == PASS_MAIN) {
-        if (kl.slots) stats_to_slot<CL>(ssum, ssq, s_red, kl.slots);
+        float* slots = NL == 2 ? ke->p.k1.slots : ke->p.k0.slots;
+        if (slots) stats_to_slot<CL>(ssum, ssq, s_red, slots);
     }
     if constexpr (PASS == PASS_BWD_C || PASS == PASS_BWD_D) {
         constexpr int CKL = NL == 2 ? C1 : CIN;                  // columns of the last block's dW
@@ -286,14 +327,18 @@ __global__ __launch_bounds__(256) void sa_pass_kernel(const SaDev p, const float
             sums_to_lds<C1>(dgamma0, red + NW + NB + C1);
         }
         __syncthreads();
-        const BlkDev& kw = BWD_LAST ? kl : p.k0;
+        const bool last1 = BWD_LAST && NL == 2;   // which block's dW/db this pass produces
+        float* dWp = last1 ? ke->p.k1.dW : ke->p.k0.dW;
+        float* dbp = last1 ? ke->p.k1.db : ke->p.k0.db;
+        float* dbeta0p = ke->p.k0.dbeta;
+        float* dgamma0p = ke->p.k0.dgamma;
         for (int i = threadIdx.x; i < NW + NB + NG; i += 256) {
             const float v = red[i];
             if (v == 0.f) continue;
-            if (i < NW) atomicAdd(&kw.dW[i], v);
-            else if (i < NW + NB) atomicAdd(&kw.db[i - NW], v);
-            else if (i < NW + NB + C1) atomicAdd(&p.k0.dbeta[i - NW - NB], v);
-            else atomicAdd(&p.k0.dgamma[i - NW - NB - C1], v);
+            if (i < NW) atomicAdd(&dWp[i], v);
+            else if (i < NW + NB) atomicAdd(&dbp[i - NW], v);
+            else if (i < NW + NB + C1) atomicAdd(&dbeta0p[i - NW - NB], v);
+            else atomicAdd(&dgamma0p[i - NW - NB - C1], v);
         }
     }
 }
@@ -390,19 +435,21 @@ int launch_pass(const sn2_sa* p, int training, hipStream_t st, int* nblocks_out 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     const sn2_block& k0 = p->blk[0];
     const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
-    // read-only views.  A gradient array that THIS pass accumulates into (block 0's dgamma/dbeta in pass C) must not
-    // also be handed in as a __restrict__ read-only argument.
+    // read-only views.  A gradient array that THIS pass accumulates into (block 0's dgamma/dbeta in pass C) is not
+    // handed in as a read-only table.
     const bool rd0 = (PASS == PASS_BWD_D);
     const bool rd1 = BWD;
-    hipLaunchKernelGGL((sa_pass_kernel<CF, NL, C1, C2, PASS>), dim3(blocks), dim3(256), lds_bytes, st, d, p->feat, p->spos,
-                       p->cpos, p->nbr, p->cnt, p->total,
-                       k0.W, k0.b, k0.gamma, (const float*)k0.a, (const float*)k0.c, (const float*)k0.mean,
-                       (const float*)k0.invstd, (const float*)(rd0 ? k0.dgamma : nullptr),
-                       (const float*)(rd0 ? k0.dbeta : nullptr),
-                       k1.W, k1.b, k1.gamma, (const float*)k1.a, (const float*)k1.c, (const float*)k1.mean,
-                       (const float*)k1.invstd, (const float*)(rd1 ? k1.dgamma : nullptr),
-                       (const float*)(rd1 ? k1.dbeta : nullptr),
-                       (const float*)(BWD ? p->dout : nullptr), (const int*)(BWD ? p->arg : nullptr));
+    SaK k;
+    k.p = d;
+    k.feat = p->feat; k.spos = p->spos; k.cpos = p->cpos; k.nbr = p->nbr; k.cnt = p->cnt; k.total = p->total;
+    const float* t0[9] = {k0.W, k0.b, k0.gamma, k0.a, k0.c, k0.mean, k0.invstd, rd0 ? k0.dgamma : nullptr,
+                          rd0 ? k0.dbeta : nullptr};
+    const float* t1[9] = {k1.W, k1.b, k1.gamma, k1.a, k1.c, k1.mean, k1.invstd, rd1 ? k1.dgamma : nullptr,
+                          rd1 ? k1.dbeta : nullptr};
+    for (int i = 0; i < 9; ++i) { k.ro0[i] = t0[i]; k.ro1[i] = t1[i]; }
+    k.dout = BWD ? p->dout : nullptr;
+    k.arg_in = BWD ? p->arg : nullptr;
+    hipLaunchKernelGGL((sa_pass_kernel<CF, NL, C1, C2, PASS>), dim3(blocks), dim3(256), lds_bytes, st, k);
     SN2_RETURN_LAUNCH();
 }
 
