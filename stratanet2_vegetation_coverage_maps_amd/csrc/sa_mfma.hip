@@ -1,0 +1,681 @@
+// sa_mfma.hip -- set-abstraction FORWARD passes with the shared MLP on the matrix cores.
+// (PointConv(local_nn) message + max aggregation, /root/reference/model/point_net2.py:19,21-29.)
+//
+// Layout: one wave per centroid, 64 messages per step = 4 tiles of 16.  lane = (q = lane>>4, c = lane&15).
+// v_mfma_f32_16x16x4_f32 computes D[i][j] += sum_k A[i][k] B[k][j] with
+//     A: lane holds A[i = c][k = q],   B: lane holds B[k = q][j = c],   D: lane holds D[i = 4q + r][j = c], r = 0..3.
+// Here i = output channel, j = message, k = input channel, i.e. D = W . U:
+//   * the weights are the A operands: W[16 io + c][4 kb + q] -- a handful of VGPRs loaded ONCE per kernel, so no weight
+//     ever streams through SGPRs (the VALU version spent 2 v_readlane per FMA on spilled SGPRs);
+//   * the B operand of layer 1 is the message input gathered straight into MFMA layout: lane (q,c) of tile t loads
+//     element 4 kb + q of the source row of message 16 t + c (16 rows x 16 B per load instruction); the last k-block is
+//     [dx, dy, dz, 1] so the bias rides in the weight matrix;
+//   * a layer's output tile is directly the next layer's B operand: contraction block (is, kb) takes register kb of
+//     every lane, i.e. channels {16 is + 4 q + kb}; the A registers of the next layer are pre-permuted accordingly, so
+//     nothing moves between lanes;
+//   * ReLU, the BatchNorm affine, the batch statistics and the signed running extremum are elementwise on D registers
+//     with per-lane constants (4 channels per lane);
+//   * the max over a centroid's messages = elementwise over tiles and steps, then a 16-lane DPP row reduction (the 16
+//     lanes of a DPP row are exactly the 16 messages of a tile): value first, then the lowest slot among the lanes that
+//     attain it -- "first maximum wins" in ascending source index, as torch_scatter.
+#include "mlp.h"
+
+namespace {
+
+struct SaFwdArgs {
+    int B, Nsrc, M, cap, feat_stride, spos_stride;
+    const float *feat, *spos, *cpos;
+    const int *nbr, *cnt;
+    const float *W0, *b0, *a0, *c0, *gamma0;
+    const float *W1, *b1, *gamma1;
+    float *slots;  // statistics slots of the block this pass measures, or nullptr
+    float* ext;
+    int* arg;
+};
+
+// every lane ends up with the reduction over its DPP row (16 lanes)
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0xB1, 0xF)));
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x4E, 0xF)));
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x141, 0xF)));
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x140, 0xF)));
+    return v;
+}
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {
+    v = min(v, (unsigned)SN2_DPP((int)v, 0xB1, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x4E, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x141, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x140, 0xF));
+    return v;
+}
+__device__ __forceinline__ float row_sum(float v) {
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0xB1, 0xF));
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x4E, 0xF));
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x141, 0xF));
+    v += __int_as_float(SN2_DPP(__float_as_int(v), 0x140, 0xF));
+    return v;
+}
+
+// PASS 0: statistics of block 0 only (nl == 2);  PASS 1: full forward, statistics of the last block, extremum
+template <int CF, int NL, int C1, int C2, int PASS>
+__global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
+    constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
+    constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16, CS = PASS == 0 ? C1 : CL, TOS = CS / 16;
+    static_assert(CF % 4 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "tile shapes");
+    __shared__ float s_red[2 * CS];
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * 4;
+    const int ncent = a.B * a.M;
+
+    // ---- operand registers, loaded once
+    float A1[TO1][KB1];
+#pragma unroll
+    for (int io = 0; io < TO1; ++io)
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+            const int k = 4 * kb + q, o = 16 * io + c;
+            A1[io][kb] = k < CIN ? a.W0[o * CIN + k] : (k == CIN ? a.b0[o] : 0.f);
+        }
+    float A2[NL == 2 ? TO2 : 1][TO1][4], bias2[NL == 2 ? TO2 : 1][4], a1v[TO1][4], c1v[TO1][4];
+    if constexpr (NL == 2 && PASS == 1) {
+#pragma unroll
+        for (int io = 0; io < TO2; ++io) {
+#pragma unroll
+            for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) A2[io][is][kb] = a.W1[(16 * io + c) * C1 + 16 * is + 4 * q + kb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias2[io][r] = a.b1[16 * io + 4 * q + r];
+        }
+#pragma unroll
+        for (int is = 0; is < TO1; ++is)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a1v[is][r] = a.a0[16 * is + 4 * q + r];
+                c1v[is][r] = a.c0[16 * is + 4 * q + r];
+            }
+    }
+    float sgn[TOL][4];
+    if constexpr (PASS == 1) {
+        const float* gl = NL == 2 ? a.gamma1 : a.gamma0;
+#pragma unroll
+        for (int io = 0; io < TOL; ++io)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sgn[io][r] = gl[16 * io + 4 * q + r] < 0.f ? -1.f : 1.f;
+    }
+    float ssum[TOS][4], ssq[TOS][4];
+#pragma unroll
+    for (int io = 0; io < TOS; ++io)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[io][r] = ssq[io][r] = 0.f;
+
+    for (int ci = wave; ci < ncent; ci += nwaves) {
+        const int b = ci / a.M;
+        const int n = a.cnt[ci];
+        const float4 cp = reinterpret_cast<const float4*>(a.cpos)[ci];
+        const float cpq = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
+        const int* nl = a.nbr + (size_t)ci * a.cap;
+        float best[TOL][4];
+        int barg[TOL][4];
+#pragma unroll
+        for (int io = 0; io < TOL; ++io)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                best[io][r] = -INFINITY;
+                barg[io][r] = 0x7FFFFFFF;
+            }
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            // ---- layer 1: gather straight into the B-operand layout, 4 message tiles
+            f32x4 D1[TO1][4];
+            bool val[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = e0 + 16 * t + c;
+                val[t] = e < n;
+                const int j = nl[val[t] ? e : 0];
+                const size_t row = (size_t)b * a.Nsrc + j;
+                float bk[KB1];
+#pragma unroll
+                for (int kb = 0; kb < KB1 - 1; ++kb) bk[kb] = a.feat[row * a.feat_stride + 4 * kb + q];
+                const float pj = a.spos[row * a.spos_stride + (q < 3 ? q : 0)];
+                bk[KB1 - 1] = q < 3 ? pj - cpq : 1.0f;   // pos_j - pos_i | bias column
+#pragma unroll
+                for (int io = 0; io < TO1; ++io) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < KB1; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[io][kb], bk[kb], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+                    D1[io][t] = acc;
+                }
+            }
+            if constexpr (PASS == 0) {
+#pragma unroll
+                for (int io = 0; io < TO1; ++io)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float h = val[t] ? D1[io][t][r] : 0.f;
+                            ssum[io][r] += h;
+                            ssq[io][r] = fmaf(h, h, ssq[io][r]);
+                        }
+            } else {
+                // ---- layer 2 (nl == 2): BN affine of block 0, then the next contraction on the same registers
+                f32x4 DL[TOL][4];
+                if constexpr (NL == 2) {
+#pragma unroll
+                    for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) D1[is][t][r] = fmaf(a1v[is][r], D1[is][t][r], c1v[is][r]);
+#pragma unroll
+                    for (int io = 0; io < TO2; ++io)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            f32x4 acc = {bias2[io][0], bias2[io][1], bias2[io][2], bias2[io][3]};
+#pragma unroll
+                            for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                                for (int kb = 0; kb < 4; ++kb)
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[io][is][kb], D1[is][t][kb], acc, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+                            DL[io][t] = acc;
+                        }
+                } else {
+#pragma unroll
+                    for (int io = 0; io < TOL; ++io)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) DL[io][t] = D1[io][t];
+                }
+                // ---- statistics of the last block + signed running extremum (slot = position in the neighbour list)
+#pragma unroll
+                for (int io = 0; io < TOL; ++io)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = e0 + 16 * t + c;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float h = val[t] ? DL[io][t][r] : 0.f;
+                            ssum[io][r] += h;
+                            ssq[io][r] = fmaf(h, h, ssq[io][r]);
+                            const float s = sgn[io][r] * DL[io][t][r];
+                            if (val[t] && s > best[io][r]) {
+                                best[io][r] = s;
+                                barg[io][r] = e;
+                            }
+                        }
+                    }
+            }
+        }
+        if constexpr (PASS == 1) {
+#pragma unroll
+            for (int io = 0; io < TOL; ++io) {
+                float ev[4];
+                int av[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m = row_max(best[io][r]);
+                    const unsigned am = row_min_u32(best[io][r] == m ? (unsigned)barg[io][r] : 0xFFFFFFFFu);
+                    ev[r] = n > 0 ? sgn[io][r] * m : 0.f;
+                    av[r] = n > 0 ? (int)am : -1;
+                }
+                if (c == 0) {
+                    const size_t o = (size_t)ci * CL + 16 * io + 4 * q;
+                    *reinterpret_cast<float4*>(a.ext + o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                    *reinterpret_cast<int4*>(a.arg + o) = make_int4(av[0], av[1], av[2], av[3]);
+                }
+            }
+        }
+    }
+
+    // ---- batch statistics: row sums (over the 16 message lanes), then workgroup slot
+    if (a.slots) {
+        for (int i = threadIdx.x; i < 2 * CS; i += 256) s_red[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int io = 0; io < TOS; ++io)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row_sum(ssum[io][r]), s2 = row_sum(ssq[io][r]);
+                if (c == 0) {
+                    atomicAdd(&s_red[16 * io + 4 * q + r], s1);
+                    atomicAdd(&s_red[CS + 16 * io + 4 * q + r], s2);
+                }
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * CS; i += 256) a.slots[(size_t)blockIdx.x * 2 * CS + i] = s_red[i];
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------- backward passes
+// Same layout.  The forward is recomputed on the matrix cores; what is new:
+//   * BatchNorm(train)+ReLU backward per element with three per-lane constants per channel,
+//         dpre = [h > 0] * (A*dy - C*h + D),  A = gamma*is,  C = gamma*is^2*dgamma/E,  D = gamma*is*(mean*is*dgamma - dbeta)/E
+//     (dy is non-zero only on the slot that attained the extremum);
+//   * the input gradient of a layer, dy1 = W2^T dp2, is again an MFMA whose B operand is the register tile dp2 as it
+//     stands (contraction block (io, kb) = register kb), with pre-permuted A registers W2[16 io + 4 q + kb][16 is + c];
+//   * weight gradients contract over MESSAGES: both factors go through a wave-private LDS image [message][channel]
+//     (one ds_write_b128 per tile for a register tile) and come back in A/B layout with the message index as K.
+struct SaBwdArgs {
+    int B, Nsrc, M, cap, feat_stride, spos_stride;
+    const float *feat, *spos, *cpos;
+    const int *nbr, *cnt;
+    const unsigned long long* total;
+    const float *W0, *b0, *a0, *c0, *gamma0, *mean0, *invstd0, *dgamma0, *dbeta0;   // dgamma0/dbeta0: read in pass D only
+    const float *W1, *b1, *gamma1, *mean1, *invstd1, *dgamma1, *dbeta1;
+    const float* dout;
+    const int* arg;
+    float *dW0, *db0, *dW1, *db1, *dgamma0_out, *dbeta0_out;   // accumulated (atomics)
+    float* dfeat;
+};
+
+// PASS 2 = "C" (nl == 2): dW/db of block 1, dgamma/dbeta of block 0.   PASS 3 = "D": dW/db of block 0 (+ dfeat).
+template <int CF, int NL, int C1, int C2, int PASS>
+__global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
+    constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
+    constexpr bool LAST2 = NL == 2 && PASS == 2;             // this pass produces block 1's weight gradient
+    constexpr int PO = LAST2 ? C2 : C1;                      // rows of the dW image
+    constexpr int QK = LAST2 ? C1 : CIN + 1;                 // columns (block 0: inputs | bias)
+    using Acc = OuterAcc<PO, QK>;
+    constexpr int PS = Acc::PS, QS = Acc::QS, TP = Acc::TO, TQ = Acc::TK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
+    const int wib = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
+    const int nwaves = gridDim.x * 4;
+    const int ncent = a.B * a.M;
+    float* lds_p = smem + wib * Acc::LDS_FLOATS;
+    float* lds_q = lds_p + 64 * PS;
+    for (int i = lane; i < Acc::LDS_FLOATS; i += 64) lds_p[i] = 0.f;
+
+    const unsigned long long etot = *a.total;
+    const float invE = etot > 0 ? (float)(1.0 / (double)etot) : 0.f;
+
+    // ---- operand registers
+    float A1[TO1][KB1];
+#pragma unroll
+    for (int io = 0; io < TO1; ++io)
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+            const int k = 4 * kb + q, o = 16 * io + c;
+            A1[io][kb] = k < CIN ? a.W0[o * CIN + k] : (k == CIN ? a.b0[o] : 0.f);
+        }
+    float A2[NL == 2 ? TO2 : 1][TO1][4], A2T[TO1][NL == 2 ? TO2 : 1][4], bias2[NL == 2 ? TO2 : 1][4], a1v[TO1][4], c1v[TO1][4];
+    // BN-backward constants: block 0 (index 0) and, for nl == 2, block 1 (index 1)
+    float cA0[TO1][4], cC0[TO1][4], cD0[TO1][4], mu0[TO1][4], is0[TO1][4];
+    float cA1[NL == 2 ? TO2 : 1][4], cC1[NL == 2 ? TO2 : 1][4], cD1[NL == 2 ? TO2 : 1][4];
+#pragma unroll
+    for (int is = 0; is < TO1; ++is)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = 16 * is + 4 * q + r;
+            mu0[is][r] = a.mean0[ch];
+            is0[is][r] = a.invstd0[ch];
+            a1v[is][r] = NL == 2 ? a.a0[ch] : 0.f;
+            c1v[is][r] = NL == 2 ? a.c0[ch] : 0.f;
+            if (NL == 1 || PASS == 3) {
+                const float g = a.gamma0[ch], dg = a.dgamma0[ch], db = a.dbeta0[ch], m = mu0[is][r], s = is0[is][r];
+                cA0[is][r] = g * s;
+                cC0[is][r] = g * s * s * dg * invE;
+                cD0[is][r] = g * s * (m * s * dg - db) * invE;
+            } else {
+                cA0[is][r] = cC0[is][r] = cD0[is][r] = 0.f;
+            }
+        }
+    if constexpr (NL == 2) {
+#pragma unroll
+        for (int io = 0; io < TO2; ++io) {
+#pragma unroll
+            for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    A2[io][is][kb] = a.W1[(16 * io + c) * C1 + 16 * is + 4 * q + kb];
+                    A2T[is][io][kb] = a.W1[(16 * io + 4 * q + kb) * C1 + 16 * is + c];
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * io + 4 * q + r;
+                bias2[io][r] = a.b1[ch];
+                const float g = a.gamma1[ch], dg = a.dgamma1[ch], db = a.dbeta1[ch], m = a.mean1[ch], s = a.invstd1[ch];
+                cA1[io][r] = g * s;
+                cC1[io][r] = g * s * s * dg * invE;
+                cD1[io][r] = g * s * (m * s * dg - db) * invE;
+            }
+        }
+    }
+    // input-gradient operand of block 0 (pass D with dfeat): W0^T rows k < CF, one 16-wide tile per 16 feature channels
+    constexpr int TF = CF / 16 > 0 ? CF / 16 : 1;
+    float A0T[TF][TO1][4];
+    if (PASS == 3 && a.dfeat) {
+#pragma unroll
+        for (int kt = 0; kt < TF; ++kt)
+#pragma unroll
+            for (int io = 0; io < TO1; ++io)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const int k = 16 * kt + c;
+                    A0T[kt][io][kb] = k < CF ? a.W0[(16 * io + 4 * q + kb) * CIN + k] : 0.f;
+                }
+    }
+
+    f32x4 acc[TP][TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbias[LAST2 ? TO2 : 1][4], dbe0[TO1][4], dga0[TO1][4];   // block 1 bias gradient; block 0 BN gradients (pass C)
+#pragma unroll
+    for (int i = 0; i < (LAST2 ? TO2 : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbias[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TO1; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbe0[i][r] = dga0[i][r] = 0.f;
+
+    constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16;
+    for (int ci = wave; ci < ncent; ci += nwaves) {
+        const int b = ci / a.M;
+        const int n = a.cnt[ci];
+        const float4 cp = reinterpret_cast<const float4*>(a.cpos)[ci];
+        const float cpq = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
+        const int* nl = a.nbr + (size_t)ci * a.cap;
+        // d loss / d output and the winning slot of this lane's 4 channels per tile row
+        float dov[TOL][4];
+        int arv[TOL][4];
+#pragma unroll
+        for (int io = 0; io < TOL; ++io) {
+            const size_t o = (size_t)ci * CL + 16 * io + 4 * q;
+            const float4 dv = *reinterpret_cast<const float4*>(a.dout + o);
+            const int4 av = *reinterpret_cast<const int4*>(a.arg + o);
+            dov[io][0] = dv.x; dov[io][1] = dv.y; dov[io][2] = dv.z; dov[io][3] = dv.w;
+            arv[io][0] = av.x; arv[io][1] = av.y; arv[io][2] = av.z; arv[io][3] = av.w;
+        }
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            f32x4 D1[TO1][4];
+            float bks[4][KB1];
+            bool val[4];
+            size_t rows[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = e0 + 16 * t + c;
+                val[t] = e < n;
+                const int j = nl[val[t] ? e : 0];
+                rows[t] = (size_t)b * a.Nsrc + j;
+#pragma unroll
+                for (int kb = 0; kb < KB1 - 1; ++kb) bks[t][kb] = a.feat[rows[t] * a.feat_stride + 4 * kb + q];
+                const float pj = a.spos[rows[t] * a.spos_stride + (q < 3 ? q : 0)];
+                bks[t][KB1 - 1] = q < 3 ? pj - cpq : 1.0f;
+#pragma unroll
+                for (int io = 0; io < TO1; ++io) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < KB1; ++kb) v = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[io][kb], bks[t][kb], v, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    D1[io][t] = v;
+                }
+            }
+            f32x4 dy1[TO1][4];   // d loss / d (BN output of block 0)
+            if constexpr (NL == 2) {
+                f32x4 Y1[TO1][4], dp2[TO2][4];
+#pragma unroll
+                for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Y1[is][t][r] = fmaf(a1v[is][r], D1[is][t][r], c1v[is][r]);
+#pragma unroll
+                for (int io = 0; io < TO2; ++io)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        f32x4 v = {bias2[io][0], bias2[io][1], bias2[io][2], bias2[io][3]};
+#pragma unroll
+                        for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb)
+                                v = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[io][is][kb], Y1[is][t][kb], v, 0, 0, 0);
+                        const int e = e0 + 16 * t + c;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float h = fmaxf(v[r], 0.f);
+                            const float dy = (val[t] && arv[io][r] == e) ? dov[io][r] : 0.f;
+                            dp2[io][t][r] = (val[t] && h > 0.f) ? fmaf(cA1[io][r], dy, fmaf(-cC1[io][r], h, cD1[io][r])) : 0.f;
+                        }
+                    }
+                // d loss / d y1 = W2^T dp2
+#pragma unroll
+                for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int io = 0; io < TO2; ++io)
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb)
+                                v = __builtin_amdgcn_mfma_f32_16x16x4f32(A2T[is][io][kb], dp2[io][t][kb], v, 0, 0, 0);
+                        dy1[is][t] = v;
+                    }
+                if constexpr (PASS == 2) {
+                    // images [message][channel]: dp2 and y1
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int io = 0; io < TO2; ++io)
+                            *reinterpret_cast<float4*>(lds_p + (16 * t + c) * PS + 16 * io + 4 * q) =
+                                make_float4(dp2[io][t][0], dp2[io][t][1], dp2[io][t][2], dp2[io][t][3]);
+#pragma unroll
+                        for (int is = 0; is < TO1; ++is)
+                            *reinterpret_cast<float4*>(lds_q + (16 * t + c) * QS + 16 * is + 4 * q) =
+                                make_float4(Y1[is][t][0], Y1[is][t][1], Y1[is][t][2], Y1[is][t][3]);
+                    }
+#pragma unroll
+                    for (int io = 0; io < TO2; ++io)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dbias[io][r] += dp2[io][t][r];
+#pragma unroll
+                    for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                dbe0[is][r] += dy1[is][t][r];
+                                dga0[is][r] = fmaf(dy1[is][t][r], (D1[is][t][r] - mu0[is][r]) * is0[is][r], dga0[is][r]);
+                            }
+                }
+            } else {
+                // nl == 1: the only block is the last one, dy comes from the extremum slot
+#pragma unroll
+                for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = e0 + 16 * t + c;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dy1[is][t][r] = (val[t] && arv[is][r] == e) ? dov[is][r] : 0.f;
+                    }
+            }
+            if constexpr (PASS == 3) {
+                f32x4 dp1[TO1][4];
+#pragma unroll
+                for (int is = 0; is < TO1; ++is)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float h = D1[is][t][r];
+                            dp1[is][t][r] = (val[t] && h > 0.f)
+                                                ? fmaf(cA0[is][r], dy1[is][t][r], fmaf(-cC0[is][r], h, cD0[is][r])) : 0.f;
+                        }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int is = 0; is < TO1; ++is)
+                        *reinterpret_cast<float4*>(lds_p + (16 * t + c) * PS + 16 * is + 4 * q) =
+                            make_float4(dp1[is][t][0], dp1[is][t][1], dp1[is][t][2], dp1[is][t][3]);
+#pragma unroll
+                    for (int kb = 0; kb < KB1; ++kb) lds_q[(16 * t + c) * QS + 4 * kb + q] = bks[t][kb];
+                }
+                if (a.dfeat) {
+                    // d loss / d source features = W0^T dp1, rows k < CF; added onto the source rows of the messages
+#pragma unroll
+                    for (int kt = 0; kt < TF; ++kt)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int io = 0; io < TO1; ++io)
+#pragma unroll
+                                for (int kb = 0; kb < 4; ++kb)
+                                    v = __builtin_amdgcn_mfma_f32_16x16x4f32(A0T[kt][io][kb], dp1[io][t][kb], v, 0, 0, 0);
+                            if (val[t]) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int k = 16 * kt + 4 * q + r;
+                                    if (k < CF) atomicAdd(&a.dfeat[rows[t] * CF + k], v[r]);
+                                }
+                            }
+                        }
+                }
+            }
+            // ---- weight gradient of this pass: contraction over the 64 messages of the step (16 k-steps of 4)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const float* rp = lds_p + q * PS + c;
+                const float* rq = lds_q + q * QS + c;
+#pragma unroll 4
+                for (int st = 0; st < 16; ++st) {
+                    float av[TP], bv[TQ];
+#pragma unroll
+                    for (int i = 0; i < TP; ++i) av[i] = rp[st * 4 * PS + 16 * i];
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) bv[j] = rq[st * 4 * QS + 16 * j];
+#pragma unroll
+                    for (int i = 0; i < TP; ++i)
+#pragma unroll
+                        for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- workgroup-level reduction, then one global atomic per element
+    constexpr int NW = PO * QK, NB = LAST2 ? C2 : 0, NG = LAST2 ? 2 * C1 : 0;
+    float* red = smem;
+    __syncthreads();
+    for (int i = threadIdx.x; i < NW + NB + NG; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * i + 4 * q + r, k = 16 * j + c;
+                if (o < PO && k < QK) atomicAdd(&red[o * QK + k], acc[i][j][r]);
+            }
+    if constexpr (LAST2) {
+#pragma unroll
+        for (int io = 0; io < TO2; ++io)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = row_sum(dbias[io][r]);
+                if (c == 0) atomicAdd(&red[NW + 16 * io + 4 * q + r], v);
+            }
+#pragma unroll
+        for (int is = 0; is < TO1; ++is)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v1 = row_sum(dbe0[is][r]), v2 = row_sum(dga0[is][r]);
+                if (c == 0) {
+                    atomicAdd(&red[NW + NB + 16 * is + 4 * q + r], v1);
+                    atomicAdd(&red[NW + NB + C1 + 16 * is + 4 * q + r], v2);
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NW + NB + NG; i += 256) {
+        const float v = red[i];
+        if (v == 0.f) continue;
+        if (i < NW) {
+            if constexpr (LAST2) {
+                atomicAdd(&a.dW1[i], v);
+            } else {
+                const int o = i / QK, k = i - o * QK;   // block 0: columns = inputs | bias
+                if (k < CIN) atomicAdd(&a.dW0[o * CIN + k], v);
+                else atomicAdd(&a.db0[o], v);
+            }
+        } else if (i < NW + NB) {
+            atomicAdd(&a.db1[i - NW], v);
+        } else if (i < NW + NB + C1) {
+            atomicAdd(&a.dbeta0_out[i - NW - NB], v);
+        } else {
+            atomicAdd(&a.dgamma0_out[i - NW - NB - C1], v);
+        }
+    }
+}
+
+}  // namespace
+
+// launched from sa.hip
+template <int CF, int NL, int C1, int C2, int PASS>
+int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nblocks_out) {
+    SaFwdArgs a;
+    a.B = p->B; a.Nsrc = p->Nsrc; a.M = p->M; a.cap = p->cap; a.feat_stride = p->feat_stride; a.spos_stride = p->spos_stride;
+    a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt;
+    const sn2_block& k0 = p->blk[0];
+    const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
+    a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma;
+    a.W1 = k1.W; a.b1 = k1.b; a.gamma1 = k1.gamma;
+    a.slots = training ? (PASS == 0 ? k0.stat_slots : k1.stat_slots) : nullptr;
+    a.ext = p->ext; a.arg = p->arg;
+    int blocks = sn2_cdiv((long)p->B * p->M, 4);
+    if (blocks > SN2_STAT_SLOTS) blocks = SN2_STAT_SLOTS;
+    if (nblocks_out) *nblocks_out = blocks;
+    hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS>), dim3(blocks), dim3(256), 0, st, a);
+    SN2_RETURN_LAUNCH();
+}
+
+template int sa_mfma_launch_fwd<8, 2, 16, 16, 0>(const sn2_sa*, int, hipStream_t, int*);
+template int sa_mfma_launch_fwd<8, 2, 16, 16, 1>(const sn2_sa*, int, hipStream_t, int*);
+template int sa_mfma_launch_fwd<16, 1, 32, 32, 1>(const sn2_sa*, int, hipStream_t, int*);
+
+template <int CF, int NL, int C1, int C2, int PASS>
+int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
+    constexpr int CIN = CF + 3;
+    constexpr bool LAST2 = NL == 2 && PASS == 2;
+    using Acc = OuterAcc<(LAST2 ? C2 : C1), (LAST2 ? C1 : CIN + 1)>;
+    SaBwdArgs a;
+    a.B = p->B; a.Nsrc = p->Nsrc; a.M = p->M; a.cap = p->cap; a.feat_stride = p->feat_stride; a.spos_stride = p->spos_stride;
+    a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt; a.total = p->total;
+    const sn2_block& k0 = p->blk[0];
+    const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
+    a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma; a.mean0 = k0.mean; a.invstd0 = k0.invstd;
+    a.dgamma0 = k0.dgamma; a.dbeta0 = k0.dbeta;
+    a.W1 = k1.W; a.b1 = k1.b; a.gamma1 = k1.gamma; a.mean1 = k1.mean; a.invstd1 = k1.invstd; a.dgamma1 = k1.dgamma;
+    a.dbeta1 = k1.dbeta;
+    a.dout = p->dout; a.arg = p->arg;
+    a.dW0 = k0.dW; a.db0 = k0.db; a.dW1 = k1.dW; a.db1 = k1.db; a.dgamma0_out = k0.dgamma; a.dbeta0_out = k0.dbeta;
+    a.dfeat = p->dfeat;
+    int blocks = sn2_cdiv((long)p->B * p->M, 4);
+    if (blocks > 512) blocks = 512;
+    const size_t lds = (size_t)Acc::LDS_FLOATS * 4 * sizeof(float);
+    auto kern = &sa_mfma_bwd_kernel<CF, NL, C1, C2, PASS>;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
+    SN2_RETURN_LAUNCH();
+}
+
+template int sa_mfma_launch_bwd<8, 2, 16, 16, 2>(const sn2_sa*, hipStream_t);
+template int sa_mfma_launch_bwd<8, 2, 16, 16, 3>(const sn2_sa*, hipStream_t);
+template int sa_mfma_launch_bwd<16, 1, 32, 32, 3>(const sn2_sa*, hipStream_t);
