@@ -110,7 +110,8 @@ typedef struct sn2_fp {
     float *dsrc; int dsrc_stride;   /* backward out: ACCUMULATED d loss / d (sa*src+sc) (B*S,dsrc_stride) or NULL */
     float *dskip; int dskip_stride; /* backward out: ACCUMULATED (B*R, >=cb) or NULL                             */
     float *du_scratch;              /* backward workspace (B*R,ca) when knn_idx and dsrc are given               */
-    float *scatter_ws;              /* backward workspace 16*B*S*ca floats when knn_idx and dsrc are given        */
+    float *scatter_ws;              /* backward workspace when knn_idx and dsrc are given: B*S*(ceil(R/2048)+2) + 6*B*R
+                                       32-bit words (inverted index of the 3-NN table)                           */
 } sn2_fp;
 int sn2_fp_forward(const sn2_fp *p, int training, void *stream);
 int sn2_fp_backward(const sn2_fp *p, void *stream);

@@ -7,9 +7,8 @@
 // the pre-BN activation h is stored once (row stride padded to 16 B) and its batch statistics are reduced per wave and
 // added as fp64 atomics.  Consumers apply the BN affine (a, c) when they read h, so no BN-apply pass exists.
 // Backward: (1) dgamma/dbeta reduction over rows, (2) main pass: dpre, dW|db through the MFMA outer-product accumulator
-// (rows = MFMA K), input gradient du; (3) the interpolation's transpose: du rows are scattered onto their 1..3 source
-// rows with LDS float atomics on a per-plot tile of the source table (global float atomics onto random rows run ~17x
-// below the streaming atomic rate on this chip), then flushed with one global atomic per element.
+// (rows = MFMA K), input gradient du; (3) the interpolation's transpose as a gather through an inverted index (no
+// floating-point atomics: see "backward (3)").
 #include "mlp.h"
 
 namespace {
@@ -261,71 +260,127 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------- backward (3)
-// dsrc[plot*S + idx_j][k] += (w_j / sum w) * du[r][k] for the 1..3 neighbours of every target row r of the plot.
-// grid (slices, tiles, B); LDS holds a tile of TS source rows x CA channels.
-template <int CA>
-__global__ __launch_bounds__(1024) void interp_scatter_kernel(int R_per_plot, int S_per_plot, int TS, int dsrc_stride,
-                                                              const int* __restrict__ knn_idx,
-                                                              const float* __restrict__ knn_w,
-                                                              const float* __restrict__ du, float* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    const int b = blockIdx.z;
-    const int s_lo = blockIdx.y * TS;
-    const int s_hi = min(S_per_plot, s_lo + TS);
-    const int nt = (s_hi - s_lo) * CA;
-    for (int i = threadIdx.x; i < nt; i += 1024) tile[i] = 0.f;
+// Transpose of the interpolation:  dsrc[s][k] += sum over (target r, slot j) with idx_j(r) = s of (w_j / sum w) * du[r][k].
+// Done as a GATHER through an inverted index (source -> list of (row, weight)), built per call from the saved 3-NN table:
+//   A  per (plot, row slice): histogram of the slice's source ids in LDS (integer atomics on 4 KB) -> H[plot][slice][s]
+//   B  per plot: exclusive prefix over the slices of every source and over the sources -> list offsets
+//   C  per (plot, row slice): LDS cursors -> (row, normalised weight) entries at their final positions
+//   D  one wave per source row, lane = channel: coalesced du rows, accumulation in registers, one plain store.
+// No floating-point atomics anywhere (LDS float atomics ran at ~0.4 lane-ops/clk/CU here: 275 us for FP1; global float
+// atomics onto random rows are worse), and dsrc is written exactly once per row.
+constexpr int INV_SLICE_ROWS = 2048;
+
+__global__ __launch_bounds__(1024) void inv_hist_kernel(int R_per_plot, int S, const int* __restrict__ knn_idx,
+                                                        const float* __restrict__ knn_w, int* __restrict__ H) {
+    extern __shared__ int s_hist[];
+    const int b = blockIdx.y, sl = blockIdx.x, SL = gridDim.x;
+    for (int i = threadIdx.x; i < S; i += 1024) s_hist[i] = 0;
     __syncthreads();
-    const int rows_per_slice = (R_per_plot + gridDim.x - 1) / gridDim.x;
-    const int r_lo = blockIdx.x * rows_per_slice;
-    const int r_hi = min(R_per_plot, r_lo + rows_per_slice);
-    // one wave per target row, lane = channel: the row's 3 neighbour indices / weights are wave-uniform (scalar loads),
-    // its du row is one coalesced load and the three LDS float atomics of a wave-instruction hit consecutive words.
-    // Four rows in flight per wave hide the load latency (the first version, one (row, channel) pair per lane with
-    // dependent loads, was latency-bound at 300 us for FP1).
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r0 = r_lo + wave * 4; r0 < r_hi; r0 += 16 * 4) {
-        float g[4], w[4][3];
-        int id[4][3];
+    const int r_lo = sl * INV_SLICE_ROWS, r_hi = min(R_per_plot, r_lo + INV_SLICE_ROWS);
+    for (int rl = r_lo + threadIdx.x; rl < r_hi; rl += 1024) {
+        const size_t r = (size_t)b * R_per_plot + rl;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rl = min(r0 + u, r_hi - 1);
-            const size_t r = (size_t)b * R_per_plot + rl;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                w[u][j] = knn_w[r * 3 + j];
-                id[u][j] = knn_idx[r * 3 + j];
-            }
-            g[u] = (lane < CA && r0 + u < r_hi) ? du[r * CA + lane] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (r0 + u >= r_hi || lane >= CA) continue;
-            const float gs = g[u] / ((w[u][0] + w[u][1]) + w[u][2]);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int i = id[u][j];
-                if ((j == 0 || w[u][j] != 0.f) && i >= s_lo && i < s_hi) atomicAdd(&tile[(i - s_lo) * CA + lane], gs * w[u][j]);
-            }
-        }
+        for (int j = 0; j < 3; ++j)
+            if (j == 0 || knn_w[r * 3 + j] != 0.f) atomicAdd(&s_hist[knn_idx[r * 3 + j]], 1);
     }
     __syncthreads();
-    // this slice's partial sums leave as plain coalesced stores (slice-major); interp_reduce_kernel adds the slices.
-    // (Flushing every slice with global float atomics -- 9 M of them for FP1 -- cost 0.3 ms.)
-    float* dst = part + (((size_t)blockIdx.x * gridDim.z + b) * S_per_plot + s_lo) * CA;
-    for (int i = threadIdx.x; i < nt; i += 1024) dst[i] = tile[i];
+    int* out = H + ((size_t)b * SL + sl) * S;
+    for (int i = threadIdx.x; i < S; i += 1024) out[i] = s_hist[i];
 }
 
-// dsrc[row][k] += sum over slices of part[slice][row][k]
-__global__ __launch_bounds__(256) void interp_reduce_kernel(const float* __restrict__ part, int slices, long n_rows, int CA,
-                                                            int dsrc_stride, float* __restrict__ dsrc) {
-    const long total = n_rows * CA;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        float a = 0.f;
-        for (int sl = 0; sl < slices; ++sl) a += part[(size_t)sl * total + i];
-        const long row = i / CA;
-        const int k = (int)(i - row * CA);
-        dsrc[(size_t)row * dsrc_stride + k] += a;
+// H[plot][slice][s] -> exclusive prefix over slices (in place);  off[plot*S + s] = plot*3*R + exclusive scan of the totals;
+// cnt[plot*S + s] = total
+__global__ __launch_bounds__(1024) void inv_scan_kernel(int R_per_plot, int S, int SL, int* __restrict__ H,
+                                                        int* __restrict__ off, int* __restrict__ cnt) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = b * 3 * R_per_plot;
+    __syncthreads();
+    for (int s0 = 0; s0 < S; s0 += 1024) {
+        const int s = s0 + threadIdx.x;
+        int tot = 0;
+        if (s < S) {
+            for (int sl = 0; sl < SL; ++sl) {
+                int* h = H + ((size_t)b * SL + sl) * S + s;
+                const int t = *h;
+                *h = tot;
+                tot += t;
+            }
+            cnt[(size_t)b * S + s] = tot;
+        }
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int base = s_carry;
+        for (int k = 0; k < wave; ++k) base += s_w[k];
+        if (s < S) off[(size_t)b * S + s] = base + incl - tot;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = base + incl;
+        __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(1024) void inv_fill_kernel(int R_per_plot, int S, const int* __restrict__ knn_idx,
+                                                        const float* __restrict__ knn_w, const int* __restrict__ H,
+                                                        const int* __restrict__ off, int* __restrict__ inv_row,
+                                                        float* __restrict__ inv_w) {
+    extern __shared__ int s_cur[];
+    const int b = blockIdx.y, sl = blockIdx.x, SL = gridDim.x;
+    const int* hp = H + ((size_t)b * SL + sl) * S;
+    for (int i = threadIdx.x; i < S; i += 1024) s_cur[i] = off[(size_t)b * S + i] + hp[i];
+    __syncthreads();
+    const int r_lo = sl * INV_SLICE_ROWS, r_hi = min(R_per_plot, r_lo + INV_SLICE_ROWS);
+    for (int rl = r_lo + threadIdx.x; rl < r_hi; rl += 1024) {
+        const size_t r = (size_t)b * R_per_plot + rl;
+        const float w0 = knn_w[r * 3 + 0], w1 = knn_w[r * 3 + 1], w2 = knn_w[r * 3 + 2];
+        const float inv = 1.0f / ((w0 + w1) + w2);
+        const float w[3] = {w0, w1, w2};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j == 0 || w[j] != 0.f) {
+                const int p = atomicAdd(&s_cur[knn_idx[r * 3 + j]], 1);
+                inv_row[p] = rl;
+                inv_w[p] = w[j] * inv;
+            }
+    }
+}
+
+template <int CA>
+__global__ __launch_bounds__(256) void interp_gather_kernel(int n_src, int R_per_plot, int S, int dsrc_stride,
+                                                            const int* __restrict__ off, const int* __restrict__ cnt,
+                                                            const int* __restrict__ inv_row, const float* __restrict__ inv_w,
+                                                            const float* __restrict__ du, float* __restrict__ dsrc) {
+    const int lane = threadIdx.x & 63;
+    const int s = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (s >= n_src) return;
+    const int b = s / S;
+    const int n = cnt[s], st = off[s];
+    const float* dub = du + (size_t)b * R_per_plot * CA;
+    const bool on = lane < CA;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {   // four independent row loads in flight
+        const int r0 = inv_row[st + i], r1 = inv_row[st + i + 1], r2 = inv_row[st + i + 2], r3 = inv_row[st + i + 3];
+        const float w0 = inv_w[st + i], w1 = inv_w[st + i + 1], w2 = inv_w[st + i + 2], w3 = inv_w[st + i + 3];
+        const float v0 = on ? dub[(size_t)r0 * CA + lane] : 0.f, v1 = on ? dub[(size_t)r1 * CA + lane] : 0.f;
+        const float v2 = on ? dub[(size_t)r2 * CA + lane] : 0.f, v3 = on ? dub[(size_t)r3 * CA + lane] : 0.f;
+        g0 = fmaf(w0, v0, g0);
+        g1 = fmaf(w1, v1, g1);
+        g2 = fmaf(w2, v2, g2);
+        g3 = fmaf(w3, v3, g3);
+    }
+    for (; i < n; ++i) {
+        const int r0 = inv_row[st + i];
+        const float w0 = inv_w[st + i];
+        g0 = fmaf(w0, on ? dub[(size_t)r0 * CA + lane] : 0.f, g0);
+    }
+    if (on) dsrc[(size_t)s * dsrc_stride + lane] += (g0 + g1) + (g2 + g3);
 }
 
 // ---------------------------------------------------------------------------------------------- small layers
@@ -560,23 +615,24 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (KNN && p->dsrc) {
-        int TS = (144 * 1024) / (CA * 4);
-        if (TS > p->S_per_plot) TS = p->S_per_plot;
-        const int tiles = sn2_cdiv(p->S_per_plot, TS);
-        int slices = sn2_cdiv(p->R_per_plot, 2048);
-        if (slices < 1) slices = 1;
-        if (slices > 32) slices = 32;
-        const size_t tb = (size_t)TS * CA * 4;
-        if (tb > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&interp_scatter_kernel<CA>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
         if (!p->scatter_ws) return SN2_EINVAL;
-        hipLaunchKernelGGL((interp_scatter_kernel<CA>), dim3(slices, tiles, p->B), dim3(1024), tb, st, p->R_per_plot,
-                           p->S_per_plot, TS, p->dsrc_stride, p->knn_idx, p->knn_w, (const float*)p->du_scratch,
-                           p->scatter_ws);
-        const long n_rows = (long)p->B * p->S_per_plot;
-        hipLaunchKernelGGL(interp_reduce_kernel, dim3(pick_grid(n_rows * CA, 256, 1)), dim3(256), 0, st,
-                           (const float*)p->scatter_ws, slices, n_rows, CA, p->dsrc_stride, p->dsrc);
+        const int S = p->S_per_plot, Rp = p->R_per_plot, B = p->B;
+        if (S > 8192) return SN2_ELIMIT;
+        const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
+        // workspace carve (32-bit words): H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp]
+        int* H = reinterpret_cast<int*>(p->scatter_ws);
+        int* off = H + (size_t)B * SL * S;
+        int* cnt = off + (size_t)B * S;
+        int* inv_row = cnt + (size_t)B * S;
+        float* inv_w = reinterpret_cast<float*>(inv_row + (size_t)3 * B * Rp);
+        hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, p->knn_idx, p->knn_w, H);
+        hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, H, off, cnt);
+        hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, p->knn_idx, p->knn_w,
+                           (const int*)H, (const int*)off, inv_row, inv_w);
+        const int n_src = B * S;
+        hipLaunchKernelGGL((interp_gather_kernel<CA>), dim3(sn2_cdiv(n_src, 4)), dim3(256), 0, st, n_src, Rp, S,
+                           p->dsrc_stride, (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
+                           (const float*)p->du_scratch, p->dsrc);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }

@@ -295,8 +295,9 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     if du_scratch is not None:
         _chk(du_scratch, F32, (R, ca), "du_scratch")
         if knn is not None and dsrc is not None:
-            # per-slice partial sums of the interpolation transpose (no initialisation needed)
-            d._scatter_ws = torch.empty(16 * n_src_rows * ca, dtype=F32, device=src.device)
+            # inverted index of the 3-NN table (no initialisation needed): see fp.hip "backward (3)"
+            words = n_src_rows * ((R_per_plot + 2047) // 2048 + 2) + 6 * R + 64
+            d._scatter_ws = torch.empty(words, dtype=F32, device=src.device)
             d.scatter_ws = _ptr(d._scatter_ws)
     d.dy, d.dsrc, d.dskip, d.du_scratch = _ptr(dy), _ptr(dsrc), _ptr(dskip), _ptr(du_scratch)
     return d
