@@ -57,17 +57,22 @@ int sn2_pack_rows(const float *cloud, const float *xyz, int B, int C, int N, flo
 /* farthest point sampling -- torch_cluster.fps, model/point_net2.py:22.
  * start (B) local start index per plot or NULL (= 0, i.e. random_start=False).
  * idx (B,M) local indices in selection order; cpos_soa (B,3,M) and cpos_aos (B*M,4) = the selected positions.
- * order_ws: workspace of 5*B*N int32 (16-byte aligned, no initialisation: B*N ints of spatial order followed by B*N
- * float4 of sorted points) enabling the bucketed kernel (exact same result, several times faster at N = 32768), or
- * NULL for the brute-force kernel. */
+ * order_ws: workspace of SN2_FPS_WS_WORDS(B,N) int32 (16-byte aligned, no initialisation: B*N ints of spatial order,
+ * B*N float4 of sorted points, B cell-grid headers) enabling the bucketed kernel (exact same result, several times
+ * faster at N = 32768), or NULL for the brute-force kernel.  After the call the workspace describes the sorted point
+ * set and can be handed to sn2_ball_query over the same sources. */
+#define SN2_FPS_WS_WORDS(B, N) (5L * (B) * (N) + 4104L * (B))
 int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
             float *cpos_aos, int *order_ws, void *stream);
 
 /* radius ball query -- torch_cluster.radius, model/point_net2.py:23-25.
- * For centroid i of plot b: all source points j of plot b with d2 < r2 (strict, canonical fp32 arithmetic),
- * ascending j, at most `cap` of them: nbr[(b*M+i)*cap + 0..cnt-1], cnt[b*M+i]. *total += sum of cnt. */
+ * For centroid i of plot b: all source points j of plot b with d2 < r2 (strict, canonical fp32 arithmetic; r2 = the
+ * fp32 value of r*r evaluated in double, as torch_cluster compares),
+ * ascending j, at most `cap` of them: nbr[(b*M+i)*cap + 0..cnt-1], cnt[b*M+i]. *total += sum of cnt.
+ * fps_ws: the workspace a bucketed sn2_fps call over the SAME sources left behind (cell lists: ~200 candidates per
+ * centroid instead of N), or NULL for the full scan; same result either way. */
 int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, int M, float r2, int cap,
-                   int *nbr, int *cnt, unsigned long long *total, void *stream);
+                   int *nbr, int *cnt, unsigned long long *total, const int *fps_ws, void *stream);
 
 /* k nearest sources (k = 1..3) + inverse squared distance weights -- the no_grad part of
  * torch_geometric.nn.knn_interpolate, model/point_net2.py:63.

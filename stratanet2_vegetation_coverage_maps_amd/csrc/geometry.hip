@@ -114,7 +114,7 @@ static int launch_fps(const float* pos, int B, int N, int M, const int* start, i
 // Bucketed FPS (exact).  The brute-force kernel above touches all N points in each of the M sequential rounds
 // (4.1 ms for 16 x 32768 -> 1024 on MI355X: 40 % of a training step).  But a new sample s only lowers the running
 // distance of points closer to s than their current distance, i.e. points near s.  So:
-//   * spatial_order_kernel sorts a plot's points by the Morton code of a 32x32x8 cell grid (LDS counting sort);
+//   * spatial_order_kernel sorts a plot's points by the Morton code of a 16x16x16 cell grid (LDS counting sort);
 //   * consecutive runs of 64 sorted points form a BUCKET = one VGPR slot of one wave (bucket b -> wave b % 16, slot
 //     b / 16, so spatially adjacent buckets sit in different waves and a round's work spreads over the 16 waves);
 //   * per bucket LDS keeps the bounding box and the maximum running distance; per round each wave tests its <= 32
@@ -138,8 +138,10 @@ __device__ __forceinline__ unsigned morton_cell(unsigned cx, unsigned cy, unsign
     return c;
 }
 
+// grid header per plot (32-bit words): [0..4096] first sorted position of every Morton cell (+ end), then lo.xyz, scale.xyz
+constexpr int GRID_WORDS = ORDER_CELLS + 1 + 6 + 1;   // padded to an even count
 __global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
-                                                             float4* __restrict__ sorted) {
+                                                             float4* __restrict__ sorted, int* __restrict__ grid) {
     __shared__ int s_hist[ORDER_CELLS];
     __shared__ float s_mm[6][16];
     __shared__ int s_wsum[16];
@@ -211,6 +213,16 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __rest
     for (int k = 0; k < PER; ++k) {
         s_hist[tid * PER + k] = run;
         run += loc[k];
+    }
+    __syncthreads();
+    if (grid) {   // cell -> first sorted position (the ball query walks these cell lists)
+        int* gb = grid + (size_t)b * GRID_WORDS;
+        for (int i = tid; i < ORDER_CELLS; i += 1024) gb[i] = s_hist[i];
+        if (tid == 0) {
+            gb[ORDER_CELLS] = N;
+            float* gf = reinterpret_cast<float*>(gb + ORDER_CELLS + 1);
+            gf[0] = lo[0]; gf[1] = lo[1]; gf[2] = lo[2]; gf[3] = sc[0]; gf[4] = sc[1]; gf[5] = sc[2];
+        }
     }
     __syncthreads();
     int* ob = order + (size_t)b * N;
@@ -429,7 +441,8 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
     int* order = ws;                                               // B*N ints
     float4* sorted = reinterpret_cast<float4*>(ws + (size_t)B * N);   // B*N float4 (16-byte aligned: B*N*4 bytes offset
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
-    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), 0, st, pos, N, order, sorted);
+    int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
+    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid);
     hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), 0, st, pos, N, M, start, (const int*)order,
                        (const float4*)sorted, idx, cs, ca);
     SN2_RETURN_LAUNCH();
@@ -512,17 +525,178 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
             sum += (unsigned long long)c;
         }
     }
-    if (lane == 0 && total) atomicAdd(total, sum);
+    (void)sum;
+    (void)total;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Grid ball query (exact): the sources were already sorted into 16^3 Morton cells by spatial_order_kernel (FPS level 1
+// runs on the same points).  One wave per centroid walks only the cells that can intersect the ball -- the cell range of
+// [c - r, c + r] per axis under the same monotone fp32 cell function, so no point with d2 < r2 is missed --, tests the
+// cells' points with the canonical sn2_d2, compacts the hits into a wave-private LDS list, rank-sorts them by ORIGINAL
+// index (the contract: ascending source index, first `cap` kept) and writes the list.  ~200 candidates per centroid
+// instead of 32 768.  A ball with more hits than the LDS list (GQ_LIST) falls back to the full scan for that centroid.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int GQ_LIST = 512;
+
+__global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __restrict__ src, int B, int N,
+                                                              const float* __restrict__ cpos, int M, float r, float r2,
+                                                              int cap, const int* __restrict__ order,
+                                                              const float4* __restrict__ sorted, const int* __restrict__ grid,
+                                                              int* __restrict__ nbr, int* __restrict__ cnt,
+                                                              unsigned long long* __restrict__ total) {
+    __shared__ int s_list[4][GQ_LIST];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int ci = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
+    if (ci >= B * M) return;
+    const int b = ci / M, m = ci - b * M;
+    const float cx = cpos[((size_t)b * 3 + 0) * M + m], cy = cpos[((size_t)b * 3 + 1) * M + m],
+                cz = cpos[((size_t)b * 3 + 2) * M + m];
+    const int* gb = grid + (size_t)b * GRID_WORDS;
+    const float* gf = reinterpret_cast<const float*>(gb + ORDER_CELLS + 1);
+    const int* ord = order + (size_t)b * N;
+    const float4* pts = sorted + (size_t)b * N;
+    int* list = s_list[wib];
+    // conservative cell range: slightly enlarged radius, same cell function as the sort (monotone in the coordinate)
+    const float rr = r * 1.0001f + 1e-6f;
+    int lo3[3], hi3[3];
+    {
+        const float cc[3] = {cx, cy, cz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int G = a < 2 ? ORDER_GX : ORDER_GZ;
+            int l = (int)(((cc[a] - rr) - gf[a]) * gf[3 + a]), h = (int)(((cc[a] + rr) - gf[a]) * gf[3 + a]);
+            // (int) truncates toward zero: a negative argument must still map to cell 0 -> clamp covers it
+            lo3[a] = l < 0 ? 0 : (l > G - 1 ? G - 1 : l);
+            hi3[a] = h < 0 ? 0 : (h > G - 1 ? G - 1 : h);
+            if ((cc[a] - rr) - gf[a] < 0.f) lo3[a] = 0;
+        }
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int h = 0;
+    // one lane per candidate cell: all cell bounds arrive with ONE round trip, then the candidates of all cells form one
+    // flat sequence that the wave walks 64 at a time (a cell-by-cell walk serialised ~50 dependent loads per centroid)
+    const int ncx = hi3[0] - lo3[0] + 1, ncy = hi3[1] - lo3[1] + 1, ncz = hi3[2] - lo3[2] + 1;
+    const int ncell = ncx * ncy * ncz;
+    bool overflow = ncell > 64;
+    if (!overflow) {
+        __shared__ int s_pre[4][65], s_p0[4][64];
+        int p0 = 0, len = 0;
+        if (lane < ncell) {
+            const int ix = lo3[0] + lane % ncx, iy = lo3[1] + (lane / ncx) % ncy, iz = lo3[2] + lane / (ncx * ncy);
+            const unsigned cell = morton_cell((unsigned)ix, (unsigned)iy, (unsigned)iz);
+            p0 = gb[cell];
+            len = gb[cell + 1] - p0;
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int T = __shfl(incl, 63);
+        s_pre[wib][lane + 1] = incl;   // exclusive prefix of cell i = s_pre[i]
+        if (lane == 0) s_pre[wib][0] = 0;
+        s_p0[wib][lane] = p0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            const bool in = t < T;
+            // the cell of candidate t: largest i with s_pre[i] <= t (binary search over <= 64 entries)
+            int lo_i = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const int mid = lo_i + step;
+                if (mid < ncell && s_pre[wib][mid] <= t) lo_i = mid;
+            }
+            const int p = in ? s_p0[wib][lo_i] + (t - s_pre[wib][lo_i]) : 0;
+            const float4 qv = pts[p];
+            const bool hit = in && (sn2_d2(qv.x, qv.y, qv.z, cx, cy, cz) < r2);
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const int nh = __popcll(mask);
+                if (h + nh > GQ_LIST) {
+                    overflow = true;
+                    break;
+                }
+                if (hit) list[h + __popcll(mask & below)] = ord[p];
+                h += nh;
+            }
+        }
+    }
+    int* out = nbr + (size_t)ci * cap;
+    if (!overflow) {
+        // rank sort by original index (indices are distinct), keep the first `cap`
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < h; i0 += 64) {
+            const int i = i0 + lane;
+            const int mine = i < h ? list[i] : 0x7FFFFFFF;
+            int rank = 0;
+            for (int j = 0; j < h; ++j) rank += list[j] < mine ? 1 : 0;
+            if (i < h && rank < cap) out[rank] = mine;
+        }
+        const int c = h < cap ? h : cap;
+        if (lane == 0) cnt[ci] = c;
+    } else {
+        // dense ball: full scan of the plot in index order (identical to ball_query_kernel for one centroid)
+        const float* px = src + (size_t)b * 3 * N;
+        const float* py = px + N;
+        const float* pz = py + N;
+        int n = 0;
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < N;
+            const float x = valid ? px[j] : 0.f, y = valid ? py[j] : 0.f, z = valid ? pz[j] : 0.f;
+            const bool hit = valid && (sn2_d2(x, y, z, cx, cy, cz) < r2);
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const int p = n + __popcll(mask & below);
+                if (hit && p < cap) out[p] = j;
+                n += __popcll(mask);
+            }
+        }
+        const int c = n < cap ? n : cap;
+        if (lane == 0) cnt[ci] = c;
+    }
+}
+
+// *total += sum of cnt (one workgroup; thousands of same-address atomics from the query waves cost 0.2 ms)
+__global__ __launch_bounds__(1024) void count_sum_kernel(const int* __restrict__ cnt, int n, unsigned long long* __restrict__ total) {
+    __shared__ float s_part[16];
+    unsigned long long acc = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += (unsigned long long)cnt[i];
+    // counts fit fp32 exactly up to 2^24 per lane partial; reduce in integers through LDS atomics instead
+    __shared__ unsigned long long s_tot;
+    if (threadIdx.x == 0) s_tot = 0ull;
+    __syncthreads();
+    atomicAdd(&s_tot, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) *total += s_tot;
+    (void)s_part;
 }
 
 extern "C" int sn2_ball_query(const float* src_soa, int B, int N, const float* cpos_soa, int M, float r2, int cap,
-                              int* nbr, int* cnt, unsigned long long* total, void* stream) {
-    if (!src_soa || !cpos_soa || !nbr || !cnt || B <= 0 || N <= 0 || M <= 0 || cap <= 0) return SN2_EINVAL;
+                              int* nbr, int* cnt, unsigned long long* total, const int* fps_ws, void* stream) {
+    if (!src_soa || !cpos_soa || !nbr || !cnt || B <= 0 || N <= 0 || M <= 0 || cap <= 0 || !(r2 > 0.f)) return SN2_EINVAL;
+    const float r = sqrtf(r2);   // only used (enlarged) to bound the cell range; the hit test is d2 < r2
+    if (fps_ws && N > 2048 && (((size_t)B * N) % 4 == 0)) {
+        // the sources are the point set FPS just sorted: walk its cell lists instead of the whole plot
+        const int* order = fps_ws;
+        const float4* sorted = reinterpret_cast<const float4*>(fps_ws + (size_t)B * N);
+        const int* grid = fps_ws + (size_t)5 * B * N;
+        hipLaunchKernelGGL(ball_query_grid_kernel, dim3(sn2_cdiv((long)B * M, 4)), dim3(256), 0, (hipStream_t)stream, src_soa,
+                           B, N, cpos_soa, M, r, r2, cap, order, sorted, grid, nbr, cnt, total);
+        if (total) hipLaunchKernelGGL(count_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)cnt, B * M, total);
+        SN2_RETURN_LAUNCH();
+    }
     constexpr int TC = 8;
     const int tiles = sn2_cdiv(M, TC);
     const long waves = (long)B * tiles;
     hipLaunchKernelGGL((ball_query_kernel<TC>), dim3(sn2_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, src_soa, B,
                        N, cpos_soa, M, r2, cap, nbr, cnt, total, tiles);
+    if (total) hipLaunchKernelGGL(count_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)cnt, B * M, total);
     SN2_RETURN_LAUNCH();
 }
 

@@ -118,9 +118,11 @@ def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor) -> torch.Tensor:
     return rows0
 
 
-def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True):
+def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True,
+        return_ws: bool = False):
     """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
-    bucketed=False forces the brute-force kernel (same result; kept for cross-checks)."""
+    bucketed=False forces the brute-force kernel (same result; kept for cross-checks).  return_ws=True also returns
+    the spatial-order workspace (or None), which `ball_query` over the same points can reuse."""
     B, three, N = pos_soa.shape
     _chk(pos_soa, F32, (B, 3, N), "pos_soa")
     if not (1 <= m <= N):
@@ -131,14 +133,16 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
     idx = torch.empty(B, m, dtype=I32, device=dev)
     cs = torch.empty(B, 3, m, dtype=F32, device=dev)
     ca = torch.empty(B * m, 4, dtype=F32, device=dev)
-    order = torch.empty(5 * B * N, dtype=I32, device=dev) if (bucketed and N > 2048) else None
+    order = torch.empty(5 * B * N + 4104 * B, dtype=I32, device=dev) if (bucketed and N > 2048) else None
     _call("sn2_fps", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), _stream(),
           tag=f"N={N}")
+    if return_ws:
+        return idx, cs, ca, order
     return idx, cs, ca
 
 
 def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int = _lib.MAX_NEIGHBORS,
-               total: Optional[torch.Tensor] = None):
+               total: Optional[torch.Tensor] = None, fps_ws: Optional[torch.Tensor] = None):
     """-> nbr (B*M,cap) int32 (first cnt entries valid, ascending source index), cnt (B*M) int32, total (1) int64."""
     B, _, N = src_soa.shape
     M = cpos_soa.shape[2]
@@ -152,8 +156,10 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
         total = torch.zeros(1, dtype=I64, device=dev)
     else:
         _chk(total, I64, (1,), "total")
-    _call("sn2_ball_query", _ptr(src_soa), B, N, _ptr(cpos_soa), M, r2_threshold(r), cap, _ptr(nbr), _ptr(cnt),
-                                     _ptr(total), _stream(), tag=f"N={N}")
+    if fps_ws is not None:
+        _chk(fps_ws, I32, (5 * B * N + 4104 * B,), "fps_ws")
+    _call("sn2_ball_query", _ptr(src_soa), B, N, _ptr(cpos_soa), M, r2_threshold(r), cap, _ptr(nbr), _ptr(cnt), _ptr(total),
+          _ptr(fps_ws), _stream(), tag=f"N={N}")
     return nbr, cnt, total
 
 

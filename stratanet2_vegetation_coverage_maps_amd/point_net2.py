@@ -194,8 +194,8 @@ class PointNet2(nn.Module):
         g = _Saved()
         g.B, g.N, g.M1, g.M2, g.xyz = B, N, M1, M2, xyz
         totals = torch.zeros(2, dtype=I64, device=dev)
-        g.idx1, g.pos1_soa, g.pos1_aos = ops.fps(xyz, M1, fps_start[0])
-        g.nbr1, g.cnt1, g.tot1 = ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, totals[0:1])
+        g.idx1, g.pos1_soa, g.pos1_aos, ws1 = ops.fps(xyz, M1, fps_start[0], return_ws=True)
+        g.nbr1, g.cnt1, g.tot1 = ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, totals[0:1], fps_ws=ws1)
         g.idx2, g.pos2_soa, g.pos2_aos = ops.fps(g.pos1_soa, M2, fps_start[1])
         g.nbr2, g.cnt2, g.tot2 = ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2])
         pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)      # GlobalSAModule: pos = zeros (point_net2.py:40)

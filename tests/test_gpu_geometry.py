@@ -106,6 +106,26 @@ def test_three_nn_matches_oracle(B, S, T, k):
         assert torch.all(w[:, kk:] == 0) and torch.equal(idx[:, kk:], idx[:, :1].expand(-1, 3 - kk))
 
 
+@pytest.mark.parametrize("B,N,M,r,cap", [(2, 32768, 1024, 1.0, 2000), (2, 4096, 512, 2 ** 0.5, 2000), (1, 8192, 64, 4.0, 300),
+                                         (2, 5000, 100, 2.0, 2000)])
+def test_grid_ball_query_equals_full_scan_and_oracle(B, N, M, r, cap):
+    """The cell-list ball query (sources sorted by FPS) returns exactly the lists of the full scan: same members, ascending
+    source index, same cap behaviour (the r = 4 m case overflows the in-LDS list and takes the fallback)."""
+    xyz, _ = _pos(B, N, first=31)
+    dev = xyz.to(DEV)
+    idx, cs, ca, ws = ops.fps(dev, M, None, return_ws=True)
+    assert ws is not None
+    nbr_g, cnt_g, tot_g = ops.ball_query(dev, cs, r, cap, fps_ws=ws)
+    nbr_f, cnt_f, tot_f = ops.ball_query(dev, cs, r, cap)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt_g, cnt_f) and int(tot_g) == int(tot_f)
+    mask = torch.arange(nbr_f.shape[1], device=DEV).unsqueeze(0) < cnt_f.unsqueeze(1)
+    assert torch.equal(nbr_g[mask], nbr_f[mask])
+    if N <= 8192:
+        row, col = _oracle_lists(xyz, cs.cpu(), r, cap)
+        assert torch.equal(nbr_g.cpu()[mask.cpu()].long(), col)
+
+
 def test_pack_rows():
     xyz, cloud = _pos(2, 777)
     rows = ops.pack_rows(cloud.to(DEV), xyz.to(DEV)).cpu().view(2, 777, 12)
