@@ -161,6 +161,19 @@ int sn2_plot_project_backward(const float *dpred, const int *arg, const int *noc
 int sn2_raster_project(const float *coverages, const float *cloud_xy, long plot_stride, int B, int N, int D,
                        int diam_meters, unsigned long long *keys, int *pix, float *rasters, void *stream);
 
+/* Parcel mosaic merge -- the plot-after-plot weighted merge of overlapping plot rasters that predict.py:136-141 obtains
+ * from rasterio.merge with the callback inference/geotiff_raster.py:294-347 (_weighted_average_of_rasters), over per-plot
+ * rasters carrying the radial weight band of add_weights_band_to_rasters (:103-118).  The callback's rule is ORDER
+ * DEPENDENT (its weight band also sums the weights of plots whose score is no-data in a pixel), so the kernel keeps the
+ * order: one thread per (band, parcel pixel) of the window folds plots 0..B-1 in sequence.
+ * rasters (B,3,D,D) as produced by sn2_raster_project (NaN = no data); weights (D,D) (NaN outside the disc);
+ * offsets (B,2) int32 = (row, col) of each plot's top-left pixel in the parcel grid;
+ * mean, wsum (3,H,W): the running mosaic's score bands and weight bands, NaN = no data (caller fills with NaN once);
+ * only parcel pixels in rows [win_y0, win_y0+win_h) x cols [win_x0, win_x0+win_w) are visited (pass the bounding window
+ * of the batch, or 0,0,H,W). */
+int sn2_mosaic_merge(const float *rasters, const float *weights, const int *offsets, int B, int D, int H, int W,
+                     float *mean, float *wsum, int win_y0, int win_x0, int win_h, int win_w, void *stream);
+
 /* ---- optimiser step of the timed training step -- torch.optim.Adam as configured in learning/train.py:180-185
  * (L2 weight decay added to the gradient), on flat buffers; grad_scale multiplies the gradient first (1/world). */
 int sn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int n, float lr, float beta1,

@@ -1,0 +1,52 @@
+"""CPU restatement of the parcel mosaic merge.  TEST INFRASTRUCTURE ONLY.
+
+Follows `/root/reference/inference/geotiff_raster.py`: `add_weights_band_to_rasters` (:103-118) and the pairwise
+`rasterio.merge` callback `_weighted_average_of_rasters` (:294-347), applied plot after plot on the parcel window
+(rasterio itself is absent; the placement rule of `get_geotransform` :46-61 is restated as integer pixel offsets).
+PARITY UNPINNED for the placement (rasterio's resampling is not available to check against); the merge arithmetic is
+restated operation for operation."""
+import numpy as np
+
+
+def weights_band(diam_pix):
+    x = (np.arange(-diam_pix // 2, diam_pix // 2, 1) + 0.5) / diam_pix
+    xx, yy = np.meshgrid(x, x, sparse=True)
+    r = np.sqrt(xx ** 2 + yy ** 2)
+    w = 1.5 - r
+    w[r > 0.5] = np.nan
+    return w
+
+
+def merge_pair(old, new):
+    """One call of the rasterio.merge callback on (2C,h,w) windows: returns the merged (2C,h,w)."""
+    old, new = old.copy(), new.copy()
+    old_nodata, new_nodata = np.isnan(old), np.isnan(new)
+    C = len(old) // 2
+    unw = np.zeros_like(old[:C])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for k in range(C):
+            w = C + k
+            old[k] = old[k] * old[w] * (1 - old_nodata[k])
+            new[k] = new[k] * new[w] * (1 - new_nodata[k])
+            w1 = old[w] * (1 - old_nodata[k])
+            w2 = new[w] * (1 - new_nodata[k])
+            unw[k] = np.nansum(np.concatenate([[w1], [w2]]), axis=0)
+            unw[k][old_nodata[k] & new_nodata[k]] = np.nan
+        old[old_nodata] = np.nan
+        new[new_nodata] = np.nan
+        out = np.nansum([old, new], axis=0)
+        out[old_nodata & new_nodata] = np.nan
+        out[:C] = out[:C] / unw
+    return out
+
+
+def mosaic(rasters, offsets, H, W, diam_pix):
+    """rasters (B,3,D,D) with NaN, offsets (B,2) (row, col) -> (6,H,W) after merging the plots one by one."""
+    w = weights_band(diam_pix)
+    acc = np.full((6, H, W), np.nan)
+    D = diam_pix
+    for r, (oy, ox) in zip(rasters, offsets):
+        img = np.concatenate([r.astype(np.float64)] + [w[None]] * 3, 0)
+        win = acc[:, oy:oy + D, ox:ox + D]
+        acc[:, oy:oy + D, ox:ox + D] = merge_pair(win, img)
+    return acc

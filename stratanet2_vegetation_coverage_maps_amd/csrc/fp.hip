@@ -451,13 +451,14 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_q = smem;                       // [64][QS]  the rows' inputs | 1, shared by the four waves
     float* s_p = s_q + 64 * QS;              // [4][64][16] per-wave d pre-activation of its channel group
-    float* s_du = s_p + 4 * 64 * 16;         // [64][CIP] input gradient, summed over the four channel groups
+    float* s_du = s_p + 4 * 64 * 16;         // [4][64][CIP] per-wave partial input gradient (summed at write-out: LDS
+                                             // float atomics are slow on this chip, plain stores + 4 reads are not)
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long r = (long)blockIdx.x * 64 + lane;
     const bool valid = r < R;
     const size_t rr = valid ? (size_t)r : (size_t)(R - 1);
-    for (int i = threadIdx.x; i < 64 * QS + 4 * 64 * 16 + 64 * CIP; i += 256) smem[i] = 0.f;
+    for (int i = threadIdx.x; i < 64 * QS + 4 * 64 * 16; i += 256) smem[i] = 0.f;
     __syncthreads();
     if (g == 0) {
         float u[CI + 1];
@@ -503,24 +504,28 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
 #pragma unroll
         for (int t = 0; t < COG; ++t)
             if (g * COG + t < CO) a = fmaf(W[(g * COG + t) * CI + k], dp[t], a);
-        atomicAdd(&s_du[lane * CIP + k], a);
+        s_du[(g * 64 + lane) * CIP + k] = a;
     }
     __syncthreads();
+    auto du_sum = [&](int row, int k) {
+        return (s_du[(0 * 64 + row) * CIP + k] + s_du[(1 * 64 + row) * CIP + k]) +
+               (s_du[(2 * 64 + row) * CIP + k] + s_du[(3 * 64 + row) * CIP + k]);
+    };
     const long r0 = (long)blockIdx.x * 64;
     if (du_out) {
         for (int i = threadIdx.x; i < 64 * CA; i += 256) {
             const int row = i / CA, k = i - row * CA;
             if (r0 + row < R) {
                 float* dst = du_out + (size_t)(r0 + row) * du_stride + k;
-                if (KNN) *dst = s_du[row * CIP + k];
-                else *dst += s_du[row * CIP + k];
+                if (KNN) *dst = du_sum(row, k);
+                else *dst += du_sum(row, k);
             }
         }
     }
     if (CB > 0 && dskip) {
         for (int i = threadIdx.x; i < 64 * CB; i += 256) {
             const int row = i / CB, k = i - row * CB;
-            if (r0 + row < R) dskip[(size_t)(r0 + row) * dskip_stride + k] += s_du[row * CIP + CA + k];
+            if (r0 + row < R) dskip[(size_t)(r0 + row) * dskip_stride + k] += du_sum(row, CA + k);
         }
     }
     {
@@ -585,7 +590,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS;
     if (small) {
         using AccS = OuterAcc<16, CI + 1>;
-        constexpr size_t lb = (size_t)(64 * AccS::QS + 4 * 64 * 16 + 64 * (CI | 1)) * 4;
+        constexpr size_t lb = (size_t)(64 * AccS::QS + 4 * 64 * 16 + 4 * 64 * (CI | 1)) * 4;
         auto ks = &fp_bwd_split_kernel<CA, CB, CO, KNN>;
         if (lb > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);

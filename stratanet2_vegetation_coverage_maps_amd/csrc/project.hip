@@ -250,3 +250,53 @@ extern "C" int sn2_raster_project(const float* coverages, const float* cloud_xy,
                        (const unsigned long long*)keys, B, D, rasters);
     SN2_RETURN_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Parcel mosaic: fold the plots of a batch, in order, into the running (mean, weight-sum) rasters with the rule of the
+// rasterio.merge callback (inference/geotiff_raster.py:294-347).  One thread per (band, parcel pixel) of the window; the
+// plot offsets are wave-uniform (scalar loads), the raster reads are contiguous along x.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void mosaic_merge_kernel(const float* __restrict__ rasters, const float* __restrict__ weights,
+                                    const int* __restrict__ offsets, int B, int D, int H, int W,
+                                    float* __restrict__ mean, float* __restrict__ wsum, int y0, int x0, int wh, int ww) {
+    const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int band = blockIdx.z;
+    if (wx >= ww || wy >= wh) return;
+    const int gy = y0 + wy, gx = x0 + wx;
+    if (gy < 0 || gy >= H || gx < 0 || gx >= W) return;
+    const size_t o = ((size_t)band * H + gy) * W + gx;
+    float V = mean[o], Wt = wsum[o];
+    const float nan = __int_as_float(0x7fc00000);
+    for (int b = 0; b < B; ++b) {
+        const int y = gy - offsets[2 * b], x = gx - offsets[2 * b + 1];
+        if (y < 0 || y >= D || x < 0 || x >= D) continue;     // pixel outside this plot's raster: the callback is not
+                                                              // called on it
+        const float v = rasters[(((size_t)b * 3 + band) * D + y) * D + x];
+        const float w = weights[y * D + x];
+        const bool on = V != V, nn = v != v, own = Wt != Wt, nwn = w != w;
+        if (on && nn) {
+            V = nan;
+        } else {
+            float a_old = V * Wt, a_new = v * w;               // NaN (no data) contributes nothing: np.nansum
+            a_old = (on || a_old != a_old) ? 0.f : a_old;
+            a_new = (nn || a_new != a_new) ? 0.f : a_new;
+            const float w_old = (on || own) ? 0.f : Wt, w_new = (nn || nwn) ? 0.f : w;
+            V = (a_old + a_new) / (w_old + w_new);
+        }
+        Wt = (own && nwn) ? nan : (own ? 0.f : Wt) + (nwn ? 0.f : w);
+    }
+    mean[o] = V;
+    wsum[o] = Wt;
+}
+}  // namespace
+
+extern "C" int sn2_mosaic_merge(const float* rasters, const float* weights, const int* offsets, int B, int D, int H, int W,
+                                float* mean, float* wsum, int win_y0, int win_x0, int win_h, int win_w, void* stream) {
+    if (!rasters || !weights || !offsets || !mean || !wsum || B <= 0 || D <= 0 || H <= 0 || W <= 0) return SN2_EINVAL;
+    if (win_h <= 0 || win_w <= 0) return 0;
+    hipLaunchKernelGGL(mosaic_merge_kernel, dim3(sn2_cdiv(win_w, 64), sn2_cdiv(win_h, 4), 3), dim3(256), 0,
+                       (hipStream_t)stream, rasters, weights, offsets, B, D, H, W, mean, wsum, win_y0, win_x0, win_h, win_w);
+    SN2_RETURN_LAUNCH();
+}

@@ -424,6 +424,20 @@ def raster_project(coverages: torch.Tensor, clouds_dev: torch.Tensor, diam_pix: 
     return rasters, pix
 
 
+def mosaic_merge(rasters, weights, offsets, mean, wsum, window=None):
+    """Fold plots 0..B-1 (in order) into the running mosaic (mean, wsum) (3,H,W), NaN = no data."""
+    B, _, D, _ = rasters.shape
+    _, H, W = mean.shape
+    _chk(rasters, F32, (B, 3, D, D), "rasters")
+    _chk(weights, F32, (D, D), "weights")
+    _chk(offsets, I32, (B, 2), "offsets")
+    _chk(mean, F32, (3, H, W), "mean")
+    _chk(wsum, F32, (3, H, W), "wsum")
+    y0, x0, wh, ww = (0, 0, H, W) if window is None else [int(v) for v in window]
+    _call("sn2_mosaic_merge", _ptr(rasters), _ptr(weights), _ptr(offsets), B, D, H, W, _ptr(mean), _ptr(wsum),
+          y0, x0, wh, ww, _stream())
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):
     """step_dev: int32 device tensor (1,) holding the number of steps taken so far; incremented by the call."""
     n = param.numel()
