@@ -1,0 +1,78 @@
+"""BASELINE config 4 (SURVEY.md 8d "C4"): parcel inference, 2048 overlapping 10 m plots x N=10000 points, B=64 per
+launch, eval-mode forward + fixed-grid max rasters + ordered weighted mosaic merge, 1 x MI355X.  Inputs resident in HBM
+when the timed region starts; GeoTIFF/shapefile I/O is out of scope.
+
+    python scripts/bench_inference.py [--plots 2048] [--batch 64] [--points 10000] [--repeat 3]
+prints one JSON line (plots/s over the whole parcel, per-entry-point time table).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, hip_ops as ops, inference  # noqa: E402
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--plots", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--points", type=int, default=10000)
+    ap.add_argument("--repeat", type=int, default=3)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    args = make_args(cuda=0, subsample_size=a.points)           # reference defaults: ratios .25/.25, r sqrt2/sqrt8
+    torch.manual_seed(0)
+    model = PointNet2(args).eval()
+    cols = 64
+    rows = (a.plots + cols - 1) // cols
+    stride = 5.0                                                # plot centres every 5 m: each pixel sees ~12 plots
+    t0 = time.time()
+    batches = []
+    for s in range(0, a.plots, a.batch):
+        nb = min(a.batch, a.plots - s)
+        d = make_batch(nb, a.points, first_plot=s)
+        k = torch.arange(s, s + nb)
+        c = torch.stack([10.0 + stride * (k % cols), 10.0 + stride * (k // cols)], 1).double()
+        batches.append({"cloud": d["cloud"].to(dev), "xyz": d["xyz"].to(dev), "plot_center": c,
+                        "fps_start": torch.zeros(2, nb, dtype=torch.int64)})
+        if (s // a.batch) % 8 == 0:
+            print(f"[bench_inference] generated {s + nb}/{a.plots} plots ({time.time() - t0:.0f}s)", file=sys.stderr,
+                  flush=True)
+    H, W = int(20 + stride * (rows - 1)), int(20 + stride * (cols - 1))
+
+    def run():
+        mos = inference.ParcelMosaic(0.0, float(H), H, W, args, dev)
+        n = inference.predict_parcel(model, batches, mos, args)
+        return mos, n
+
+    run()                                                        # warm-up (allocator, lazy module load)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(a.repeat):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        mos, n = run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    with ops.timing() as tm:
+        run()
+    table = {k: {"calls": c, "ms_per_batch": round(ms / len(batches), 4)} for k, (c, ms) in sorted(
+        tm.summary().items(), key=lambda kv: -kv[1][1])}
+    res = mos.result()
+    cover = float((~torch.isnan(res[0])).float().mean())
+    print(json.dumps({"metric": "plots/s parcel inference (fwd + rasters + mosaic merge)", "value": round(n / best, 1),
+                      "unit": "plots/s", "n_gpus": 1, "seconds_per_parcel": round(best, 4),
+                      "config": {"workload": f"C4: {a.plots} plots x N={a.points}, B={a.batch}, ref-arch defaults",
+                                 "parcel_pix": [H, W], "covered_frac": round(cover, 3)},
+                      "dtype": "f32", "data": "synthetic", "kernels": table}))
+
+
+if __name__ == "__main__":
+    main()
