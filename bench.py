@@ -140,8 +140,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
-    ap.add_argument("--no-pipeline", action="store_true", help="skip the extra geometry-prefetch measurement")
+    ap.add_argument("--eager", action="store_true", help="do not capture the feature passes into hipGraphs")
+    ap.add_argument("--serial", action="store_true",
+                    help="headline = the unpipelined step (geometry and features of a batch back to back on one stream)")
+    ap.add_argument("--depth", type=int, default=2, help="geometry passes kept in flight ahead of the feature pass")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,68 +163,109 @@ def main():
     model = PointNet2(args).train()
     flatten_parameters(model)
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
-    host = make_batch(B, N_POINTS, first_plot=shard_of_rank(rank, B)[0])       # this rank's shard of the plot batch
-    data = {"cloud": host["cloud"].to(dev), "xyz": host["xyz"].to(dev),
-            "fps_start": torch.zeros(2, B, dtype=torch.int32, device=dev)}
-    gt, pdf = host["coverages"].to(dev), host["pdf_all"].to(dev)
+    # depth+1 resident batches (the pipeline's slots); batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
+    n_slots = 1 if a.serial else a.depth + 1
+    slots = []
+    for j in range(n_slots):
+        host = make_batch(B, N_POINTS, first_plot=j * world * B + shard_of_rank(rank, B)[0])
+        slots.append({"cloud": host["cloud"].to(dev), "xyz": host["xyz"].to(dev),
+                      "fps_start": torch.zeros(2, B, dtype=torch.int32, device=dev),
+                      "gt": host["coverages"].to(dev), "pdf": host["pdf_all"].to(dev)})
+    data = slots[0]
 
-    def step():
+    def feature_step(inp, geo=None):
+        """zero_grad -> forward -> plot-wise projection -> loss -> backward (everything but exchange + Adam)"""
         opt.zero_grad(set_to_none=True)
-        cov, proba = model(data)
-        pred = project_to_plotwise_coverages(cov, data["cloud"], args)
-        loss, _ = losses.total_loss(pred, proba, gt, pdf, args.m, args.e)
+        cd = {"cloud": inp["cloud"], "xyz": inp["xyz"], "fps_start": inp["fps_start"]}
+        if geo is not None:
+            cd["geometry"] = geo
+        cov, proba = model(cd)
+        pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
+        loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
         loss.backward()
-        opt.step()
         return loss
 
-    # ---- warm-up; the first warm-up step is instrumented to find the dominant entry point
-    log("inputs resident; first (instrumented) step")
-    with ops.timing() as t0:
-        step()
-    prof = t0.summary()
-    log("first step done: " + ", ".join(f"{k} {v[1]:.3f} ms" for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:6]))
-    dominant = max(prof, key=lambda k: prof[k][1]) if prof else None
-    for _ in range(max(0, a.warmup - 1)):
-        step()
+    def step():
+        """the unpipelined step on slot 0: geometry, features, exchange, Adam back to back on the current stream"""
+        loss = feature_step(data)
+        opt.step()
+        return loss
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # ---- the step is ~100 short kernels with no host synchronisation: capture it once into a hipGraph and replay it
-    # (the single-GPU step is launch-bound otherwise: ~1 ms of host gaps per 6.6 ms step).  Every replay does the full
-    # work of a step on the resident inputs: FPS, ball query, forward, projection, loss, backward, Adam.
-    launch = "eager"
+    # ---- first step instrumented per entry point: finds the dominant one
+    log("inputs resident; first (instrumented) step")
+    with ops.timing() as t0:
+        step()
+    prof = t0.summary()
+    log("first step done: " + ", ".join(f"{k} {v[1]:.3f} ms" for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:6]))
+    dominant = max(prof, key=lambda k: prof[k][1]) if prof else None
+
+    def capture_serial():
+        """the whole unpipelined step as ONE hipGraph (single GPU only: no collective inside a graph)"""
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()                                   # allocator warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            l = step()
+        g.replay()
+        torch.cuda.synchronize()
+        return g, l
+
+    pipe = None
     graph, loss_static = None, None
-    if not a.eager and world == 1:
+    if a.serial:
+        launch = "eager"
+        for _ in range(max(0, a.warmup - 1)):
+            step()
+        if not a.eager and world == 1:
+            try:
+                graph, loss_static = capture_serial()
+                launch = "hipGraph"
+            except Exception as exc:                 # noqa: BLE001 - fall back loudly, never silently change the work
+                log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eager")
+                graph = None
+                torch.cuda.synchronize()
+        mode = f"serial/{launch}"
+    else:
+        # ---- software pipeline (stratanet2_vegetation_coverage_maps_amd/pipeline.py): geometry of batches i+1..i+depth on
+        # side streams while batch i's feature pass (one hipGraph per slot) runs; the all-reduce stays an eager RCCL call
+        from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
+        pipe = TrainPipeline(model, opt, feature_step, slots, depth=a.depth, use_graph=not a.eager)
         try:
+            pipe.capture()
+            launch = "eager" if a.eager else "hipGraph"
+        except Exception as exc:                     # noqa: BLE001
+            log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); pipeline runs eager")
             torch.cuda.synchronize()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()                                   # allocator warm-up on the capture stream
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss_static = step()
-            graph.replay()
-            torch.cuda.synchronize()
-            launch = "hipGraph"
-        except Exception as exc:                         # noqa: BLE001 - fall back loudly, never silently change the work
-            log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eager")
-            graph = None
-            torch.cuda.synchronize()
-    log(f"launch mode: {launch}")
+            pipe = TrainPipeline(model, opt, feature_step, slots, depth=a.depth, use_graph=False)
+            pipe.capture()
+            launch = "eager"
+        pipe.prime()
+        for _ in range(a.warmup):
+            pipe.step()
+        mode = f"pipelined depth {a.depth}/{launch}"
+    log(f"mode: {mode}")
 
     barrier()
     t_start = time.perf_counter()
-    if graph is not None:
+    tdom = None
+    if pipe is not None:
+        for _ in range(a.steps):
+            loss = pipe.step()
+        pipe.drain()
+    elif graph is not None:
         for _ in range(a.steps):
             graph.replay()
         loss = loss_static
-        tdom = None
     else:
         with ops.timing({dominant}) as tdom:   # 2 event records per step on the dominant entry point only
             for _ in range(a.steps):
@@ -235,43 +278,35 @@ def main():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el.item())
     log(f"timed region: {elapsed / a.steps * 1e3:.3f} ms/step")
+    loss_value = float(loss.item())
     if tdom is None:
-        # graph replays cannot carry event records: time the dominant entry point over 5 eager steps right after
+        # graph replays / side streams cannot carry the event records: time the dominant entry point over 5 unpipelined
+        # eager steps right after the timed region
         with ops.timing({dominant}) as tdom:
             for _ in range(5):
                 step()
     dom = tdom.summary()
 
-    # ---- extra measurement (NOT `value`): the position-only kernels of step k+1 (FPS, ball query, 3-NN: no weights
-    # involved) run on a side stream while step k's feature kernels run; every step still executes one full geometry
-    # pass and one full feature pass, K+1 geometry passes for K steps.
-    pipelined_ms = None
-    if not a.no_pipeline and world == 1:
-        def step_p(geo):
-            nxt = model.prefetch_geometry(data)
-            opt.zero_grad(set_to_none=True)
-            cov, proba = model({"cloud": data["cloud"], "xyz": data["xyz"], "geometry": geo})
-            pred = project_to_plotwise_coverages(cov, data["cloud"], args)
-            l, _ = losses.total_loss(pred, proba, gt, pdf, args.m, args.e)
-            l.backward()
-            opt.step()
-            return nxt
-        geo = model.prefetch_geometry(data)
-        for _ in range(3):
-            geo = step_p(geo)
-        torch.cuda.synchronize()
-        t0p = time.perf_counter()
-        for _ in range(a.steps):
-            geo = step_p(geo)
-        torch.cuda.synchronize()
-        pipelined_ms = (time.perf_counter() - t0p) / a.steps * 1e3
-        log(f"geometry-prefetch pipeline (eager, 2 streams): {pipelined_ms:.3f} ms/step")
+    # ---- secondary figure (NOT `value`): the unpipelined step as one hipGraph, the latency of a single batch
+    serial_ms = None
+    if pipe is not None and world == 1 and not a.eager:
+        try:
+            g1, _ = capture_serial()
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            for _ in range(a.steps):
+                g1.replay()
+            torch.cuda.synchronize()
+            serial_ms = (time.perf_counter() - t0s) / a.steps * 1e3
+            log(f"unpipelined step (one hipGraph): {serial_ms:.3f} ms/step")
+        except Exception as exc:                     # noqa: BLE001
+            log(f"serial capture failed ({type(exc).__name__}: {exc})")
+            torch.cuda.synchronize()
 
     # ---- one fully instrumented step for the per-entry-point table (after the timed region)
     with ops.timing() as tall:
         step()
     table = tall.summary()
-    s = model  # sizes for the byte model
     e1 = e2 = 0
     with torch.no_grad():
         _, _, saved = model._forward_impl(data["xyz"], data["cloud"], data["fps_start"], False)
@@ -295,8 +330,8 @@ def main():
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None if ach is None else round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6),
                     "traffic": traffic, "traffic_source": tsrc, "avg_ms": round(avg_ms, 4), "algorithmic_bytes": by,
-                    "timing": ("HIP events inside the timed region" if launch == "eager" else
-                               "HIP events over 5 eager steps right after the hipGraph-replayed timed region"),
+                    "timing": ("HIP events inside the timed region" if mode == "serial/eager" else
+                               "HIP events over 5 unpipelined eager steps right after the timed region"),
                     "note": ("fps is latency/VALU-bound by construction (M strictly sequential argmax rounds, one "
                              "workgroup per plot); its HBM traffic is 12 B/point once" if dominant.startswith("sn2_fps")
                              else "")}
@@ -305,13 +340,16 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "C2 ref-arch: 16 plots/GPU x 32768 pts, SA npoint 1024/256 + global, r 1/2 m, "
                                       "train step fwd+P2+loss+bwd+Adam, inputs resident in HBM",
-                          "launch": launch, "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
+                          "mode": mode + ("" if a.serial else
+                                          ": every step runs one geometry pass (FPS, ball query, 3-NN of a later batch, side "
+                                          "streams) and one feature pass (this batch); distinct batches in the slots"),
+                          "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
-               "loss": round(float(loss.item()), 6), "roofline": roof, "kernels": kernels}
-        if pipelined_ms is not None:
-            out["pipelined"] = {"ms_per_step": round(pipelined_ms, 4), "plots_per_s": round(B / (pipelined_ms * 1e-3), 2),
-                                "what": "same step, position-only kernels of step k+1 prefetched on a side stream during "
-                                        "step k (PointNet2.prefetch_geometry); eager launch; not the headline value"}
+               "loss": round(loss_value, 6), "roofline": roof, "kernels": kernels}
+        if serial_ms is not None:
+            out["unpipelined"] = {"ms_per_step": round(serial_ms, 4), "plots_per_s": round(B / (serial_ms * 1e-3), 2),
+                                  "what": "the same step with geometry and features of ONE batch back to back on one "
+                                          "stream, captured as one hipGraph (single-batch latency; not the headline value)"}
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()

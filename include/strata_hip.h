@@ -68,7 +68,7 @@ int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *id
 /* radius ball query -- torch_cluster.radius, model/point_net2.py:23-25.
  * For centroid i of plot b: all source points j of plot b with d2 < r2 (strict, canonical fp32 arithmetic; r2 = the
  * fp32 value of r*r evaluated in double, as torch_cluster compares),
- * ascending j, at most `cap` of them: nbr[(b*M+i)*cap + 0..cnt-1], cnt[b*M+i]. *total += sum of cnt.
+ * ascending j, at most `cap` of them: nbr[(b*M+i)*cap + 0..cnt-1], cnt[b*M+i]. *total = sum of cnt (overwritten).
  * fps_ws: the workspace a bucketed sn2_fps call over the SAME sources left behind (cell lists: ~200 candidates per
  * centroid instead of N), or NULL for the full scan; same result either way. */
 int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, int M, float r2, int cap,

@@ -662,19 +662,16 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
     }
 }
 
-// *total += sum of cnt (one workgroup; thousands of same-address atomics from the query waves cost 0.2 ms)
+// *total = sum of cnt (one workgroup; thousands of same-address atomics from the query waves cost 0.2 ms)
 __global__ __launch_bounds__(1024) void count_sum_kernel(const int* __restrict__ cnt, int n, unsigned long long* __restrict__ total) {
-    __shared__ float s_part[16];
+    __shared__ unsigned long long s_tot;
     unsigned long long acc = 0;
     for (int i = threadIdx.x; i < n; i += 1024) acc += (unsigned long long)cnt[i];
-    // counts fit fp32 exactly up to 2^24 per lane partial; reduce in integers through LDS atomics instead
-    __shared__ unsigned long long s_tot;
     if (threadIdx.x == 0) s_tot = 0ull;
     __syncthreads();
     atomicAdd(&s_tot, acc);
     __syncthreads();
-    if (threadIdx.x == 0) *total += s_tot;
-    (void)s_part;
+    if (threadIdx.x == 0) *total = s_tot;
 }
 
 extern "C" int sn2_ball_query(const float* src_soa, int B, int N, const float* cpos_soa, int M, float r2, int cap,

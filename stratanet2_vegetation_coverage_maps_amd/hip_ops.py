@@ -118,11 +118,17 @@ def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor) -> torch.Tensor:
     return rows0
 
 
+def fps_ws_words(B: int, N: int) -> int:
+    """SN2_FPS_WS_WORDS of include/strata_hip.h."""
+    return 5 * B * N + 4104 * B
+
+
 def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True,
-        return_ws: bool = False):
+        return_ws: bool = False, out=None):
     """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
     bucketed=False forces the brute-force kernel (same result; kept for cross-checks).  return_ws=True also returns
-    the spatial-order workspace (or None), which `ball_query` over the same points can reuse."""
+    the spatial-order workspace (or None), which `ball_query` over the same points can reuse.
+    out = (idx, cpos_soa, cpos_aos, workspace-or-None): caller-owned result buffers (persistent pipelines)."""
     B, three, N = pos_soa.shape
     _chk(pos_soa, F32, (B, 3, N), "pos_soa")
     if not (1 <= m <= N):
@@ -130,10 +136,18 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
     if start is not None:
         _chk(start, I32, (B,), "start")
     dev = pos_soa.device
-    idx = torch.empty(B, m, dtype=I32, device=dev)
-    cs = torch.empty(B, 3, m, dtype=F32, device=dev)
-    ca = torch.empty(B * m, 4, dtype=F32, device=dev)
-    order = torch.empty(5 * B * N + 4104 * B, dtype=I32, device=dev) if (bucketed and N > 2048) else None
+    if out is not None:
+        idx, cs, ca, order = out
+        _chk(idx, I32, (B, m), "out idx")
+        _chk(cs, F32, (B, 3, m), "out cpos_soa")
+        _chk(ca, F32, (B * m, 4), "out cpos_aos")
+        if order is not None:
+            _chk(order, I32, (fps_ws_words(B, N),), "out workspace")
+    else:
+        idx = torch.empty(B, m, dtype=I32, device=dev)
+        cs = torch.empty(B, 3, m, dtype=F32, device=dev)
+        ca = torch.empty(B * m, 4, dtype=F32, device=dev)
+        order = torch.empty(fps_ws_words(B, N), dtype=I32, device=dev) if (bucketed and N > 2048) else None
     _call("sn2_fps", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), _stream(),
           tag=f"N={N}")
     if return_ws:
@@ -142,16 +156,22 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
 
 
 def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int = _lib.MAX_NEIGHBORS,
-               total: Optional[torch.Tensor] = None, fps_ws: Optional[torch.Tensor] = None):
-    """-> nbr (B*M,cap) int32 (first cnt entries valid, ascending source index), cnt (B*M) int32, total (1) int64."""
+               total: Optional[torch.Tensor] = None, fps_ws: Optional[torch.Tensor] = None, out=None):
+    """-> nbr (B*M,cap) int32 (first cnt entries valid, ascending source index), cnt (B*M) int32, total (1) int64.
+    out = (nbr, cnt): caller-owned result buffers."""
     B, _, N = src_soa.shape
     M = cpos_soa.shape[2]
     _chk(src_soa, F32, (B, 3, N), "src_soa")
     _chk(cpos_soa, F32, (B, 3, M), "cpos_soa")
     cap = min(cap, N)
     dev = src_soa.device
-    nbr = torch.empty(B * M, cap, dtype=I32, device=dev)
-    cnt = torch.empty(B * M, dtype=I32, device=dev)
+    if out is not None:
+        nbr, cnt = out
+        _chk(nbr, I32, (B * M, cap), "out nbr")
+        _chk(cnt, I32, (B * M,), "out cnt")
+    else:
+        nbr = torch.empty(B * M, cap, dtype=I32, device=dev)
+        cnt = torch.empty(B * M, dtype=I32, device=dev)
     if total is None:
         total = torch.zeros(1, dtype=I64, device=dev)
     else:
@@ -163,15 +183,21 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
     return nbr, cnt, total
 
 
-def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int):
-    """-> idx (B*T,3) int32 local source indices, w (B*T,3) = 1/max(d2,1e-16) (0 on unused slots)."""
+def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int, out=None):
+    """-> idx (B*T,3) int32 local source indices, w (B*T,3) = 1/max(d2,1e-16) (0 on unused slots).
+    out = (idx, w): caller-owned result buffers."""
     B, _, S = src_soa.shape
     T = dst_soa.shape[2]
     _chk(src_soa, F32, (B, 3, S), "src_soa")
     _chk(dst_soa, F32, (B, 3, T), "dst_soa")
     dev = src_soa.device
-    idx = torch.empty(B * T, 3, dtype=I32, device=dev)
-    w = torch.empty(B * T, 3, dtype=F32, device=dev)
+    if out is not None:
+        idx, w = out
+        _chk(idx, I32, (B * T, 3), "out idx")
+        _chk(w, F32, (B * T, 3), "out w")
+    else:
+        idx = torch.empty(B * T, 3, dtype=I32, device=dev)
+        w = torch.empty(B * T, 3, dtype=F32, device=dev)
     _call("sn2_three_nn", _ptr(src_soa), B, S, _ptr(dst_soa), T, k, _ptr(idx), _ptr(w), _stream(), tag=f"T={T}")
     return idx, w
 

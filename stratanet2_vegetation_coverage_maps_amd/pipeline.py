@@ -1,0 +1,143 @@
+"""Software-pipelined training step: position-only kernels of later batches overlap the feature kernels of this one.
+
+The reference runs, per batch and in this order (`model/point_net2.py:21-29,62-67` under `learning/train.py:52-66`):
+fps -> radius -> PointConv ... knn_interpolate ... -> loss -> backward -> Adam.  `fps`, `radius` and `knn` read point
+POSITIONS only -- no weights, no features -- so for batch i+1, i+2 they can run while batch i is still in its
+forward/backward.  That matters on MI355X because FPS is M strictly sequential rounds in ONE workgroup per plot: with
+16 plots per GPU it keeps 16 of 256 CUs busy for ~2 ms while the feature kernels (which fill the chip) need ~2 ms too.
+
+Layout: `slots` = depth+1 sets of persistent buffers (inputs + `PointNet2.alloc_geometry`), `depth` side streams.
+
+    side[j]  : geometry(batch i+depth) -> slot (i+depth) % slots          launched eagerly (about 10 kernels)
+    main     : wait geo_ready[slot i] ; features(batch i) = zero_grad, forward, projection, loss, backward
+               [; all-reduce of the flat gradient when world > 1] ; Adam ; record slot_done[slot i]
+
+The feature pass of each slot is captured once into a hipGraph (static addresses: the slot's buffers) and replayed; the
+all-reduce stays an ordinary eager RCCL call between the backward graph and the Adam graph.  Every step executes exactly
+one geometry pass and one feature pass; results are identical to the unpipelined step (tests/test_gpu_pipeline.py).
+"""
+import torch
+
+from . import hip_ops as ops
+from .optim import allreduce_flat_grad
+
+
+class TrainPipeline:
+    def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True):
+        """model: PointNet2 (train mode); opt: FlatAdam; slot_inputs: list of depth+1 dicts with device tensors "cloud"
+        (B,10,N), "xyz" (B,3,N), "fps_start" (2,B) int32 + whatever `feature_step` needs;
+        feature_step(inputs, geometry) -> loss: zero_grad, forward (with cloud_data["geometry"] = geometry),
+        projection, loss, backward -- everything of the step except the gradient exchange and the optimiser."""
+        if len(slot_inputs) != depth + 1:
+            raise ValueError("need depth+1 input slots")
+        self.model, self.opt, self.feature_step = model, opt, feature_step
+        self.inputs = slot_inputs
+        self.depth, self.slots = depth, depth + 1
+        dev = slot_inputs[0]["xyz"].device
+        self.dev = dev
+        B, _, N = slot_inputs[0]["xyz"].shape
+        self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.geo_ready = [torch.cuda.Event() for _ in range(self.slots)]
+        self.slot_done = [None] * self.slots
+        self.graph_fb = [None] * self.slots       # zero_grad .. backward
+        self.graph_opt = [None] * self.slots      # Adam on that slot's flat gradient
+        self.flat_grad = [None] * self.slots
+        self.loss = [None] * self.slots
+        self.issued = 0                           # geometry passes launched so far
+        self.done = 0                             # feature passes launched so far
+        self.use_graph = use_graph
+
+    # ---- geometry of batch number i (its inputs must already be in slot i % slots)
+    def issue_geometry(self, i=None):
+        i = self.issued if i is None else i
+        k = i % self.slots
+        st = self.side[i % self.depth]
+        if self.slot_done[k] is not None:
+            st.wait_event(self.slot_done[k])      # the feature pass that last read this slot's tables has finished
+        else:
+            st.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(st):
+            d = self.inputs[k]
+            self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k])
+            self.geo_ready[k].record(st)
+        self.issued = max(self.issued, i + 1)
+
+    def _exchange_and_update(self, k):
+        g = self.flat_grad[k]
+        self.model._last_flat_grad = g
+        self.opt.step()                           # all-reduce (world > 1) + Adam kernel
+
+    def capture(self):
+        """Warm every slot eagerly (allocator, lazy loads), then capture each slot's feature pass.  Geometry of all
+        slots must be valid while warming: computed here, and left valid for steps 0..slots-1."""
+        main = torch.cuda.current_stream(self.dev)
+        for i in range(self.slots):
+            self.issue_geometry(i)
+        self.issued = 0
+        for st in self.side:
+            main.wait_stream(st)
+        torch.cuda.synchronize(self.dev)
+        if not self.use_graph:
+            return
+        cap = torch.cuda.Stream(device=self.dev)
+        cap.wait_stream(main)
+        with torch.cuda.stream(cap):
+            for k in range(self.slots):           # warm-up on the capture stream
+                self.feature_step(self.inputs[k], self.geo[k])
+        main.wait_stream(cap)
+        torch.cuda.synchronize(self.dev)
+        pool = torch.cuda.graph_pool_handle()
+        world = getattr(self.opt, "world_size", 1)
+        for k in range(self.slots):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self.loss[k] = self.feature_step(self.inputs[k], self.geo[k])
+                self.flat_grad[k] = self.model._last_flat_grad
+                if world == 1:
+                    self._exchange_and_update(k)  # no exchange: Adam rides in the same graph
+            self.graph_fb[k] = g
+            if world > 1:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=pool):
+                    ops.adam_step(self.opt.flat, self.flat_grad[k], self.opt.exp_avg, self.opt.exp_avg_sq, self.opt.lr,
+                                  self.opt.betas[0], self.opt.betas[1], self.opt.eps, self.opt.weight_decay,
+                                  self.opt.step_dev, 1.0 / world)
+                self.graph_opt[k] = g2
+        torch.cuda.synchronize(self.dev)
+
+    def prime(self):
+        """Launch the geometry of the first `depth` batches (before the first step)."""
+        while self.issued < self.done + self.depth:
+            self.issue_geometry()
+
+    def step(self):
+        """One training step on batch number `done` (slot done % slots); keeps `depth` geometry passes in flight."""
+        i = self.done
+        k = i % self.slots
+        main = torch.cuda.current_stream(self.dev)
+        if self.issued <= i:
+            self.issue_geometry(i)
+        main.wait_event(self.geo_ready[k])
+        if self.graph_fb[k] is not None:
+            self.graph_fb[k].replay()
+            if self.graph_opt[k] is not None:
+                allreduce_flat_grad(self.flat_grad[k], self.opt.world_size, self.opt.process_group)
+                self.graph_opt[k].replay()
+            loss = self.loss[k]
+        else:
+            loss = self.feature_step(self.inputs[k], self.geo[k])
+            self.flat_grad[k] = self.model._last_flat_grad
+            self._exchange_and_update(k)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.slot_done[k] = ev
+        self.done = i + 1
+        # the slot of batch i+depth was last read by batch i-1 (slots = depth+1): its tables are free now
+        if self.issued < self.done + self.depth:
+            self.issue_geometry(self.issued)
+        return loss
+
+    def drain(self):
+        for st in self.side:
+            torch.cuda.current_stream(self.dev).wait_stream(st)

@@ -162,13 +162,15 @@ class PointNet2(nn.Module):
             cloud_d = cloud.to(device=dev, dtype=F32, non_blocking=True).contiguous()
             geo = cloud_data.get("geometry", None) if isinstance(cloud_data, dict) else None
             if geo is not None:
-                # position-only kernels already ran (or are running) on the side stream: wait for them here
-                cs = torch.cuda.current_stream()
-                cs.wait_event(geo.ready)
-                for v in geo.__dict__.values():          # allocated on the side stream, consumed on this one
-                    for t in (v if isinstance(v, tuple) else (v,)):
-                        if isinstance(t, torch.Tensor):
-                            t.record_stream(cs)
+                if getattr(geo, "ready", None) is not None:
+                    # position-only kernels already ran (or are running) on the side stream: wait for them here
+                    cs = torch.cuda.current_stream()
+                    cs.wait_event(geo.ready)
+                    for v in geo.__dict__.values():          # allocated on the side stream, consumed on this one
+                        for t in (v if isinstance(v, tuple) else (v,)):
+                            if isinstance(t, torch.Tensor):
+                                t.record_stream(cs)
+                # ready is None: persistent buffers (alloc_geometry); the caller orders the streams itself
                 xyz_d, fs = geo.xyz, None
             else:
                 xyz_d, fs = self._stage_positions(cloud_data, dev)
@@ -183,21 +185,60 @@ class PointNet2(nn.Module):
         return M1, M2
 
     # ------------------------------------------------------------------------------------------ geometry
-    def _geometry(self, xyz, fps_start):
+    def alloc_geometry(self, B, N, device=None):
+        """Persistent result buffers for `_geometry(..., out=)`: what a software-pipelined training loop hands to the
+        position-only kernels of the batches in flight (pipeline.TrainPipeline)."""
+        dev = torch.device(device if device is not None else self.lin1.weight.device)
+        M1, M2 = self._sizes(N)
+        e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
+        g = _Saved()
+        g.B, g.N, g.M1, g.M2 = B, N, M1, M2
+        g.idx1, g.pos1_soa, g.pos1_aos = e(B, M1, dt=I32), e(B, 3, M1), e(B * M1, 4)
+        g.ws1 = e(ops.fps_ws_words(B, N), dt=I32) if N > 2048 else None
+        g.nbr1, g.cnt1 = e(B * M1, min(MAX_NEIGHBORS, N), dt=I32), e(B * M1, dt=I32)
+        g.idx2, g.pos2_soa, g.pos2_aos = e(B, M2, dt=I32), e(B, 3, M2), e(B * M2, 4)
+        g.ws2 = e(ops.fps_ws_words(B, M1), dt=I32) if M1 > 2048 else None
+        g.nbr2, g.cnt2 = e(B * M2, min(MAX_NEIGHBORS, M1), dt=I32), e(B * M2, dt=I32)
+        g.totals = torch.zeros(2, dtype=I64, device=dev)
+        g.pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)
+        g.knn3 = (e(B * M2, 3, dt=I32), e(B * M2, 3))
+        g.knn2 = (e(B * M1, 3, dt=I32), e(B * M1, 3))
+        g.knn1 = (e(B * N, 3, dt=I32), e(B * N, 3))
+        g.tot1, g.tot2 = g.totals[0:1], g.totals[1:2]
+        g.ready = None
+        return g
+
+    def _geometry(self, xyz, fps_start, out=None):
         """Everything that depends on the point POSITIONS only (no weights, no features): both FPS levels, both ball
         queries, the three 3-NN tables.  In the reference these are the torch_cluster calls inside SAModule / FPModule
         (point_net2.py:22-25, 63).  Because they need no parameters they can run ahead of the feature kernels: see
-        `prefetch_geometry`."""
+        `prefetch_geometry`.  `out`: buffers from `alloc_geometry` to write into (no allocation, same addresses every
+        time: what a hipGraph-replayed feature pass needs)."""
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
+        if out is not None:
+            g = out
+            if (g.B, g.N, g.M1, g.M2) != (B, N, M1, M2):
+                raise ValueError("geometry buffers do not match this batch")
+            g.xyz = xyz
+            ops.fps(xyz, M1, fps_start[0], out=(g.idx1, g.pos1_soa, g.pos1_aos, g.ws1))
+            ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
+            ops.fps(g.pos1_soa, M2, fps_start[1], out=(g.idx2, g.pos2_soa, g.pos2_aos, g.ws2))
+            ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, g.tot2, fps_ws=g.ws2,
+                           out=(g.nbr2, g.cnt2))
+            ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
+            ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2)
+            ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1)
+            return g
         g = _Saved()
         g.B, g.N, g.M1, g.M2, g.xyz = B, N, M1, M2, xyz
         totals = torch.zeros(2, dtype=I64, device=dev)
         g.idx1, g.pos1_soa, g.pos1_aos, ws1 = ops.fps(xyz, M1, fps_start[0], return_ws=True)
         g.nbr1, g.cnt1, g.tot1 = ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, totals[0:1], fps_ws=ws1)
-        g.idx2, g.pos2_soa, g.pos2_aos = ops.fps(g.pos1_soa, M2, fps_start[1])
-        g.nbr2, g.cnt2, g.tot2 = ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2])
+        g.idx2, g.pos2_soa, g.pos2_aos, ws2 = ops.fps(g.pos1_soa, M2, fps_start[1], return_ws=True)
+        g.nbr2, g.cnt2, g.tot2 = ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2],
+                                                fps_ws=ws2)
         pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)      # GlobalSAModule: pos = zeros (point_net2.py:40)
         g.knn3 = ops.three_nn(pos3, g.pos2_soa, 1)
         g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3)
@@ -247,7 +288,7 @@ class PointNet2(nn.Module):
         elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
             raise ValueError("prefetched geometry does not match this batch")
         s = _Saved()
-        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream")})
+        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream", "ws1", "ws2", "totals")})
         s.xyz = xyz
         # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd and the per-workgroup statistics
         # slots (written before they are read: no zero fill)

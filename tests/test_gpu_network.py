@@ -115,9 +115,11 @@ def test_pixel_indices_bit_exact_and_p2_gradient():
         assert np.array_equal(np.nan_to_num(got), np.nan_to_num(ref))     # maxima of identical fp32 values: exact
 
 
-@pytest.mark.parametrize("B,N,ratio1,r1,r2", [(2, 3000, 0.1, 1.0, 2.0), (1, 8192, 0.125, 1.0, 2.0)])
+@pytest.mark.parametrize("B,N,ratio1,r1,r2", [(2, 3000, 0.1, 1.0, 2.0), (1, 8192, 0.125, 1.0, 2.0),
+                                               (1, 10000, 0.25, 2 ** 0.5, 8 ** 0.5)])
 def test_forward_backward_vs_oracle_other_sizes(B, N, ratio1, r1, r2):
-    """Sizes outside the goldens (N not a multiple of 64, C2-style radii): oracle restatement as the checker."""
+    """Sizes outside the goldens (N not a multiple of 64, C2-style radii, the reference defaults at N = 10000 where
+    level 2 also takes the bucketed FPS + cell-list ball query): oracle restatement as the checker."""
     args = make_args(subsample_size=N, ratio1=ratio1, r1=r1, ratio2=0.25, r2=r2)
     d = make_batch(B, N, first_plot=200)
     sd = network.init_state_dict(3)
