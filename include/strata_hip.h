@@ -174,6 +174,18 @@ int sn2_raster_project(const float *coverages, const float *cloud_xy, long plot_
 int sn2_mosaic_merge(const float *rasters, const float *weights, const int *offsets, int B, int D, int H, int W,
                      float *mean, float *wsum, int win_y0, int win_x0, int win_h, int win_w, void *stream);
 
+/* ---- loss block of the timed training step: learning/loss_functions.py:9-57 combined as learning/train.py:58-62,
+ *   total = get_absolute_loss(pred, gt) + m * get_NLL_loss(proba, pdf_all) + e * get_entropy_loss(proba)
+ * pred (B,4) fp32 plot-wise coverages, gt (B,4) fp64, proba (R,4) fp32 pointwise class probabilities, pdf (R,3) fp64 the
+ * KDE-mixture densities at the points' heights (the reference evaluates them on the CPU each step, :30-42; KDE fitting is
+ * out of scope, so they are an input).  partials: 2*SN2_LOSS_BLOCKS fp64 workspace.  out[4] = total, absolute, NLL,
+ * entropy.  Backward: grad_total = device scalar d(objective)/d(total); writes dpred (B,4), dproba (R,4). */
+#define SN2_LOSS_BLOCKS 1024
+int sn2_loss_forward(const float *pred, const double *gt, int B, const float *proba, const double *pdf, int R, double m,
+                     double e, double *partials, double *out, void *stream);
+int sn2_loss_backward(const float *pred, const double *gt, int B, const float *proba, const double *pdf, int R, double m,
+                      double e, const double *grad_total, float *dpred, float *dproba, void *stream);
+
 /* ---- optimiser step of the timed training step -- torch.optim.Adam as configured in learning/train.py:180-185
  * (L2 weight decay added to the gradient), on flat buffers; grad_scale multiplies the gradient first (1/world). */
 int sn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int n, float lr, float beta1,

@@ -1,0 +1,74 @@
+"""Where does the pipelined step's time go?  feature graphs alone / geometry alone / both, at several depths."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_plotwise_coverages, losses
+from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters
+from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
+
+B, N = 16, 32768
+args = make_args(cuda=0, subsample_size=N, ratio1=1024 / N, r1=1.0, ratio2=0.25, r2=2.0)
+torch.manual_seed(0)
+model = PointNet2(args).train()
+flatten_parameters(model)
+opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3)
+dev = torch.device("cuda:0")
+
+
+def mk(j):
+    h = make_batch(B, N, first_plot=j * B)
+    return {"cloud": h["cloud"].to(dev), "xyz": h["xyz"].to(dev), "fps_start": torch.zeros(2, B, dtype=torch.int32, device=dev),
+            "gt": h["coverages"].to(dev), "pdf": h["pdf_all"].to(dev)}
+
+
+def fstep(inp, geo=None):
+    opt.zero_grad()
+    cd = {"cloud": inp["cloud"], "xyz": inp["xyz"], "fps_start": inp["fps_start"]}
+    if geo is not None:
+        cd["geometry"] = geo
+    cov, proba = model(cd)
+    pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
+    loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
+    loss.backward()
+    return loss
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+for depth in [int(x) for x in os.environ.get('DEPTHS', '1,2,3').split(',')]:
+    slots = [mk(j) for j in range(depth + 1)]
+    pipe = TrainPipeline(model, opt, fstep, slots, depth=depth)
+    pipe.capture()
+    if depth == 1 and not os.environ.get('ONLY_FULL'):
+        k = [0]
+        def feat_only():
+            pipe.graph_fb[k[0] % 2].replay(); k[0] += 1
+        print(f"feature graph alone: {timeit(feat_only):.3f} ms", flush=True)
+        i = [0]
+        def geo_only():
+            pipe.issue_geometry(i[0]); i[0] += 1
+        pipe.slot_done = [None] * pipe.slots
+        print(f"geometry alone, 1 side stream: {timeit(geo_only):.3f} ms", flush=True)
+    if depth == 2 and not os.environ.get('ONLY_FULL'):
+        i = [0]
+        def geo_only2():
+            pipe.issue_geometry(i[0]); i[0] += 1
+        print(f"geometry alone, 2 side streams: {timeit(geo_only2):.3f} ms per pass", flush=True)
+        pipe.issued = 0
+    pipe.issued, pipe.done = 0, 0
+    pipe.prime()
+    def full():
+        pipe.step()
+    print(f"pipeline depth {depth}: {timeit(full):.3f} ms/step", flush=True)
+    pipe.drain(); torch.cuda.synchronize()
+    del pipe

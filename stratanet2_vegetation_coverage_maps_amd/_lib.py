@@ -2,7 +2,7 @@
 is missing the product path raises."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_float, c_int, c_long, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_long, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libstrata_hip.so")
@@ -65,6 +65,10 @@ SIGNATURES = {
                            c_void_p],
     "sn2_mosaic_merge": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                          c_int, c_int, c_int, c_int, c_void_p],
+    "sn2_loss_forward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p,
+                         c_void_p],
+    "sn2_loss_backward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p,
+                          c_void_p, c_void_p],
     "sn2_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
                       c_void_p, c_float, c_void_p],
 }

@@ -1,6 +1,8 @@
 // geometry.hip -- position-only kernels: row packing, farthest point sampling, radius ball query, 3-NN.
 // All discrete decisions use the canonical fp32 squared distance sn2_d2 (common.h) so that the index structures
 // are bit-identical to the oracle's.
+#include <stdlib.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -443,7 +445,8 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
     int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
     hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid);
-    hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), 0, st, pos, N, M, start, (const int*)order,
+    static const int pad = getenv("SN2_FPS_LDS_PAD") ? atoi(getenv("SN2_FPS_LDS_PAD")) : 0;
+    hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), pad, st, pos, N, M, start, (const int*)order,
                        (const float4*)sorted, idx, cs, ca);
     SN2_RETURN_LAUNCH();
 }

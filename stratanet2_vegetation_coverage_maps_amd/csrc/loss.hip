@@ -1,0 +1,138 @@
+// loss.hip -- the loss block of the training step as three kernels (gfx950).
+//
+// Replaces the ~75 elementwise / reduction launches torch needs for
+//   loss = get_absolute_loss(pred, gt) + m * get_NLL_loss(proba, pdf_all) + e * get_entropy_loss(proba)
+// (/root/reference/learning/loss_functions.py:9-57 as combined by learning/train.py:58-62) and for its backward.
+// Arithmetic types follow what torch's type promotion gives the reference: the absolute loss and the NLL in fp64
+// (gt and the KDE densities are fp64 numpy arrays), the entropy terms in fp32.  Sums are per-workgroup partials added in
+// a fixed order: deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int LOSS_BLOCKS = SN2_LOSS_BLOCKS;
+constexpr float EPS_F = 0.0001f;
+constexpr double EPS_D = 0.0001;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one row per lane: 16 B of probabilities + 24 B of densities, both contiguous across the wave
+__global__ __launch_bounds__(256) void loss_point_kernel(const float4* __restrict__ proba, const double* __restrict__ pdf,
+                                                         int R, double* __restrict__ partials) {
+    __shared__ double s_part[2][4];
+    double nll = 0.0, ent = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) {
+        const float4 p = proba[i];
+        const double f0 = pdf[3 * (size_t)i], f1 = pdf[3 * (size_t)i + 1], f2 = pdf[3 * (size_t)i + 2];
+        const float pg = p.x + p.y;                                   // pred[:, :2].sum(1) in fp32 (:44)
+        const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
+        nll -= log(lik);
+        const float e2 = p.z * logf(p.z + EPS_F) + (1.f - p.z) * logf(1.f - p.z + EPS_F);
+        const float e3 = p.w * logf(p.w + EPS_F) + (1.f - p.w) * logf(1.f - p.w + EPS_F);
+        ent -= (double)e2 + (double)e3;
+    }
+    nll = wave_sum_f64(nll);
+    ent = wave_sum_f64(ent);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_part[0][w] = nll; s_part[1][w] = ent; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = (s_part[0][0] + s_part[0][1]) + (s_part[0][2] + s_part[0][3]);
+        partials[2 * blockIdx.x + 1] = (s_part[1][0] + s_part[1][1]) + (s_part[1][2] + s_part[1][3]);
+    }
+}
+
+// out[0..3] = total, absolute, NLL, entropy
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ pred, const double* __restrict__ gt, int B,
+                                                         const double* __restrict__ partials, int nblocks, int R, double m,
+                                                         double e, double* __restrict__ out) {
+    __shared__ double s[3][256];
+    double nll = 0.0, ent = 0.0, ab = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { nll += partials[2 * i]; ent += partials[2 * i + 1]; }
+    for (int i = threadIdx.x; i < 3 * B; i += 256) {                   // strata low, medium, high = columns 0, 2, 3 (:12)
+        const int b = i / 3, c = i - 3 * b, col = c == 0 ? 0 : c + 1;
+        const double d = (double)pred[4 * b + col] - gt[4 * b + col];
+        ab += sqrt(d * d + EPS_D);
+    }
+    s[0][threadIdx.x] = nll; s[1][threadIdx.x] = ent; s[2][threadIdx.x] = ab;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            s[0][threadIdx.x] += s[0][threadIdx.x + o];
+            s[1][threadIdx.x] += s[1][threadIdx.x + o];
+            s[2][threadIdx.x] += s[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double l_abs = s[2][0] / (3.0 * B), l_nll = s[0][0] / R;
+        const double l_ent = (double)(float)(s[1][0] / (2.0 * R));      // the reference's entropy is an fp32 tensor
+        out[0] = l_abs + m * l_nll + e * l_ent;
+        out[1] = l_abs;
+        out[2] = l_nll;
+        out[3] = l_ent;
+    }
+}
+
+// d loss / d proba, d loss / d pred for the upstream gradient g of the TOTAL loss (device scalar)
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ pred, const double* __restrict__ gt, int B,
+                                                       const float4* __restrict__ proba, const double* __restrict__ pdf, int R,
+                                                       double m, double e, const double* __restrict__ gout,
+                                                       float* __restrict__ dpred, float4* __restrict__ dproba) {
+    const double g = gout[0];
+    const double cn = g * m / R, ce = g * e / (2.0 * R);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) {
+        const float4 p = proba[i];
+        const double f0 = pdf[3 * (size_t)i], f1 = pdf[3 * (size_t)i + 1], f2 = pdf[3 * (size_t)i + 2];
+        const float pg = p.x + p.y;
+        const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
+        const double il = -cn / lik;
+        const float h2 = -(logf(p.z + EPS_F) + p.z / (p.z + EPS_F) - logf(1.f - p.z + EPS_F) - (1.f - p.z) / (1.f - p.z + EPS_F));
+        const float h3 = -(logf(p.w + EPS_F) + p.w / (p.w + EPS_F) - logf(1.f - p.w + EPS_F) - (1.f - p.w) / (1.f - p.w + EPS_F));
+        float4 d;
+        d.x = d.y = (float)(il * f0);
+        d.z = (float)(il * f1 + ce * (double)h2);
+        d.w = (float)(il * f2 + ce * (double)h3);
+        dproba[i] = d;
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 4 * B; i += 256) {
+            const int col = i & 3;
+            float r = 0.f;
+            if (col != 1) {
+                const double d = (double)pred[i] - gt[i];
+                r = (float)(g * d / sqrt(d * d + EPS_D) / (3.0 * B));
+            }
+            dpred[i] = r;
+        }
+    }
+}
+
+inline int loss_grid(int R) {
+    const int n = sn2_cdiv(R, 256);
+    return n < LOSS_BLOCKS ? n : LOSS_BLOCKS;
+}
+
+}  // namespace
+
+extern "C" int sn2_loss_forward(const float* pred, const double* gt, int B, const float* proba, const double* pdf, int R,
+                                double m, double e, double* partials, double* out, void* stream) {
+    if (!pred || !gt || !proba || !pdf || !partials || !out || B <= 0 || R <= 0) return SN2_EINVAL;
+    const int nb = loss_grid(R);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_point_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4*>(proba), pdf, R, partials);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, pred, gt, B, (const double*)partials, nb, R, m, e, out);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_loss_backward(const float* pred, const double* gt, int B, const float* proba, const double* pdf, int R,
+                                 double m, double e, const double* grad_total, float* dpred, float* dproba, void* stream) {
+    if (!pred || !gt || !proba || !pdf || !grad_total || !dpred || !dproba || B <= 0 || R <= 0) return SN2_EINVAL;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(loss_grid(R)), dim3(256), 0, (hipStream_t)stream, pred, gt, B,
+                       reinterpret_cast<const float4*>(proba), pdf, R, m, e, grad_total, dpred, reinterpret_cast<float4*>(dproba));
+    SN2_RETURN_LAUNCH();
+}

@@ -464,6 +464,33 @@ def mosaic_merge(rasters, weights, offsets, mean, wsum, window=None):
           y0, x0, wh, ww, _stream())
 
 
+LOSS_BLOCKS = 1024
+
+
+def loss_forward(pred, gt, proba, pdf, m: float, e: float):
+    """-> out (4,) fp64 = [total, absolute, NLL, entropy] (include/strata_hip.h: sn2_loss_forward)."""
+    B, R = pred.shape[0], proba.shape[0]
+    _chk(pred, F32, (B, 4), "pred")
+    _chk(gt, F64, (B, 4), "gt")
+    _chk(proba, F32, (R, 4), "proba")
+    _chk(pdf, F64, (R, 3), "pdf")
+    partials = torch.empty(2 * LOSS_BLOCKS, dtype=F64, device=pred.device)
+    out = torch.empty(4, dtype=F64, device=pred.device)
+    _call("sn2_loss_forward", _ptr(pred), _ptr(gt), B, _ptr(proba), _ptr(pdf), R, float(m), float(e), _ptr(partials),
+          _ptr(out), _stream())
+    return out
+
+
+def loss_backward(pred, gt, proba, pdf, m: float, e: float, grad_total):
+    B, R = pred.shape[0], proba.shape[0]
+    _chk(grad_total, F64, None, "grad_total")
+    dpred = torch.empty(B, 4, dtype=F32, device=pred.device)
+    dproba = torch.empty(R, 4, dtype=F32, device=pred.device)
+    _call("sn2_loss_backward", _ptr(pred), _ptr(gt), B, _ptr(proba), _ptr(pdf), R, float(m), float(e), _ptr(grad_total),
+          _ptr(dpred), _ptr(dproba), _stream())
+    return dpred, dproba
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):
     """step_dev: int32 device tensor (1,) holding the number of steps taken so far; incremented by the call."""
     n = param.numel()

@@ -3,11 +3,18 @@
 
     loss = get_absolute_loss(pred, gt) + m * get_NLL_loss(proba, pdf_all) + e * get_entropy_loss(proba)
 
-Plain torch ops on the device (harness-level code; SURVEY.md 8f ranks a fused HIP loss kernel as the next row).
+`total_loss` is ONE autograd node over three HIP kernels (csrc/loss.hip: pointwise partial sums, finalize, backward)
+instead of the ~75 elementwise launches torch needs for the same expression and its gradient -- at 2.5 ms per step
+those launches were a fifth of the step.  `total_loss_torch` and the three `get_*` functions keep the plain torch-op form
+(same as the reference, usable on any device); the tests hold the fused kernels to them.
+
 Difference from the reference signature: `get_NLL_loss` takes the KDE-mixture densities `pdf_all (B*N,3)` directly
 instead of evaluating `args.kde_mixture` on the CPU each step (`loss_functions.py:30-42`; KDE fitting is out of scope).
 """
 import torch
+
+from . import hip_ops as ops
+from ._lib import StrataHipError
 
 EPS = 0.0001
 
@@ -30,8 +37,38 @@ def get_NLL_loss(pred_pointwise, pdf_all):
     return -torch.log(lik).mean()
 
 
-def total_loss(pred_coverages, proba_pointwise, gt, pdf_all, m=0.10, e=0.2 / 5):
+def total_loss_torch(pred_coverages, proba_pointwise, gt, pdf_all, m=0.10, e=0.2 / 5):
     l_abs = get_absolute_loss(pred_coverages, gt)
     l_log = get_NLL_loss(proba_pointwise, pdf_all)
     l_e = get_entropy_loss(proba_pointwise)
     return l_abs + m * l_log + e * l_e, (l_abs, l_log, l_e)
+
+
+class _TotalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, proba, gt, pdf, m, e):
+        out = ops.loss_forward(pred, gt, proba, pdf, m, e)
+        ctx.save_for_backward(pred, proba, gt, pdf)
+        ctx.me = (m, e)
+        total, l_abs, l_log, l_e = out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(l_abs, l_log, l_e)
+        return total, l_abs, l_log, l_e
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        pred, proba, gt, pdf = ctx.saved_tensors
+        m, e = ctx.me
+        dpred, dproba = ops.loss_backward(pred, gt, proba, pdf, m, e, g.to(torch.float64).contiguous())
+        return dpred, dproba, None, None, None, None
+
+
+def total_loss(pred_coverages, proba_pointwise, gt, pdf_all, m=0.10, e=0.2 / 5):
+    """-> (total, (absolute, NLL, entropy)), fp64 scalars on the device; differentiable w.r.t. the first two arguments."""
+    if not (pred_coverages.is_cuda and proba_pointwise.is_cuda):
+        raise StrataHipError("losses.total_loss runs on the HIP device (total_loss_torch is the plain torch form)")
+    with torch.cuda.device(pred_coverages.device):
+        gt = gt.to(device=pred_coverages.device, dtype=torch.float64).contiguous()
+        pdf_all = pdf_all.to(device=pred_coverages.device, dtype=torch.float64).contiguous()
+        total, l_abs, l_log, l_e = _TotalLoss.apply(pred_coverages.float().contiguous(), proba_pointwise.float().contiguous(),
+                                                    gt, pdf_all, float(m), float(e))
+    return total, (l_abs, l_log, l_e)

@@ -37,7 +37,9 @@ class TrainPipeline:
         self.dev = dev
         B, _, N = slot_inputs[0]["xyz"].shape
         self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        import os
+        prio = int(os.environ.get('SN2_PIPE_PRIO', '0'))
+        self.side = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(depth)]
         self.geo_ready = [torch.cuda.Event() for _ in range(self.slots)]
         self.slot_done = [None] * self.slots
         self.graph_fb = [None] * self.slots       # zero_grad .. backward

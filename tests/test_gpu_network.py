@@ -189,18 +189,30 @@ def test_flat_adam_matches_torch_adam():
 
 
 def test_losses_match_oracle():
-    """Device loss block (product, hipGraph-capturable) vs the oracle's restatement of learning/loss_functions.py."""
+    """Fused loss kernels (product, hipGraph-capturable) vs the oracle's restatement of learning/loss_functions.py and vs
+    the plain torch-op form on the device: values 1e-6, gradients 1e-6 relative to the largest entry."""
     from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
     g = torch.Generator().manual_seed(0)
-    pred = torch.rand(6, 4, generator=g)
-    proba = torch.softmax(torch.randn(3000, 4, generator=g), 1)
-    gt = torch.rand(6, 4, generator=g, dtype=torch.float64)
-    pdf = torch.rand(3000, 3, generator=g, dtype=torch.float64) + 0.05
-    a, pa = dev_losses.total_loss(pred.cuda(), proba.cuda(), gt.cuda(), pdf.cuda())
-    b, pb = losses.total_loss(pred, proba, gt, pdf)
-    assert abs(a.item() - b.item()) < 1e-6
-    for x, y in zip(pa, pb):
-        assert abs(x.item() - y.item()) < 1e-6
+    for B, R in ((6, 3000), (16, 70001)):
+        pred = torch.rand(B, 4, generator=g)
+        proba = torch.softmax(torch.randn(R, 4, generator=g), 1) * torch.rand(R, 1, generator=g)
+        gt = torch.rand(B, 4, generator=g, dtype=torch.float64)
+        pdf = torch.rand(R, 3, generator=g, dtype=torch.float64) + 0.05
+        pd, qd = pred.cuda().requires_grad_(True), proba.cuda().requires_grad_(True)
+        a, pa = dev_losses.total_loss(pd, qd, gt.cuda(), pdf.cuda(), 0.1, 0.04)
+        (3.0 * a).backward()                                        # a non-unit upstream gradient
+        pt, qt = pred.cuda().requires_grad_(True), proba.cuda().requires_grad_(True)
+        t, _ = dev_losses.total_loss_torch(pt, qt, gt.cuda(), pdf.cuda(), 0.1, 0.04)
+        (3.0 * t).backward()
+        pr, qr = pred.clone().requires_grad_(True), proba.clone().requires_grad_(True)
+        b, pb = losses.total_loss(pr, qr, gt, pdf, 0.1, 0.04)
+        (3.0 * b).backward()
+        assert abs(a.item() - b.item()) < 1e-6 and abs(a.item() - t.item()) < 1e-6
+        for x, y in zip(pa, pb):
+            assert abs(x.item() - y.item()) < 1e-6
+        for got, ref in ((pd.grad, pr.grad), (qd.grad, qr.grad), (pd.grad, pt.grad.cpu()), (qd.grad, qt.grad.cpu())):
+            ref = ref.cpu().numpy()
+            np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
 
 
 def test_prefetched_geometry_gives_identical_results():
