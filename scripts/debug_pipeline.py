@@ -41,19 +41,23 @@ def timeit(fn, n=30):
     t = time.perf_counter()
     for _ in range(n):
         fn()
+    th = time.perf_counter() - t
     torch.cuda.synchronize()
+    print(f"   (host issue time {th / n * 1e3:.3f} ms/iter)")
     return (time.perf_counter() - t) / n * 1e3
 
 
 for depth in [int(x) for x in os.environ.get('DEPTHS', '1,2,3').split(',')]:
-    slots = [mk(j) for j in range(depth + 1)]
-    pipe = TrainPipeline(model, opt, fstep, slots, depth=depth)
+    slots = [mk(j) for j in range(depth + 1 + int(os.environ.get('EXTRA_SLOTS', '0')))]
+    pipe = TrainPipeline(model, opt, fstep, slots, depth=depth, n_streams=int(os.environ.get('NSTREAMS', '0')) or None)
     pipe.capture()
     if depth == 1 and not os.environ.get('ONLY_FULL'):
         k = [0]
         def feat_only():
             pipe.graph_fb[k[0] % 2].replay(); k[0] += 1
         print(f"feature graph alone: {timeit(feat_only):.3f} ms", flush=True)
+        if os.environ.get('ONLY_FEAT'):
+            sys.exit(0)
         i = [0]
         def geo_only():
             pipe.issue_geometry(i[0]); i[0] += 1

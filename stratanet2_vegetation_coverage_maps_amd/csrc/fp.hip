@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
     float* __restrict__ du_out /* KNN: (R,CA) scratch; else ACCUMULATED rows (R,du_stride) */,
     float* __restrict__ dskip) {
     constexpr int CI = CA + CB;
-    using Acc = OuterAcc<CO, CI + 1>;
+    using Acc = OuterAcc<CO, CI + 1, 32>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lds = smem + (threadIdx.x >> 6) * Acc::LDS_FLOATS;
     Acc acc;
@@ -575,8 +575,9 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
 template <int CA, int CB, int CO, bool KNN>
 int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     constexpr int CI = CA + CB;
-    using Acc = OuterAcc<CO, CI + 1>;
-    constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : ((Acc::LDS_FLOATS * 4 * 2 <= 150 * 1024) ? 2 : 1);
+    using Acc = OuterAcc<CO, CI + 1, 32>;
+    // waves per workgroup (one workgroup per CU): as many as the staging regions and 256 VGPRs per lane allow
+    constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 8 <= 150 * 1024) ? 8 : ((Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : 2);
     const int R = p->B * p->R_per_plot;
     int g1 = pick_grid(R, 256, R >= (1 << 18) ? 8 : 1);
     if (g1 > 256) g1 = 256;
@@ -744,7 +745,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int R, int f_stride, cons
     }
 }
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(int R, int f_stride, const float* __restrict__ f,
+constexpr int HEAD_BWD_THREADS = 1024;
+constexpr int HEAD_BWD_LDS_FLOATS = OuterAcc<16, 35, 32>::LDS_FLOATS;   // >= OuterAcc<16, 17, 32>::LDS_FLOATS
+__global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f_stride, const float* __restrict__ f,
                                                        const float* __restrict__ fa, const float* __restrict__ fc,
                                                        const float* __restrict__ W1g, const float* __restrict__ b1,
                                                        const float* __restrict__ W2g, const float* __restrict__ b2,
@@ -752,19 +755,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int R, int f_stride, cons
                                                        float* __restrict__ dy, float* __restrict__ dW1,
                                                        float* __restrict__ db1, float* __restrict__ dW2,
                                                        float* __restrict__ db2) {
-    using Acc2 = OuterAcc<16, 17>;  // rows 0..4 = d scores, rest zero;  Q = [z1 | 1]
-    using Acc1 = OuterAcc<16, 35>;  // d pre-activation of lin1;          Q = [y | 1]
+    using Acc2 = OuterAcc<16, 17, 32>;  // rows 0..4 = d scores, rest zero;  Q = [z1 | 1]
+    using Acc1 = OuterAcc<16, 35, 32>;  // d pre-activation of lin1;          Q = [y | 1]
+    // 16 waves per workgroup (4 per SIMD: the row loads are 144-byte strided, only occupancy hides them); the two
+    // accumulators take turns in one 8 KB staging region per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lds2 = smem + (threadIdx.x >> 6) * (Acc2::LDS_FLOATS + Acc1::LDS_FLOATS);
-    float* lds1 = lds2 + Acc2::LDS_FLOATS;
+    float* lds2 = smem + (threadIdx.x >> 6) * HEAD_BWD_LDS_FLOATS;
+    float* lds1 = lds2;
     Acc2 acc2;
     Acc1 acc1;
     acc2.init(lds2);
     acc1.init(lds1);
-    const long nthreads = (long)gridDim.x * 256;
+    const long nthreads = (long)gridDim.x * HEAD_BWD_THREADS;
     const long rounds = (R + nthreads - 1) / nthreads;
     for (long it = 0; it < rounds; ++it) {
-        const long r = it * nthreads + (long)blockIdx.x * 256 + threadIdx.x;
+        const long r = it * nthreads + (long)blockIdx.x * HEAD_BWD_THREADS + threadIdx.x;
         const bool valid = r < R;
         const size_t rr = valid ? (size_t)r : 0;
         const cfp W1 = opaque(as_const(W1g)), W2 = opaque(as_const(W2g));
@@ -825,12 +830,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int R, int f_stride, cons
     float* red = smem;
     constexpr int N2 = 16 * 17, N1 = 16 * 35;
     __syncthreads();
-    for (int i = threadIdx.x; i < N2 + N1; i += 256) red[i] = 0.f;
+    for (int i = threadIdx.x; i < N2 + N1; i += HEAD_BWD_THREADS) red[i] = 0.f;
     __syncthreads();
     acc2.flush_lds(red);
     acc1.flush_lds(red + N2);
     __syncthreads();
-    for (int i = threadIdx.x; i < N2 + N1; i += 256) {
+    for (int i = threadIdx.x; i < N2 + N1; i += HEAD_BWD_THREADS) {
         const float v = red[i];
         if (v == 0.f) continue;
         if (i < N2) {
@@ -862,12 +867,13 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
 extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     SN2_TRY(check_head(p));
     if (!p->dy || !p->dW1 || !p->db1 || !p->dW2 || !p->db2) return SN2_EINVAL;
-    constexpr size_t lds_bytes = (size_t)(OuterAcc<16, 17>::LDS_FLOATS + OuterAcc<16, 35>::LDS_FLOATS) * 4 * 4;
+    static_assert(OuterAcc<16, 17, 32>::LDS_FLOATS <= HEAD_BWD_LDS_FLOATS, "shared staging region");
+    constexpr size_t lds_bytes = (size_t)HEAD_BWD_LDS_FLOATS * 4 * (HEAD_BWD_THREADS / 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
-    int grid = pick_grid(p->R, 256, 4);
+    int grid = pick_grid(p->R, HEAD_BWD_THREADS, 1);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
                        p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
                        p->db2);
     SN2_RETURN_LAUNCH();

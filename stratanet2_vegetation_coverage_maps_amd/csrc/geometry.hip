@@ -1,8 +1,6 @@
 // geometry.hip -- position-only kernels: row packing, farthest point sampling, radius ball query, 3-NN.
 // All discrete decisions use the canonical fp32 squared distance sn2_d2 (common.h) so that the index structures
 // are bit-identical to the oracle's.
-#include <stdlib.h>
-
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -142,17 +140,19 @@ __device__ __forceinline__ unsigned morton_cell(unsigned cx, unsigned cy, unsign
 
 // grid header per plot (32-bit words): [0..4096] first sorted position of every Morton cell (+ end), then lo.xyz, scale.xyz
 constexpr int GRID_WORDS = ORDER_CELLS + 1 + 6 + 1;   // padded to an even count
-__global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
+// NT threads per plot (1024: 0.10 ms at N = 32768; 256 threads measured 0.18 ms and changed nothing else).
+template <int NT>
+__global__ __launch_bounds__(NT) void spatial_order_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
                                                              float4* __restrict__ sorted, int* __restrict__ grid) {
     __shared__ int s_hist[ORDER_CELLS];
-    __shared__ float s_mm[6][16];
-    __shared__ int s_wsum[16];
+    __shared__ float s_mm[6][NT / 64];
+    __shared__ int s_wsum[NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* px = pos + (size_t)b * 3 * N;
     const float* py = px + N;
     const float* pz = py + N;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += 1024) {
+    for (int i = tid; i < N; i += NT) {
         const float v[3] = {px[i], py[i], pz[i]};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -169,13 +169,13 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __rest
             s_mm[3 + a][wave] = mx[a];
         }
     }
-    for (int i = tid; i < ORDER_CELLS; i += 1024) s_hist[i] = 0;
+    for (int i = tid; i < ORDER_CELLS; i += NT) s_hist[i] = 0;
     __syncthreads();
     float lo[3], sc[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float l = s_mm[a][0], h = s_mm[3 + a][0];
-        for (int k = 1; k < 16; ++k) {
+        for (int k = 1; k < NT / 64; ++k) {
             l = fminf(l, s_mm[a][k]);
             h = fmaxf(h, s_mm[3 + a][k]);
         }
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __rest
         cz = cz < 0 ? 0 : (cz > ORDER_GZ - 1 ? ORDER_GZ - 1 : cz);
         return morton_cell((unsigned)cx, (unsigned)cy, (unsigned)cz);
     };
-    for (int i = tid; i < N; i += 1024) atomicAdd(&s_hist[cell_of(i)], 1);
+    for (int i = tid; i < N; i += NT) atomicAdd(&s_hist[cell_of(i)], 1);
     __syncthreads();
     // exclusive scan over the cells: PER consecutive cells per thread, wave scan, 16 wave totals
-    constexpr int PER = ORDER_CELLS / 1024;
+    constexpr int PER = ORDER_CELLS / NT;
     int loc[PER], sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __rest
     __syncthreads();
     if (grid) {   // cell -> first sorted position (the ball query walks these cell lists)
         int* gb = grid + (size_t)b * GRID_WORDS;
-        for (int i = tid; i < ORDER_CELLS; i += 1024) gb[i] = s_hist[i];
+        for (int i = tid; i < ORDER_CELLS; i += NT) gb[i] = s_hist[i];
         if (tid == 0) {
             gb[ORDER_CELLS] = N;
             float* gf = reinterpret_cast<float*>(gb + ORDER_CELLS + 1);
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __rest
     __syncthreads();
     int* ob = order + (size_t)b * N;
     float4* sb = sorted + (size_t)b * N;
-    for (int i = tid; i < N; i += 1024) {
+    for (int i = tid; i < N; i += NT) {
         const int p = atomicAdd(&s_hist[cell_of(i)], 1);
         ob[p] = i;
-        sb[p] = make_float4(px[i], py[i], pz[i], 0.f);
+        sb[p] = make_float4(px[i], py[i], pz[i], INFINITY);   // .w = running FPS distance (fps_bucket_kernel)
     }
 }
 
@@ -251,10 +251,17 @@ __device__ __forceinline__ float sn2_box_d2(float lx, float ly, float lz, float 
 }
 
 // SPW = bucket slots per wave (bucket b lives in wave b % 16, slot b / 16); 16 waves.  The sorted points stay in
-// global memory (an L2-resident 16 B x N table, one dwordx4 per lane fetches a whole bucket); LDS holds the running
-// distances, the bucket boxes and each bucket's current farthest point; registers hold no per-point state, so the
-// round loop is a short body executed only for the buckets that can change (no 32-way unrolled branch chain: that
-// version was instruction-fetch bound).
+// global memory (an L2-resident 16 B x N table, one dwordx4 per lane fetches a whole bucket) and the table's .w lane is
+// the point's RUNNING DISTANCE: it arrives with the coordinates in the same dwordx4 and is written back when it shrinks.
+// Plain loads and stores are enough: a bucket is only ever touched by its own wave, and a CU's vector L1 is write-through
+// and coherent with that CU's own stores (agent-scope `sc1` accesses were tried first: they bypass the XCD's L2 too and
+// made the kernel 27 % slower).
+// LDS holds only the bucket boxes and the per-wave exchange records (13 KB): with the distances in LDS (128 KB at
+// N = 32768) a workgroup needed a CU with no other LDS user, and next to the feature kernels of the pipelined training
+// step such a CU only turned up when another FPS workgroup retired -- two FPS passes in flight ran back to back.
+// Registers hold no per-point state, so the round loop is a short body executed only for the buckets that can change
+// (no 32-way unrolled branch chain: that version was instruction-fetch bound).
+__device__ __forceinline__ void fps_st_dist(float4* t, int p, float v) { reinterpret_cast<float*>(t + p)[3] = v; }
 #ifdef SN2_FPS_STAMPS
 // diagnostic build only (never shipped): per-phase cycle totals of wave 0 of workgroup 0
 __device__ unsigned long long g_fps_dbg[8];
@@ -269,11 +276,10 @@ extern "C" int sn2_debug_fps_stamps(unsigned long long* out) {
 template <int SPW, int NW>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __restrict__ pos, int N, int M,
                                                           const int* __restrict__ start, const int* __restrict__ order,
-                                                          const float4* __restrict__ sorted, int* __restrict__ idx_out,
+                                                          float4* sorted, int* __restrict__ idx_out,
                                                           float* __restrict__ cpos_soa, float* __restrict__ cpos_aos) {
     constexpr int NBK = SPW * NW;
     static_assert(SPW <= 64 && NW <= 16, "one lane per bucket slot of the wave");
-    __shared__ float s_dist[SPW * NW * 64];            // running min distance, [wave][slot][lane]
     __shared__ float s_box[6 * NBK];                   // bucket boxes, [component][wave][slot]: lane j reads word j of its
                                                        // wave's row => conflict-free (an AoS box layout cost 32-way conflicts)
     __shared__ float4 s_xchg[2][2][NW];                // per wave: (max distance, tie flag, -, -) and (x, y, z, sorted position)
@@ -284,14 +290,12 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
     const float* py = px + N;
     const float* pz = py + N;
     const int* ord = order + (size_t)b * N;
-    const float4* pts = sorted + (size_t)b * N;
-    float* my_dist = s_dist + wave * SPW * 64 + lane;
+    float4* pts = sorted + (size_t)b * N;              // (x, y, z, running distance = +inf from spatial_order_kernel)
     float* my_box = s_box + wave * SPW;                // + component * NBK + slot
     for (int k = 0; k < SPW; ++k) {
         const int p = (k * NW + wave) * 64 + lane;     // position in the sorted order (bucket k*NW + wave)
         const bool v = p < N;
         const float4 q = v ? pts[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-        my_dist[k * 64] = v ? INFINITY : -1.f;
         const float lx = -wave_max_dpp(v ? -q.x : -INFINITY), ly = -wave_max_dpp(v ? -q.y : -INFINITY),
                     lz = -wave_max_dpp(v ? -q.z : -INFINITY);
         const float hx = wave_max_dpp(v ? q.x : -INFINITY), hy = wave_max_dpp(v ? q.y : -INFINITY),
@@ -317,10 +321,10 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
 
     // one dirty bucket: new distances, bucket maximum, its point -> the registers of lane k
     auto update = [&](int k, int p, const float4& q) {
-        const float d = my_dist[k * 64];
+        const float d = q.w;
         const float dd = sn2_d2(q.x, q.y, q.z, cx, cy, cz);
-        const float nd = d < 0.f ? d : fminf(d, dd);   // padding lanes stay at -1
-        my_dist[k * 64] = nd;
+        const float nd = p < N ? fminf(d, dd) : -1.f;   // padding lanes of the last bucket never win
+        if (p < N && nd < d) fps_st_dist(pts, p, nd);
         const float m = wave_max_dpp(nd);
         const unsigned long long bal = __ballot(nd == m);
         const int first = __ffsll((long long)bal) - 1;
@@ -408,9 +412,10 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
             while (cand) {
                 const int kk = __ffsll((long long)cand) - 1;
                 cand &= cand - 1;
-                const float d = my_dist[kk * 64];
+                const int pp = (kk * NW + wave) * 64 + lane;
+                const float d = pp < N ? pts[pp].w : -1.f;
                 unsigned oi = 0xFFFFFFFFu;
-                if (d == V) oi = (unsigned)ord[(kk * NW + wave) * 64 + lane];
+                if (d == V) oi = (unsigned)ord[pp];
                 oi = wave_min_u32_dpp(oi);
                 if (lane == 0) atomicMin(&s_win, oi);
             }
@@ -444,10 +449,9 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
     float4* sorted = reinterpret_cast<float4*>(ws + (size_t)B * N);   // B*N float4 (16-byte aligned: B*N*4 bytes offset
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
     int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
-    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid);
-    static const int pad = getenv("SN2_FPS_LDS_PAD") ? atoi(getenv("SN2_FPS_LDS_PAD")) : 0;
-    hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), pad, st, pos, N, M, start, (const int*)order,
-                       (const float4*)sorted, idx, cs, ca);
+    hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid);
+    hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), 0, st, pos, N, M, start, (const int*)order,
+                       sorted, idx, cs, ca);
     SN2_RETURN_LAUNCH();
 }
 

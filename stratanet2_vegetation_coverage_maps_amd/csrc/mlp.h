@@ -31,61 +31,81 @@ __device__ __forceinline__ void dense_t(cfp W, const float (&g)[CO], float (&out
 }
 
 // D[o][k] += sum over the wave's 64 rows r of P[r][o] * Q[r][k], lane r holding row r of P (CO values) and Q (CK values).
-// The rows are staged in a wave-private LDS region ([64][PS] and [64][QS] floats, pad columns stay zero) and contracted
-// with v_mfma_f32_16x16x4_f32 (exact fp32): A[o][r] = P[r][o] is read as lds_p[(4s + lane>>4)*PS + 16*to + (lane&15)],
-// B[r][k] likewise; 16 k-steps cover the 64 rows.  Row strides are == 16 (mod 32) floats so the two 32-lane halves of
-// a ds_read_b32 hit disjoint banks.  Accumulators live in registers for the whole kernel and are flushed once with
-// float atomics (D layout: row = 4*(lane>>4) + reg, col = lane & 15).
-template <int CO, int CK>
+// The rows are staged in a wave-private LDS region ([ROWS][PS] and [ROWS][QS] floats) and contracted with
+// v_mfma_f32_16x16x4_f32 (exact fp32): A[o][r] = P[r][o] is read as lds_p[(4s + lane>>4)*PS + 16*to + (lane&15)],
+// B[r][k] likewise; ROWS/4 k-steps cover ROWS rows, 64/ROWS phases cover the wave (phase h stages the rows of lanes
+// [h*ROWS, (h+1)*ROWS)).  ROWS = 32 or 16 trades a few more (partially masked) ds_write for a 2-4x smaller region: the
+// staging area, not registers, is what limits the waves per CU of the row kernels (head_bwd ran 1 wave per SIMD with
+// ROWS = 64).  Every add writes its full tile columns (values, then zeros up to the tile edge), so the region needs no
+// initialisation and several accumulators can take turns in one region.  Row strides are == 16 (mod 32) floats so the
+// two 32-lane halves of a ds_read_b32 hit disjoint banks.  Accumulators live in registers for the whole kernel and are
+// flushed once (D layout: row = 4*(lane>>4) + reg, col = lane & 15).
+template <int CO, int CK, int ROWS = 64>
 struct OuterAcc {
+    static_assert(ROWS == 64 || ROWS == 32 || ROWS == 16, "ROWS");
     static constexpr int TO = (CO + 15) / 16, TK = (CK + 15) / 16;
     static constexpr int PS = ((TO * 16) % 32 == 0) ? TO * 16 + 16 : TO * 16;
     static constexpr int QS = ((TK * 16) % 32 == 0) ? TK * 16 + 16 : TK * 16;
-    static constexpr int LDS_FLOATS = 64 * (PS + QS);
+    static constexpr int LDS_FLOATS = ROWS * (PS + QS);
     f32x4 acc[TO][TK];
 
-    __device__ __forceinline__ void init(float* lds) {
+    __device__ __forceinline__ void init(float*) {
 #pragma unroll
         for (int a = 0; a < TO; ++a)
 #pragma unroll
             for (int c = 0; c < TK; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int lane = threadIdx.x & 63;
-        for (int i = lane; i < LDS_FLOATS; i += 64) lds[i] = 0.f;
-        __builtin_amdgcn_wave_barrier();
     }
 
     __device__ __forceinline__ void add(float* lds, const float (&p)[CO], const float (&q)[CK]) {
         const int lane = threadIdx.x & 63;
-        float* lp = lds + lane * PS;
-        float* lq = lds + 64 * PS + lane * QS;
-#pragma unroll
-        for (int o = 0; o + 3 < CO; o += 4) *reinterpret_cast<float4*>(lp + o) = make_float4(p[o], p[o + 1], p[o + 2], p[o + 3]);
-#pragma unroll
-        for (int o = CO & ~3; o < CO; ++o) lp[o] = p[o];
-#pragma unroll
-        for (int k = 0; k + 3 < CK; k += 4) *reinterpret_cast<float4*>(lq + k) = make_float4(q[k], q[k + 1], q[k + 2], q[k + 3]);
-#pragma unroll
-        for (int k = CK & ~3; k < CK; ++k) lq[k] = q[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const int row = lane & (ROWS - 1);
+        float* lp = lds + row * PS;
+        float* lq = lds + ROWS * PS + row * QS;
         const int r4 = lane >> 4, c = lane & 15;
         const float* rp = lds + r4 * PS + c;
-        const float* rq = lds + 64 * PS + r4 * QS + c;
+        const float* rq = lds + ROWS * PS + r4 * QS + c;
+#pragma unroll
+        for (int h = 0; h < 64 / ROWS; ++h) {
+            if (ROWS == 64 || (lane / ROWS) == h) {
+#pragma unroll
+                for (int o = 0; o < TO * 16; o += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (o + t < CO) v[t] = p[o + t < CO ? o + t : 0];
+                        else v[t] = 0.f;
+                    }
+                    *reinterpret_cast<float4*>(lp + o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+#pragma unroll
+                for (int k = 0; k < TK * 16; k += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (k + t < CK) v[t] = q[k + t < CK ? k + t : 0];
+                        else v[t] = 0.f;
+                    }
+                    *reinterpret_cast<float4*>(lq + k) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            float av[TO], bv[TK];
+            for (int s = 0; s < ROWS / 4; ++s) {
+                float av[TO], bv[TK];
 #pragma unroll
-            for (int a = 0; a < TO; ++a) av[a] = rp[s * 4 * PS + a * 16];
+                for (int a = 0; a < TO; ++a) av[a] = rp[s * 4 * PS + a * 16];
 #pragma unroll
-            for (int b = 0; b < TK; ++b) bv[b] = rq[s * 4 * QS + b * 16];
+                for (int b = 0; b < TK; ++b) bv[b] = rq[s * 4 * QS + b * 16];
 #pragma unroll
-            for (int a = 0; a < TO; ++a)
+                for (int a = 0; a < TO; ++a)
 #pragma unroll
-                for (int b = 0; b < TK; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < TK; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 
     // add this wave's tile sums into a block-shared LDS image red[CO][CK] (LDS float atomics; the image must be zeroed

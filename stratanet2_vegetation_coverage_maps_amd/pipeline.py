@@ -8,7 +8,7 @@ forward/backward.  That matters on MI355X because FPS is M strictly sequential r
 
 Layout: `slots` = depth+1 sets of persistent buffers (inputs + `PointNet2.alloc_geometry`), `depth` side streams.
 
-    side[j]  : geometry(batch i+depth) -> slot (i+depth) % slots          launched eagerly (about 10 kernels)
+    side[j]  : wait slot_done[slot of batch i-1] ; geometry(batch i+depth) -> that slot     launched eagerly (10 kernels)
     main     : wait geo_ready[slot i] ; features(batch i) = zero_grad, forward, projection, loss, backward
                [; all-reduce of the flat gradient when world > 1] ; Adam ; record slot_done[slot i]
 
@@ -23,23 +23,22 @@ from .optim import allreduce_flat_grad
 
 
 class TrainPipeline:
-    def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True):
+    def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True, n_streams=None):
         """model: PointNet2 (train mode); opt: FlatAdam; slot_inputs: list of depth+1 dicts with device tensors "cloud"
         (B,10,N), "xyz" (B,3,N), "fps_start" (2,B) int32 + whatever `feature_step` needs;
         feature_step(inputs, geometry) -> loss: zero_grad, forward (with cloud_data["geometry"] = geometry),
         projection, loss, backward -- everything of the step except the gradient exchange and the optimiser."""
-        if len(slot_inputs) != depth + 1:
-            raise ValueError("need depth+1 input slots")
+        if len(slot_inputs) < depth + 1:
+            raise ValueError("need at least depth+1 input slots")
         self.model, self.opt, self.feature_step = model, opt, feature_step
         self.inputs = slot_inputs
-        self.depth, self.slots = depth, depth + 1
+        self.depth, self.slots = depth, len(slot_inputs)
         dev = slot_inputs[0]["xyz"].device
         self.dev = dev
         B, _, N = slot_inputs[0]["xyz"].shape
         self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
-        import os
-        prio = int(os.environ.get('SN2_PIPE_PRIO', '0'))
-        self.side = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(depth)]
+        self.n_streams = n_streams or depth
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
         self.geo_ready = [torch.cuda.Event() for _ in range(self.slots)]
         self.slot_done = [None] * self.slots
         self.graph_fb = [None] * self.slots       # zero_grad .. backward
@@ -54,7 +53,7 @@ class TrainPipeline:
     def issue_geometry(self, i=None):
         i = self.issued if i is None else i
         k = i % self.slots
-        st = self.side[i % self.depth]
+        st = self.side[i % self.n_streams]
         if self.slot_done[k] is not None:
             st.wait_event(self.slot_done[k])      # the feature pass that last read this slot's tables has finished
         else:
@@ -135,8 +134,8 @@ class TrainPipeline:
         ev.record(main)
         self.slot_done[k] = ev
         self.done = i + 1
-        # the slot of batch i+depth was last read by batch i-1 (slots = depth+1): its tables are free now
-        if self.issued < self.done + self.depth:
+        # geometry of batch i+depth goes into the slot whose tables batch i+depth-slots (= i-1 when slots = depth+1) read
+        while self.issued < self.done + self.depth:
             self.issue_geometry(self.issued)
         return loss
 
