@@ -76,9 +76,14 @@ int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, in
 
 /* k nearest sources (k = 1..3) + inverse squared distance weights -- the no_grad part of
  * torch_geometric.nn.knn_interpolate, model/point_net2.py:63.
- * idx (B*T,3), w (B*T,3): w = 1/max(d2,1e-16); unused slots (k<3 or S<k) get w = 0 and idx = idx[0]. */
+ * idx (B*T,3), w (B*T,3): w = 1/max(d2,1e-16); unused slots (k<3 or S<k) get w = 0 and idx = idx[0].
+ * ws + dst_fps_ws (optional, both or neither): ws = 16-byte aligned workspace of SN2_THREE_NN_WS_WORDS(B,S) 32-bit words,
+ * dst_fps_ws = the workspace sn2_fps filled for the TARGET points (same B, N = T > 2048).  With them (and 128 <= S <= 8192)
+ * a wave takes 64 spatially adjacent targets and searches a per-plot x,y grid of the sources instead of scanning all S
+ * (same result, bit for bit); results are still written at the targets' original positions. */
+#define SN2_THREE_NN_WS_WORDS(B, S) ((size_t)(B) * (4 * (size_t)(S) + 1032))
 int sn2_three_nn(const float *src_soa, int B, int S, const float *dst_soa, int T, int k, int *idx, float *w,
-                 void *stream);
+                 void *ws, const int *dst_fps_ws, void *stream);
 
 /* ---- set abstraction: gather + shared MLP + BN + max -- SAModule/PointConv, model/point_net2.py:19,21-29 --- */
 typedef struct sn2_sa {

@@ -760,10 +760,209 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__
     w[o + 2] = u2 ? 1.0f / fmaxf(d2, 1e-16f) : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Grid 3-NN (exact), for targets that FPS already put into Morton order (FP1: the targets are the plot's points).
+// The plot's S sources are binned once into a G x G grid over their x,y bounding box (nn_grid_build_kernel: LDS counting
+// sort -> a table of (x, y, z, source index) in cell order + the cell starts).  One wave takes 64 consecutive SORTED
+// targets -- neighbours in space -- and treats them as one query box: it visits the cells under the box, then square
+// rings of growing radius rho around it, every lane testing every visited source (wave-uniform loops, LDS broadcast
+// reads; a per-lane walk of each lane's own cells was tried first and lost to the brute-force scan: a wave runs as long
+// as its worst lane at every cell).  It stops when the largest k-th best squared distance of its lanes is below what any
+// unvisited source can reach: such a source lies in a cell more than rho columns or rows away from the cells of ALL the
+// wave's targets, so its x or y gap -- hence its distance -- to each of them exceeds rho cell widths (taken 0.1 % short
+// and minus 1e-4 m, which covers the fp32 rounding of the cell assignment and of sn2_d2).  Candidates arrive in arbitrary
+// index order, so the running best three are kept in (d2, index) lexicographic order: exactly the brute-force scan's
+// "ascending index, strict <" result, bit for bit.  ~50-150 distance evaluations per target instead of S = 1024.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int NN_GMAX = 32;
+constexpr int NN_HDR = NN_GMAX * NN_GMAX + 1 + 7;   // cell starts (G*G+1), then x0, y0, inv_x, inv_y, min cell width, G (as int), pad
+
+__global__ __launch_bounds__(256) void nn_grid_build_kernel(const float* __restrict__ src, int S, int G,
+                                                            float4* __restrict__ tbl, int* __restrict__ hdr) {
+    __shared__ int s_hist[NN_GMAX * NN_GMAX + 1];
+    __shared__ float s_mm[4][4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sx = src + (size_t)b * 3 * S;
+    const float* sy = sx + S;
+    const float* sz = sy + S;
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = tid; i < S; i += 256) {
+        mnx = fminf(mnx, sx[i]); mxx = fmaxf(mxx, sx[i]);
+        mny = fminf(mny, sy[i]); mxy = fmaxf(mxy, sy[i]);
+    }
+    mnx = wave_min(mnx); mny = wave_min(mny); mxx = wave_max(mxx); mxy = wave_max(mxy);
+    if (lane == 0) { s_mm[0][wave] = mnx; s_mm[1][wave] = mny; s_mm[2][wave] = mxx; s_mm[3][wave] = mxy; }
+    for (int i = tid; i <= G * G; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const float x0 = fminf(fminf(s_mm[0][0], s_mm[0][1]), fminf(s_mm[0][2], s_mm[0][3]));
+    const float y0 = fminf(fminf(s_mm[1][0], s_mm[1][1]), fminf(s_mm[1][2], s_mm[1][3]));
+    const float x1 = fmaxf(fmaxf(s_mm[2][0], s_mm[2][1]), fmaxf(s_mm[2][2], s_mm[2][3]));
+    const float y1 = fmaxf(fmaxf(s_mm[3][0], s_mm[3][1]), fmaxf(s_mm[3][2], s_mm[3][3]));
+    const float ex = fmaxf(x1 - x0, 1e-6f), ey = fmaxf(y1 - y0, 1e-6f);
+    const float ix = (float)G / ex, iy = (float)G / ey;
+    auto cell_of = [&](int i) {
+        int cx = (int)((sx[i] - x0) * ix), cy = (int)((sy[i] - y0) * iy);
+        cx = cx < 0 ? 0 : (cx > G - 1 ? G - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > G - 1 ? G - 1 : cy);
+        return cy * G + cx;
+    };
+    for (int i = tid; i < S; i += 256) atomicAdd(&s_hist[cell_of(i)], 1);
+    __syncthreads();
+    {   // exclusive scan over the <= 1024 cells: 4 consecutive cells per thread, wave scan, 4 wave totals
+        __shared__ int s_wsum[4];
+        int loc[4], sum = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            loc[c] = (tid * 4 + c < G * G) ? s_hist[tid * 4 + c] : 0;
+            sum += loc[c];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int k = 0; k < wave; ++k) run += s_wsum[k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (tid * 4 + c < G * G) s_hist[tid * 4 + c] = run;
+            run += loc[c];
+        }
+        if (tid == 255) s_hist[G * G] = run;     // = S: thread 255 ends the scan whatever G is (empty tail cells add 0)
+    }
+    __syncthreads();
+    int* hb = hdr + (size_t)b * NN_HDR;
+    for (int i = tid; i <= G * G; i += 256) hb[i] = s_hist[i];
+    if (tid == 0) {
+        float* hf = reinterpret_cast<float*>(hb + NN_GMAX * NN_GMAX + 1);
+        hf[0] = x0; hf[1] = y0; hf[2] = ix; hf[3] = iy; hf[4] = fminf(ex, ey) / (float)G;
+        hb[NN_GMAX * NN_GMAX + 1 + 5] = G;
+    }
+    __syncthreads();
+    float4* tb = tbl + (size_t)b * S;
+    for (int i = tid; i < S; i += 256) {
+        const int p = atomicAdd(&s_hist[cell_of(i)], 1);
+        tb[p] = make_float4(sx[i], sy[i], sz[i], __int_as_float(i));
+    }
+}
+
+__global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __restrict__ tbl, const int* __restrict__ hdr, int S,
+                                                            int T, int k, const int* __restrict__ dst_order,
+                                                            const float4* __restrict__ dst_sorted,
+                                                            int* __restrict__ idx, float* __restrict__ w) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_tbl[];      // S entries, then the cell starts
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int* hb = hdr + (size_t)b * NN_HDR;
+    const int G = __builtin_amdgcn_readfirstlane(hb[NN_GMAX * NN_GMAX + 1 + 5]);
+    int* s_cell = reinterpret_cast<int*>(s_tbl + S);
+    for (int i = threadIdx.x; i < S; i += 256) s_tbl[i] = tbl[(size_t)b * S + i];
+    for (int i = threadIdx.x; i <= G * G; i += 256) s_cell[i] = hb[i];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;                        // sorted position
+    if (p - lane >= T) return;                                           // whole wave past the end
+    const bool valid = p < T;
+    const float* hf = reinterpret_cast<const float*>(hb + NN_GMAX * NN_GMAX + 1);
+    const float x0 = hf[0], y0 = hf[1], ix = hf[2], iy = hf[3], cw = hf[4];
+    const float4 q = dst_sorted[(size_t)b * T + (valid ? p : T - 1)];
+    const float qx = q.x, qy = q.y, qz = q.z;
+    // the cells under the wave's targets (clamped like the sources' cells; the cell function is monotone)
+    auto cell1 = [&](float v, float o, float inv) {
+        int c = (int)((v - o) * inv);
+        return (v - o < 0.f || c < 0) ? 0 : (c > G - 1 ? G - 1 : c);
+    };
+    const int bx0 = __builtin_amdgcn_readfirstlane(cell1(wave_min(qx), x0, ix)),
+              bx1 = __builtin_amdgcn_readfirstlane(cell1(wave_max(qx), x0, ix));
+    const int by0 = __builtin_amdgcn_readfirstlane(cell1(wave_min(qy), y0, iy)),
+              by1 = __builtin_amdgcn_readfirstlane(cell1(wave_max(qy), y0, iy));
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
+    const int kk = k < S ? k : S;          // slots that will be filled
+    for (int rho = 0;; ++rho) {
+        const int xl = bx0 - rho, xh = bx1 + rho, yl = by0 - rho, yh = by1 + rho;
+        const int cxl = xl < 0 ? 0 : xl, cxh = xh > G - 1 ? G - 1 : xh;
+        for (int cy = (yl < 0 ? 0 : yl); cy <= (yh > G - 1 ? G - 1 : yh); ++cy) {
+            // a new row of the rectangle is one segment of contiguous cells; an old row contributes its two new end cells
+            const bool whole = rho == 0 || cy == yl || cy == yh;
+            for (int sg = 0; sg < (whole ? 1 : 2); ++sg) {
+                int c_lo, c_hi;
+                if (whole) {
+                    c_lo = cy * G + cxl; c_hi = cy * G + cxh;
+                } else if (sg == 0) {
+                    if (xl < 0) continue;
+                    c_lo = c_hi = cy * G + xl;
+                } else {
+                    if (xh > G - 1) continue;
+                    c_lo = c_hi = cy * G + xh;
+                }
+                // wave-uniform bounds in SGPRs: scalar loop control and one broadcast LDS read per candidate; the common
+                // case (the candidate beats nobody's third best) is 8 VALU ops, one compare and one branch.  (Written
+                // inline, not as a lambda: called through a closure the best-three state ended up in scratch memory.)
+                const int p_lo = __builtin_amdgcn_readfirstlane(s_cell[c_lo]), p_hi = __builtin_amdgcn_readfirstlane(s_cell[c_hi + 1]);
+                float4 cn = s_tbl[p_lo];                                  // one candidate ahead: its LDS latency hides
+                for (int s = p_lo; s < p_hi; ++s) {                      // behind the previous candidate's arithmetic
+                    const float4 c = cn;
+                    cn = s_tbl[s + 1];                                   // (the table is followed by the cell starts: in bounds)
+                    const float dd = sn2_d2(c.x, c.y, c.z, qx, qy, qz);
+                    if (dd <= d2) {
+                        const int ii = __float_as_int(c.w);
+                        if (dd < d2 || ii < i2) {
+                            if (dd < d1 || (dd == d1 && ii < i1)) {
+                                d2 = d1; i2 = i1;
+                                if (dd < d0 || (dd == d0 && ii < i0)) {
+                                    d1 = d0; i1 = i0; d0 = dd; i0 = ii;
+                                } else {
+                                    d1 = dd; i1 = ii;
+                                }
+                            } else {
+                                d2 = dd; i2 = ii;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (xl <= 0 && yl <= 0 && xh >= G - 1 && yh >= G - 1) break;     // the whole grid has been visited
+        const float reach = (float)rho * cw * 0.999f - 1e-4f;           // nothing unvisited is closer than this
+        const float dk = kk >= 3 ? d2 : (kk == 2 ? d1 : d0);
+        const float worst = wave_max(valid ? dk : 0.f);
+        if (reach > 0.f && worst < reach * reach) break;
+    }
+    if (!valid) return;
+    const int t = dst_order[(size_t)b * T + p];
+    const size_t o = ((size_t)b * T + t) * 3;
+    const bool u1 = (k >= 2) && (i1 != 0x7FFFFFFF), u2 = (k >= 3) && (i2 != 0x7FFFFFFF);
+    idx[o + 0] = i0;
+    idx[o + 1] = u1 ? i1 : i0;
+    idx[o + 2] = u2 ? i2 : i0;
+    w[o + 0] = 1.0f / fmaxf(d0, 1e-16f);
+    w[o + 1] = u1 ? 1.0f / fmaxf(d1, 1e-16f) : 0.f;
+    w[o + 2] = u2 ? 1.0f / fmaxf(d2, 1e-16f) : 0.f;
+}
+
 extern "C" int sn2_three_nn(const float* src_soa, int B, int S, const float* dst_soa, int T, int k, int* idx, float* w,
-                            void* stream) {
+                            void* ws, const int* dst_fps_ws, void* stream) {
     if (!src_soa || !dst_soa || !idx || !w || B <= 0 || S <= 0 || T <= 0 || k < 1 || k > 3) return SN2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // grid search: needs the targets in the spatial order sn2_fps built for them (workspace laid out as there)
+    if (ws && dst_fps_ws && S >= 128 && S <= 8192 && T > 2048 && (((size_t)B * T) % 4 == 0) && (((size_t)ws) % 16 == 0)) {
+        int G = (int)sqrtf((float)S / 4.f);   // about 4 sources per cell
+        G = G < 2 ? 2 : (G > NN_GMAX ? NN_GMAX : G);
+        float4* tbl = reinterpret_cast<float4*>(ws);
+        int* hdr = reinterpret_cast<int*>(tbl + (size_t)B * S);
+        hipLaunchKernelGGL(nn_grid_build_kernel, dim3(B), dim3(256), 0, st, src_soa, S, G, tbl, hdr);
+        const size_t lds = (size_t)S * 16 + (size_t)(G * G + 1) * 4;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&three_nn_grid_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(three_nn_grid_kernel, dim3(sn2_cdiv(T, 256), B), dim3(256), lds, st, (const float4*)tbl,
+                           (const int*)hdr, S, T, k, dst_fps_ws, reinterpret_cast<const float4*>(dst_fps_ws + (size_t)B * T),
+                           idx, w);
+        SN2_RETURN_LAUNCH();
+    }
     dim3 grid(sn2_cdiv(T, 256), B);
-    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, src_soa, S, dst_soa, T, k, idx, w);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, st, src_soa, S, dst_soa, T, k, idx, w);
     SN2_RETURN_LAUNCH();
 }

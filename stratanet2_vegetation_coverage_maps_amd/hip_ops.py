@@ -183,9 +183,18 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
     return nbr, cnt, total
 
 
-def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int, out=None):
+def three_nn_ws_words(B: int, S: int) -> int:
+    """SN2_THREE_NN_WS_WORDS of include/strata_hip.h."""
+    return B * (4 * S + 1032)
+
+
+def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int, out=None, grid: bool = True, ws=None,
+             dst_fps_ws: Optional[torch.Tensor] = None):
     """-> idx (B*T,3) int32 local source indices, w (B*T,3) = 1/max(d2,1e-16) (0 on unused slots).
-    out = (idx, w): caller-owned result buffers."""
+    out = (idx, w): caller-owned result buffers.
+    dst_fps_ws: the workspace `fps(..., return_ws=True)` filled for the TARGET points: enables the grid search (waves of
+    spatially adjacent targets; same result); ws: caller-owned workspace of three_nn_ws_words(B, S) int32 for it
+    (allocated here when None); grid=False forces the full scan (cross-checks)."""
     B, _, S = src_soa.shape
     T = dst_soa.shape[2]
     _chk(src_soa, F32, (B, 3, S), "src_soa")
@@ -198,7 +207,16 @@ def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int, out=None):
     else:
         idx = torch.empty(B * T, 3, dtype=I32, device=dev)
         w = torch.empty(B * T, 3, dtype=F32, device=dev)
-    _call("sn2_three_nn", _ptr(src_soa), B, S, _ptr(dst_soa), T, k, _ptr(idx), _ptr(w), _stream(), tag=f"T={T}")
+    if grid and dst_fps_ws is not None and 128 <= S <= 8192 and T > 2048:
+        if ws is None:
+            ws = torch.empty(three_nn_ws_words(B, S), dtype=I32, device=dev)
+        else:
+            _chk(ws, I32, (three_nn_ws_words(B, S),), "ws")
+        _chk(dst_fps_ws, I32, (fps_ws_words(B, T),), "dst_fps_ws")
+    else:
+        ws = dst_fps_ws = None
+    _call("sn2_three_nn", _ptr(src_soa), B, S, _ptr(dst_soa), T, k, _ptr(idx), _ptr(w), _ptr(ws), _ptr(dst_fps_ws), _stream(),
+          tag=f"T={T}")
     return idx, w
 
 

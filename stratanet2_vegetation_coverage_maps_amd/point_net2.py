@@ -205,6 +205,7 @@ class PointNet2(nn.Module):
         g.knn2 = (e(B * M1, 3, dt=I32), e(B * M1, 3))
         g.knn1 = (e(B * N, 3, dt=I32), e(B * N, 3))
         g.tot1, g.tot2 = g.totals[0:1], g.totals[1:2]
+        g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S), dt=I32) if 128 <= S <= 8192 else None for S in (M2, M1))
         g.ready = None
         return g
 
@@ -228,8 +229,8 @@ class PointNet2(nn.Module):
             ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, g.tot2, fps_ws=g.ws2,
                            out=(g.nbr2, g.cnt2))
             ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
-            ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2)
-            ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1)
+            ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[0], dst_fps_ws=g.ws2)
+            ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1], dst_fps_ws=g.ws1)
             return g
         g = _Saved()
         g.B, g.N, g.M1, g.M2, g.xyz = B, N, M1, M2, xyz
@@ -241,8 +242,8 @@ class PointNet2(nn.Module):
                                                 fps_ws=ws2)
         pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)      # GlobalSAModule: pos = zeros (point_net2.py:40)
         g.knn3 = ops.three_nn(pos3, g.pos2_soa, 1)
-        g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3)
-        g.knn1 = ops.three_nn(g.pos1_soa, xyz, 3)
+        g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3, dst_fps_ws=ws2)
+        g.knn1 = ops.three_nn(g.pos1_soa, xyz, 3, dst_fps_ws=ws1)
         return g
 
     def prefetch_geometry(self, cloud_data):
@@ -288,7 +289,7 @@ class PointNet2(nn.Module):
         elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
             raise ValueError("prefetched geometry does not match this batch")
         s = _Saved()
-        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream", "ws1", "ws2", "totals")})
+        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws")})
         s.xyz = xyz
         # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd and the per-workgroup statistics
         # slots (written before they are read: no zero fill)

@@ -106,6 +106,27 @@ def test_three_nn_matches_oracle(B, S, T, k):
         assert torch.all(w[:, kk:] == 0) and torch.equal(idx[:, kk:], idx[:, :1].expand(-1, 3 - kk))
 
 
+@pytest.mark.parametrize("B,S,T,k", [(2, 1024, 32768, 3), (4, 256, 4096, 3), (2, 2500, 10000, 3), (4, 128, 2051, 2),
+                                     (2, 625, 2500, 1)])
+def test_grid_three_nn_equals_full_scan(B, S, T, k):
+    """The grid walk returns the full scan's table bit for bit: same indices (lowest index on ties), same weights.
+    Sources = an FPS-like subset of the targets plus duplicates; some targets lie outside the sources' bounding box."""
+    xyz, _ = _pos(B, T, first=77)
+    g = torch.Generator().manual_seed(S)
+    pick = torch.stack([torch.randperm(T, generator=g)[:S] for _ in range(B)])
+    src = torch.gather(xyz, 2, pick.unsqueeze(1).expand(-1, 3, -1)).contiguous()
+    src[:, :, 5] = src[:, :, 9]                       # duplicated sources: exact ties, lowest index must win
+    src[:, :, S // 2] = src[:, :, S // 2 + 1]
+    dst = xyz.clone()
+    dst[:, :2, :50] *= 1.7                            # targets outside the sources' x,y range
+    dst[:, 2, 50:100] += 30.0                         # and far above them (many rings)
+    _, _, _, fws = ops.fps(dst.to(DEV), 64, None, return_ws=True)      # the targets' Morton order
+    a_i, a_w = ops.three_nn(src.to(DEV), dst.to(DEV), k, dst_fps_ws=fws)
+    b_i, b_w = ops.three_nn(src.to(DEV), dst.to(DEV), k, grid=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a_i, b_i) and torch.equal(a_w, b_w)
+
+
 @pytest.mark.parametrize("B,N,M,r,cap", [(2, 32768, 1024, 1.0, 2000), (2, 4096, 512, 2 ** 0.5, 2000), (1, 8192, 64, 4.0, 300),
                                          (2, 5000, 100, 2.0, 2000)])
 def test_grid_ball_query_equals_full_scan_and_oracle(B, N, M, r, cap):
