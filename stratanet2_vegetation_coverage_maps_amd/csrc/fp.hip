@@ -364,21 +364,28 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(int n_src, int R_per
     const float* dub = du + (size_t)b * R_per_plot * CA;
     const bool on = lane < CA;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-    int i = 0;
-    for (; i + 4 <= n; i += 4) {   // four independent row loads in flight
-        const int r0 = inv_row[st + i], r1 = inv_row[st + i + 1], r2 = inv_row[st + i + 2], r3 = inv_row[st + i + 3];
-        const float w0 = inv_w[st + i], w1 = inv_w[st + i + 1], w2 = inv_w[st + i + 2], w3 = inv_w[st + i + 3];
-        const float v0 = on ? dub[(size_t)r0 * CA + lane] : 0.f, v1 = on ? dub[(size_t)r1 * CA + lane] : 0.f;
-        const float v2 = on ? dub[(size_t)r2 * CA + lane] : 0.f, v3 = on ? dub[(size_t)r3 * CA + lane] : 0.f;
-        g0 = fmaf(w0, v0, g0);
-        g1 = fmaf(w1, v1, g1);
-        g2 = fmaf(w2, v2, g2);
-        g3 = fmaf(w3, v3, g3);
-    }
-    for (; i < n; ++i) {
-        const int r0 = inv_row[st + i];
-        const float w0 = inv_w[st + i];
-        g0 = fmaf(w0, on ? dub[(size_t)r0 * CA + lane] : 0.f, g0);
+    // The list is ~96 entries long and every entry is one 136-byte row somewhere in a 70 MB array: pure latency.  64 list
+    // entries are fetched with one coalesced load (lane j keeps entry j, broadcast by v_readlane), then eight independent
+    // row loads are in flight at a time (four gave 1.7 TB/s).
+    for (int base = 0; base < n; base += 64) {
+        const int m = (n - base) < 64 ? (n - base) : 64;
+        const int rj = lane < m ? inv_row[st + base + lane] : 0;          // entries past the end: row 0 with weight 0
+        const float wj = lane < m ? inv_w[st + base + lane] : 0.f;
+        for (int i = 0; i < m; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = __builtin_amdgcn_readlane(rj, i + u);
+                v[u] = on ? dub[(size_t)r * CA + lane] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                g0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), i + u)), v[u], g0);
+                g1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), i + u + 1)), v[u + 1], g1);
+                g2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), i + u + 2)), v[u + 2], g2);
+                g3 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), i + u + 3)), v[u + 3], g3);
+            }
+        }
     }
     if (on) dsrc[(size_t)s * dsrc_stride + lane] += (g0 + g1) + (g2 + g3);
 }
