@@ -170,6 +170,17 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
     float* lds = smem + (threadIdx.x >> 6) * Acc::LDS_FLOATS;
     Acc acc;
     acc.init(lds);
+    // W as the B operand of the input-gradient product: lane (qq, cc) keeps W[o = 4 kb + qq][col = 16 jt + cc]
+    constexpr int KBO = (CO + 3) / 4, TJ = (CI + 15) / 16;
+    const int qq = (threadIdx.x & 63) >> 4, cc = threadIdx.x & 15;
+    float Wb[KBO][TJ];
+#pragma unroll
+    for (int kb = 0; kb < KBO; ++kb)
+#pragma unroll
+        for (int jt = 0; jt < TJ; ++jt) {
+            const int o = 4 * kb + qq, col = 16 * jt + cc;
+            Wb[kb][jt] = (o < CO && col < CI) ? Wg[o * CI + col] : 0.f;
+        }
     const long nthreads = (long)gridDim.x * WAVES * 64;
     const long rounds = (R + nthreads - 1) / nthreads;  // every lane of a wave runs the same number of rounds
     for (long it = 0; it < rounds; ++it) {
@@ -199,49 +210,46 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
                 }
             }
         }
-        acc.add(lds, dp, u);
-        if (!valid) continue;
-        // input gradient
-        if (du_out) {
+        // weight gradient: dW += dp^T [u | 1] over the wave's rows.  Input gradient: d[u] = dp W over the same staged dp
+        // rows, also on the matrix cores -- A[row][o] read back from the staging region, B[o][col] = W in registers for the
+        // whole kernel (as per-lane FMA chains this product was ~1400 FMAs per row fed by ~300 scalar loads of 16 dwords,
+        // and the waves spent most of their time waiting for those loads).
+        const long wave_row0 = it * nthreads + (long)blockIdx.x * WAVES * 64 + (threadIdx.x & ~63);
+        acc.add_then(lds, dp, u, [&](int hph) __attribute__((always_inline)) {
+            if (!du_out && !(CB > 0 && dskip)) return;
 #pragma unroll
-            for (int k4 = 0; k4 < CA; k4 += 4) {
-                float v[4];
+            for (int t = 0; t < Acc::STAGED_ROWS / 16; ++t) {
+                f32x4 D[TJ];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float a = 0.f;
-                    if (k4 + t < CA) {
+                for (int jt = 0; jt < TJ; ++jt) D[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int o = 0; o < CO; ++o) a = fmaf(W[o * CI + k4 + t], dp[o], a);
-                    }
-                    v[t] = a;
+                for (int kb = 0; kb < KBO; ++kb) {
+                    const float av = lds[(16 * t + cc) * Acc::PS + 4 * kb + qq];
+#pragma unroll
+                    for (int jt = 0; jt < TJ; ++jt) D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wb[kb][jt], D[jt], 0, 0, 0);
                 }
-                float* dst = du_out + rr * du_stride + k4;
-                if constexpr (KNN) {
-                    if constexpr (CA % 4 == 0) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (k4 + t < CA) dst[t] = v[t];
+                for (int r = 0; r < 4; ++r) {
+                    const long row = wave_row0 + hph * Acc::STAGED_ROWS + 16 * t + 4 * qq + r;
+                    if (row >= R) continue;
+#pragma unroll
+                    for (int jt = 0; jt < TJ; ++jt) {
+                        const int col = 16 * jt + cc;
+                        if (col < CA) {
+                            if (du_out) {
+                                float* dst = du_out + (size_t)row * du_stride + col;
+                                if constexpr (KNN) *dst = D[jt][r];
+                                else *dst += D[jt][r];
+                            }
+                        } else if (col < CI) {
+                            if constexpr (CB > 0) {
+                                if (dskip) dskip[(size_t)row * dskip_stride + (col - CA)] += D[jt][r];
+                            }
+                        }
                     }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (k4 + t < CA) dst[t] += v[t];
                 }
             }
-        }
-        if constexpr (CB > 0) {
-            if (dskip) {
-#pragma unroll
-                for (int k = 0; k < CB; ++k) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int o = 0; o < CO; ++o) a = fmaf(W[o * CI + CA + k], dp[o], a);
-                    dskip[rr * dskip_stride + k] += a;
-                }
-            }
-        }
+        });
     }
     // workgroup-level reduction of the [dW | db] image, then one global atomic per element and workgroup
     float* red = smem;

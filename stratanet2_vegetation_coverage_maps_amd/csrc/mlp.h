@@ -47,6 +47,7 @@ struct OuterAcc {
     static constexpr int PS = ((TO * 16) % 32 == 0) ? TO * 16 + 16 : TO * 16;
     static constexpr int QS = ((TK * 16) % 32 == 0) ? TK * 16 + 16 : TK * 16;
     static constexpr int LDS_FLOATS = ROWS * (PS + QS);
+    static constexpr int STAGED_ROWS = ROWS;
     f32x4 acc[TO][TK];
 
     __device__ __forceinline__ void init(float*) {
@@ -57,6 +58,13 @@ struct OuterAcc {
     }
 
     __device__ __forceinline__ void add(float* lds, const float (&p)[CO], const float (&q)[CK]) {
+        add_then(lds, p, q, [](int) {});
+    }
+
+    // as add(); `after(h)` runs while phase h's rows (lanes [h*ROWS, (h+1)*ROWS) of the wave) are still staged: the P rows
+    // are at lds[row * PS + o], row = lane % ROWS -- a second contraction over them (the input gradient) needs no restaging
+    template <class F>
+    __device__ __forceinline__ void add_then(float* lds, const float (&p)[CO], const float (&q)[CK], F after) {
         const int lane = threadIdx.x & 63;
         const int row = lane & (ROWS - 1);
         float* lp = lds + row * PS;
@@ -103,6 +111,7 @@ struct OuterAcc {
                     for (int b = 0; b < TK; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
             }
+            after(h);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
