@@ -512,14 +512,39 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
             for (int c = 0; c < TK; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, rq[st * 4 * QS + c * 16], acc[c], 0, 0, 0);
         }
     }
-    // partial input gradient of this channel group
+    // partial input gradient of this channel group, dp_g (64 x 16) . W_g (16 x CI), on the matrix cores: A[row][o] read
+    // back from this wave's staged dp rows, B[o][col] = the group's weight rows in registers (as per-lane FMA chains with
+    // scalar-loaded weights this was the longest part of the kernel: 16 x 96 FMAs per lane for FP3)
+    {
+        constexpr int TJ = (CI + 15) / 16;
+        const int qq = lane >> 4, cc = lane & 15;
+        float Wb[4][TJ];
 #pragma unroll
-    for (int k = 0; k < CI; ++k) {
-        float a = 0.f;
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int t = 0; t < COG; ++t)
-            if (g * COG + t < CO) a = fmaf(W[(g * COG + t) * CI + k], dp[t], a);
-        s_du[(g * 64 + lane) * CIP + k] = a;
+            for (int jt = 0; jt < TJ; ++jt) {
+                const int t = 4 * kb + qq, o = g * COG + t, col = 16 * jt + cc;
+                Wb[kb][jt] = (t < COG && o < CO && col < CI) ? W[o * CI + col] : 0.f;
+            }
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            f32x4 D[TJ];
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt) D[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const float av = s_p[(g * 64 + 16 * tile + cc) * 16 + 4 * kb + qq];
+#pragma unroll
+                for (int jt = 0; jt < TJ; ++jt) D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wb[kb][jt], D[jt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 16 * jt + cc;
+                    if (col < CI) s_du[(g * 64 + 16 * tile + 4 * qq + r) * CIP + col] = D[jt][r];
+                }
+        }
     }
     __syncthreads();
     auto du_sum = [&](int row, int k) {
