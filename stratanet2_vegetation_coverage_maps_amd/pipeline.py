@@ -23,7 +23,8 @@ from .optim import allreduce_flat_grad
 
 
 class TrainPipeline:
-    def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True, n_streams=None):
+    def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True, n_streams=None,
+                 split_exchange=None):
         """model: PointNet2 (train mode); opt: FlatAdam; slot_inputs: list of depth+1 dicts with device tensors "cloud"
         (B,10,N), "xyz" (B,3,N), "fps_start" (2,B) int32 + whatever `feature_step` needs;
         feature_step(inputs, geometry) -> loss: zero_grad, forward (with cloud_data["geometry"] = geometry),
@@ -48,6 +49,9 @@ class TrainPipeline:
         self.issued = 0                           # geometry passes launched so far
         self.done = 0                             # feature passes launched so far
         self.use_graph = use_graph
+        # exchange between the backward graph and the Adam graph (always when world > 1; can be forced on one GPU to
+        # exercise exactly the launch sequence the multi-GPU run uses)
+        self.split_exchange = (getattr(opt, "world_size", 1) > 1) if split_exchange is None else bool(split_exchange)
 
     # ---- geometry of batch number i (its inputs must already be in slot i % slots)
     def issue_geometry(self, i=None):
@@ -95,10 +99,10 @@ class TrainPipeline:
             with torch.cuda.graph(g, pool=pool):
                 self.loss[k] = self.feature_step(self.inputs[k], self.geo[k])
                 self.flat_grad[k] = self.model._last_flat_grad
-                if world == 1:
+                if not self.split_exchange:
                     self._exchange_and_update(k)  # no exchange: Adam rides in the same graph
             self.graph_fb[k] = g
-            if world > 1:
+            if self.split_exchange:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, pool=pool):
                     ops.adam_step(self.opt.flat, self.flat_grad[k], self.opt.exp_avg, self.opt.exp_avg_sq, self.opt.lr,

@@ -39,8 +39,8 @@ def _setup(N, B, depth):
     return model, opt, slots, feature_step
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_pipeline_matches_plain_loop(use_graph):
+@pytest.mark.parametrize("use_graph,split", [(False, False), (True, False), (True, True)])
+def test_pipeline_matches_plain_loop(use_graph, split):
     N, B, depth, steps = 4096, 2, 2, 7
     model, opt, slots, fstep = _setup(N, B, depth)
     ref_losses = []
@@ -52,7 +52,7 @@ def test_pipeline_matches_plain_loop(use_graph):
     ref_rm = model.fp1_module.nn[0][2].running_mean.clone()
 
     model2, opt2, slots2, fstep2 = _setup(N, B, depth)
-    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=use_graph)
+    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=use_graph, split_exchange=split)
     pipe.capture()
     # capture() warms each slot with feature passes that update the BN running statistics but not the weights; reset
     # the model/optimiser state so both loops start equal
