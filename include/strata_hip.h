@@ -95,6 +95,7 @@ typedef struct sn2_sa {
     const float *cpos;              /* centroid positions AoS4 (B*M,4)                                          */
     const int *nbr, *cnt;           /* from sn2_ball_query                                                      */
     const unsigned long long *total;/* number of messages E (device)                                            */
+    const int *order;               /* from sn2_sa_order, or NULL: quads of consecutive centroids                      */
     sn2_block blk[2];
     float *ext; int *arg;           /* (B*M,cout): signed extremum of the last block's pre-BN activation and the
                                        neighbour slot attaining it                                              */
@@ -102,6 +103,16 @@ typedef struct sn2_sa {
     const float *dout;              /* backward in : d loss / d out (B*M,cout)                                  */
     float *dfeat;                   /* backward out: ACCUMULATED d loss / d feat (B*Nsrc,cf) or NULL            */
 } sn2_sa;
+/* Work items of the SA passes (position-only: part of the geometry pass).  A wave step is four 16-message tiles: a
+ * centroid with more than SN2_SA_SOLO_MIN neighbours takes all four (a solo item), the others share a step four at a time
+ * (a quad: ranks 4k..4k+3 of the plot's centroids by DESCENDING neighbour count, ties by ascending id -- deterministic).
+ * Item k of plot b sits at position k*B + b, i.e. heaviest first across plots.  order: SN2_SA_ORDER_WORDS(B,M) ints = 4
+ * per position (solo: id | SN2_SA_SOLO_FLAG four times; quad: four ids; -1 = none) + a 4-int trailer whose first word is
+ * the largest item count of any plot.  (Ball sizes at C2: median 5, mean 25, maximum 261.) */
+#define SN2_SA_SOLO_MIN 48
+#define SN2_SA_SOLO_FLAG 0x40000000
+#define SN2_SA_ORDER_WORDS(B, M) ((size_t)4 * (B) * (M) + 4)
+int sn2_sa_order(const int *cnt, int B, int M, int *order, void *stream);
 int sn2_sa_forward(const sn2_sa *p, int training, void *stream);
 int sn2_sa_backward(const sn2_sa *p, void *stream);
 

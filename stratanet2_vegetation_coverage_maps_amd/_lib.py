@@ -22,7 +22,8 @@ class Block(Structure):  # sn2_block
 class SA(Structure):  # sn2_sa
     _fields_ = [("B", c_int), ("Nsrc", c_int), ("M", c_int), ("cap", c_int), ("cf", c_int), ("nl", c_int),
                 ("feat", c_void_p), ("feat_stride", c_int), ("spos", c_void_p), ("spos_stride", c_int),
-                ("cpos", c_void_p), ("nbr", c_void_p), ("cnt", c_void_p), ("total", c_void_p), ("blk", Block * 2),
+                ("cpos", c_void_p), ("nbr", c_void_p), ("cnt", c_void_p), ("total", c_void_p), ("order", c_void_p),
+                ("blk", Block * 2),
                 ("ext", c_void_p), ("arg", c_void_p), ("out", c_void_p), ("dout", c_void_p), ("dfeat", c_void_p)]
 
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "sn2_ball_query": [c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_void_p],
     "sn2_three_nn": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sn2_sa_order": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sn2_sa_forward": [POINTER(SA), c_int, c_void_p],
     "sn2_sa_backward": [POINTER(SA), c_void_p],
     "sn2_fp_forward": [POINTER(FP), c_int, c_void_p],

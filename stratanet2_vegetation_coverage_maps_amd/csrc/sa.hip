@@ -104,6 +104,53 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------
+// Work items of the SA passes.  A wave step is four 16-message tiles.  A centroid with more than SN2_SA_SOLO_MIN
+// neighbours takes all four tiles itself (a SOLO item: 64 messages per step); the others are ranked by descending
+// neighbour count (ties: ascending id) and ranks 4k..4k+3 share a step as a QUAD, one tile each, so that the four lists
+// end together.  (Ball sizes at C2: median 5, mean 25, maximum 261 -- four tiles of one centroid ran 32 % full; quads
+// alone made the longest item 17 steps.)  Ranking = comparison counting against the plot's counts in LDS: deterministic,
+// no atomics.  Items of all plots are interleaved heaviest first -- item k of plot b at position k*B + b -- and the SA
+// kernels deal them to their waves in that order (in a snake).  order: 4 ints per position (solo: the id | SN2_SA_SOLO_FLAG
+// four times; quad: four ids; -1 = none), 4*B*M ints + a 4-int trailer whose first word is max_b(items of plot b).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void sa_order_kernel(const int* __restrict__ cnt, int B, int M, int* __restrict__ order) {
+    extern __shared__ int s_cnt[];
+    const int b = blockIdx.y;
+    const int* cb = cnt + (size_t)b * M;
+    for (int i = threadIdx.x; i < M; i += 256) s_cnt[i] = cb[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int mine = s_cnt[i];
+    int rank = 0, nsolo = 0;
+    for (int j = 0; j < M; ++j) {
+        const int o = s_cnt[j];
+        rank += (o > mine || (o == mine && j < i)) ? 1 : 0;
+        nsolo += o > SN2_SA_SOLO_MIN ? 1 : 0;
+    }
+    const int id = b * M + i;
+    if (mine > SN2_SA_SOLO_MIN) {                       // the solos are exactly the ranks 0..nsolo-1
+        int* dst = order + 4 * ((size_t)rank * B + b);
+        dst[0] = dst[1] = dst[2] = dst[3] = id | SN2_SA_SOLO_FLAG;
+    } else {
+        const int rl = rank - nsolo;
+        order[4 * ((size_t)(nsolo + (rl >> 2)) * B + b) + (rl & 3)] = id;
+    }
+    if (i == 0) atomicMax(&order[(size_t)4 * B * M], nsolo + ((M - nsolo + 3) >> 2));
+}
+}  // namespace
+
+extern "C" int sn2_sa_order(const int* cnt, int B, int M, int* order, void* stream) {
+    if (!cnt || !order || B <= 0 || M <= 0) return SN2_EINVAL;
+    if (M > 16384) return SN2_ELIMIT;                     // the plot's counts must fit LDS
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(order, 0xFF, SN2_SA_ORDER_WORDS(B, M) * sizeof(int), st) != hipSuccess) return SN2_EINVAL;   // all -1
+    hipLaunchKernelGGL(sa_order_kernel, dim3(sn2_cdiv(M, 256), B), dim3(256), (size_t)M * 4, st, cnt, B, M, order);
+    SN2_RETURN_LAUNCH();
+}
+
 extern "C" int sn2_sa_forward(const sn2_sa* p, int training, void* stream) {
     SN2_TRY(check(p));
     if (p->nl == 2) return forward_t<8, 2, 16, 16>(p, training, (hipStream_t)stream);

@@ -1,7 +1,10 @@
 // sa_mfma.hip -- set-abstraction FORWARD passes with the shared MLP on the matrix cores.
 // (PointConv(local_nn) message + max aggregation, /root/reference/model/point_net2.py:19,21-29.)
 //
-// Layout: one wave per centroid, 64 messages per step = 4 tiles of 16.  lane = (q = lane>>4, c = lane&15).
+// Layout: one wave per work item (sn2_sa_order), 64 messages per step = 4 tiles of 16.  A SOLO item is one centroid with a
+// long list: tile t takes messages e0 + 16 t + c, 64 per step.  A QUAD item is four centroids with short lists of similar
+// length: tile t takes the next 16 messages of the quad's t-th centroid.  (Ball sizes are very uneven -- median 5, mean
+// 25, maximum 261 at C2: four tiles of one centroid ran 32 % full.)  lane = (q = lane>>4, c = lane&15).
 // v_mfma_f32_16x16x4_f32 computes D[i][j] += sum_k A[i][k] B[k][j] with
 //     A: lane holds A[i = c][k = q],   B: lane holds B[k = q][j = c],   D: lane holds D[i = 4q + r][j = c], r = 0..3.
 // Here i = output channel, j = message, k = input channel, i.e. D = W . U:
@@ -25,7 +28,7 @@ namespace {
 struct SaFwdArgs {
     int B, Nsrc, M, cap, feat_stride, spos_stride;
     const float *feat, *spos, *cpos;
-    const int *nbr, *cnt;
+    const int *nbr, *cnt, *order;
     const float *W0, *b0, *a0, *c0, *gamma0;
     const float *W1, *b1, *gamma1;
     float *slots;  // statistics slots of the block this pass measures, or nullptr
@@ -110,36 +113,59 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) ssum[io][r] = ssq[io][r] = 0.f;
 
-    for (int ci = wave; ci < ncent; ci += nwaves) {
-        const int b = ci / a.M;
-        const int n = a.cnt[ci];
-        const float4 cp = reinterpret_cast<const float4*>(a.cpos)[ci];
-        const float cpq = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
-        const int* nl = a.nbr + (size_t)ci * a.cap;
-        float best[TOL][4];
-        int barg[TOL][4];
+    const int nquads = a.order ? a.order[(size_t)4 * ncent] * a.B : (ncent + 3) >> 2;
+    // items are ordered heaviest first: the waves take them in a snake (round 0: item w, round 1: item 2W-1-w, ...), so the
+    // wave with the longest item of a round gets the shortest of the next.  (A shared work counter was tried: 8000 atomics
+    // on one address cost more than the imbalance they removed.)
+    for (int round = 0;; ++round) {
+        const int qi = round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave);
+        if (round * nwaves >= nquads) break;
+        if (qi >= nquads) continue;
+        // the quad's four centroids (wave-uniform: SGPRs), tile t walks the list of centroid cid[t]
+        int cid[4], nn[4], nmax = 0;
+        bool solo = false;
+        float cpq[4];
 #pragma unroll
-        for (int io = 0; io < TOL; ++io)
+        for (int t = 0; t < 4; ++t) {
+            const int slot = 4 * qi + t;
+            const int ent = a.order ? a.order[slot] : (slot < ncent ? slot : -1);
+            if (t == 0) solo = ent >= 0 && (ent & SN2_SA_SOLO_FLAG) != 0;
+            const int ci = ent >= 0 ? (ent & ~SN2_SA_SOLO_FLAG) : -1;
+            cid[t] = ci;
+            nn[t] = ci >= 0 ? a.cnt[ci] : 0;
+            nmax = nn[t] > nmax ? nn[t] : nmax;
+            const float4 cp = reinterpret_cast<const float4*>(a.cpos)[ci >= 0 ? ci : 0];
+            cpq[t] = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
+        }
+        float best[4][TOL][4];
+        int barg[4][TOL][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                best[io][r] = -INFINITY;
-                barg[io][r] = 0x7FFFFFFF;
-            }
-        for (int e0 = 0; e0 < n; e0 += 64) {
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int io = 0; io < TOL; ++io)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    best[t][io][r] = -INFINITY;
+                    barg[t][io][r] = 0x7FFFFFFF;
+                }
+        if (nmax == 0) continue;                                         // an empty position
+        const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
+        for (int e0 = 0; e0 < nmax; e0 += estep) {
             // ---- layer 1: gather straight into the B-operand layout, 4 message tiles
             f32x4 D1[TO1][4];
             bool val[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int e = e0 + 16 * t + c;
-                val[t] = e < n;
-                const int j = nl[val[t] ? e : 0];
-                const size_t row = (size_t)b * a.Nsrc + j;
+                const int e = e0 + eoff * t + c;                         // slot in tile t's list
+                val[t] = e < nn[t];
+                const int cit = cid[t] >= 0 ? cid[t] : 0;
+                const int j = val[t] ? a.nbr[(size_t)cit * a.cap + e] : 0;
+                const size_t row = (size_t)(cit / a.M) * a.Nsrc + j;
                 float bk[KB1];
 #pragma unroll
                 for (int kb = 0; kb < KB1 - 1; ++kb) bk[kb] = a.feat[row * a.feat_stride + 4 * kb + q];
                 const float pj = a.spos[row * a.spos_stride + (q < 3 ? q : 0)];
-                bk[KB1 - 1] = q < 3 ? pj - cpq : 1.0f;   // pos_j - pos_i | bias column
+                bk[KB1 - 1] = q < 3 ? pj - cpq[t] : 1.0f;   // pos_j - pos_i | bias column
 #pragma unroll
                 for (int io = 0; io < TO1; ++io) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -196,37 +222,54 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
                 for (int io = 0; io < TOL; ++io)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int e = e0 + 16 * t + c;
+                        const int e = e0 + eoff * t + c;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float h = val[t] ? DL[io][t][r] : 0.f;
                             ssum[io][r] += h;
                             ssq[io][r] = fmaf(h, h, ssq[io][r]);
                             const float s = sgn[io][r] * DL[io][t][r];
-                            if (val[t] && s > best[io][r]) {
-                                best[io][r] = s;
-                                barg[io][r] = e;
+                            if (val[t] && s > best[t][io][r]) {
+                                best[t][io][r] = s;
+                                barg[t][io][r] = e;
                             }
                         }
                     }
             }
         }
         if constexpr (PASS == 1) {
+            if (solo) {   // the four tiles belong to one centroid: fold them (greater value, then lower slot), tile 0 writes
 #pragma unroll
-            for (int io = 0; io < TOL; ++io) {
-                float ev[4];
-                int av[4];
+                for (int t = 1; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m = row_max(best[io][r]);
-                    const unsigned am = row_min_u32(best[io][r] == m ? (unsigned)barg[io][r] : 0xFFFFFFFFu);
-                    ev[r] = n > 0 ? sgn[io][r] * m : 0.f;
-                    av[r] = n > 0 ? (int)am : -1;
-                }
-                if (c == 0) {
-                    const size_t o = (size_t)ci * CL + 16 * io + 4 * q;
-                    *reinterpret_cast<float4*>(a.ext + o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
-                    *reinterpret_cast<int4*>(a.arg + o) = make_int4(av[0], av[1], av[2], av[3]);
+                    for (int io = 0; io < TOL; ++io)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool take = best[t][io][r] > best[0][io][r] ||
+                                              (best[t][io][r] == best[0][io][r] && barg[t][io][r] < barg[0][io][r]);
+                            best[0][io][r] = take ? best[t][io][r] : best[0][io][r];
+                            barg[0][io][r] = take ? barg[t][io][r] : barg[0][io][r];
+                        }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (cid[t] < 0 || (solo && t > 0)) continue;
+#pragma unroll
+                for (int io = 0; io < TOL; ++io) {
+                    float ev[4];
+                    int av[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = row_max(best[t][io][r]);
+                        const unsigned am = row_min_u32(best[t][io][r] == m ? (unsigned)barg[t][io][r] : 0xFFFFFFFFu);
+                        ev[r] = nn[t] > 0 ? sgn[io][r] * m : 0.f;
+                        av[r] = nn[t] > 0 ? (int)am : -1;
+                    }
+                    if (c == 0) {
+                        const size_t o = (size_t)cid[t] * CL + 16 * io + 4 * q;
+                        *reinterpret_cast<float4*>(a.ext + o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                        *reinterpret_cast<int4*>(a.arg + o) = make_int4(av[0], av[1], av[2], av[3]);
+                    }
                 }
             }
         }
@@ -264,7 +307,7 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
 struct SaBwdArgs {
     int B, Nsrc, M, cap, feat_stride, spos_stride;
     const float *feat, *spos, *cpos;
-    const int *nbr, *cnt;
+    const int *nbr, *cnt, *order;
     const unsigned long long* total;
     const float *W0, *b0, *a0, *c0, *gamma0, *mean0, *invstd0, *dgamma0, *dbeta0;   // dgamma0/dbeta0: read in pass D only
     const float *W1, *b1, *gamma1, *mean1, *invstd1, *dgamma1, *dbeta1;
@@ -379,38 +422,60 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
         for (int r = 0; r < 4; ++r) dbe0[i][r] = dga0[i][r] = 0.f;
 
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16;
-    for (int ci = wave; ci < ncent; ci += nwaves) {
-        const int b = ci / a.M;
-        const int n = a.cnt[ci];
-        const float4 cp = reinterpret_cast<const float4*>(a.cpos)[ci];
-        const float cpq = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
-        const int* nl = a.nbr + (size_t)ci * a.cap;
-        // d loss / d output and the winning slot of this lane's 4 channels per tile row
-        float dov[TOL][4];
-        int arv[TOL][4];
+    const int nquads = a.order ? a.order[(size_t)4 * ncent] * a.B : (ncent + 3) >> 2;
+    // items are ordered heaviest first: the waves take them in a snake (round 0: item w, round 1: item 2W-1-w, ...), so the
+    // wave with the longest item of a round gets the shortest of the next.  (A shared work counter was tried: 8000 atomics
+    // on one address cost more than the imbalance they removed.)
+    for (int round = 0;; ++round) {
+        const int qi = round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave);
+        if (round * nwaves >= nquads) break;
+        if (qi >= nquads) continue;
+        // the quad's four centroids (wave-uniform), tile t walks the list of centroid cid[t]
+        int cid[4], nn[4], nmax = 0;
+        bool solo = false;
+        float cpq[4];
+        // d loss / d output and the winning slot of this lane's 4 channels, per tile (= per centroid of the quad)
+        float dov[4][TOL][4];
+        int arv[4][TOL][4];
 #pragma unroll
-        for (int io = 0; io < TOL; ++io) {
-            const size_t o = (size_t)ci * CL + 16 * io + 4 * q;
-            const float4 dv = *reinterpret_cast<const float4*>(a.dout + o);
-            const int4 av = *reinterpret_cast<const int4*>(a.arg + o);
-            dov[io][0] = dv.x; dov[io][1] = dv.y; dov[io][2] = dv.z; dov[io][3] = dv.w;
-            arv[io][0] = av.x; arv[io][1] = av.y; arv[io][2] = av.z; arv[io][3] = av.w;
+        for (int t = 0; t < 4; ++t) {
+            const int slot = 4 * qi + t;
+            const int ent = a.order ? a.order[slot] : (slot < ncent ? slot : -1);
+            if (t == 0) solo = ent >= 0 && (ent & SN2_SA_SOLO_FLAG) != 0;
+            const int ci = ent >= 0 ? (ent & ~SN2_SA_SOLO_FLAG) : -1;
+            cid[t] = ci;
+            nn[t] = ci >= 0 ? a.cnt[ci] : 0;
+            nmax = nn[t] > nmax ? nn[t] : nmax;
+            const int cit = ci >= 0 ? ci : 0;
+            const float4 cp = reinterpret_cast<const float4*>(a.cpos)[cit];
+            cpq[t] = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
+#pragma unroll
+            for (int io = 0; io < TOL; ++io) {
+                const size_t o = (size_t)cit * CL + 16 * io + 4 * q;
+                const float4 dv = *reinterpret_cast<const float4*>(a.dout + o);
+                const int4 av = *reinterpret_cast<const int4*>(a.arg + o);
+                dov[t][io][0] = dv.x; dov[t][io][1] = dv.y; dov[t][io][2] = dv.z; dov[t][io][3] = dv.w;
+                arv[t][io][0] = av.x; arv[t][io][1] = av.y; arv[t][io][2] = av.z; arv[t][io][3] = av.w;
+            }
         }
-        for (int e0 = 0; e0 < n; e0 += 64) {
+        if (nmax == 0) continue;                                         // an empty position
+        const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
+        for (int e0 = 0; e0 < nmax; e0 += estep) {
             f32x4 D1[TO1][4];
             float bks[4][KB1];
             bool val[4];
             size_t rows[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int e = e0 + 16 * t + c;
-                val[t] = e < n;
-                const int j = nl[val[t] ? e : 0];
-                rows[t] = (size_t)b * a.Nsrc + j;
+                const int e = e0 + eoff * t + c;                         // slot in tile t's list
+                val[t] = e < nn[t];
+                const int cit = cid[t] >= 0 ? cid[t] : 0;
+                const int j = val[t] ? a.nbr[(size_t)cit * a.cap + e] : 0;
+                rows[t] = (size_t)(cit / a.M) * a.Nsrc + j;
 #pragma unroll
                 for (int kb = 0; kb < KB1 - 1; ++kb) bks[t][kb] = a.feat[rows[t] * a.feat_stride + 4 * kb + q];
                 const float pj = a.spos[rows[t] * a.spos_stride + (q < 3 ? q : 0)];
-                bks[t][KB1 - 1] = q < 3 ? pj - cpq : 1.0f;
+                bks[t][KB1 - 1] = q < 3 ? pj - cpq[t] : 1.0f;
 #pragma unroll
                 for (int io = 0; io < TO1; ++io) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -440,11 +505,11 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 #pragma unroll
                             for (int kb = 0; kb < 4; ++kb)
                                 v = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[io][is][kb], Y1[is][t][kb], v, 0, 0, 0);
-                        const int e = e0 + 16 * t + c;
+                        const int e = e0 + eoff * t + c;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float h = fmaxf(v[r], 0.f);
-                            const float dy = (val[t] && arv[io][r] == e) ? dov[io][r] : 0.f;
+                            const float dy = (val[t] && arv[t][io][r] == e) ? dov[t][io][r] : 0.f;
                             dp2[io][t][r] = (val[t] && h > 0.f) ? fmaf(cA1[io][r], dy, fmaf(-cC1[io][r], h, cD1[io][r])) : 0.f;
                         }
                     }
@@ -496,9 +561,9 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
                 for (int is = 0; is < TO1; ++is)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int e = e0 + 16 * t + c;
+                        const int e = e0 + eoff * t + c;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dy1[is][t][r] = (val[t] && arv[is][r] == e) ? dov[is][r] : 0.f;
+                        for (int r = 0; r < 4; ++r) dy1[is][t][r] = (val[t] && arv[t][is][r] == e) ? dov[t][is][r] : 0.f;
                     }
             }
             if constexpr (PASS == 3) {
@@ -631,14 +696,14 @@ template <int CF, int NL, int C1, int C2, int PASS>
 int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nblocks_out) {
     SaFwdArgs a;
     a.B = p->B; a.Nsrc = p->Nsrc; a.M = p->M; a.cap = p->cap; a.feat_stride = p->feat_stride; a.spos_stride = p->spos_stride;
-    a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt;
+    a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt; a.order = p->order;
     const sn2_block& k0 = p->blk[0];
     const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
     a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma;
     a.W1 = k1.W; a.b1 = k1.b; a.gamma1 = k1.gamma;
     a.slots = training ? (PASS == 0 ? k0.stat_slots : k1.stat_slots) : nullptr;
     a.ext = p->ext; a.arg = p->arg;
-    int blocks = sn2_cdiv((long)p->B * p->M, 4);
+    int blocks = sn2_cdiv((long)p->B * p->M, 16);          // one wave per quad of centroids, four waves per workgroup
     if (blocks > SN2_STAT_SLOTS) blocks = SN2_STAT_SLOTS;
     if (nblocks_out) *nblocks_out = blocks;
     hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS>), dim3(blocks), dim3(256), 0, st, a);
@@ -656,7 +721,7 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
     using Acc = OuterAcc<(LAST2 ? C2 : C1), (LAST2 ? C1 : CIN + 1)>;
     SaBwdArgs a;
     a.B = p->B; a.Nsrc = p->Nsrc; a.M = p->M; a.cap = p->cap; a.feat_stride = p->feat_stride; a.spos_stride = p->spos_stride;
-    a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt; a.total = p->total;
+    a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt; a.order = p->order; a.total = p->total;
     const sn2_block& k0 = p->blk[0];
     const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
     a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma; a.mean0 = k0.mean; a.invstd0 = k0.invstd;
@@ -666,7 +731,7 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
     a.dout = p->dout; a.arg = p->arg;
     a.dW0 = k0.dW; a.db0 = k0.db; a.dW1 = k1.dW; a.db1 = k1.db; a.dgamma0_out = k0.dgamma; a.dbeta0_out = k0.dbeta;
     a.dfeat = p->dfeat;
-    int blocks = sn2_cdiv((long)p->B * p->M, 4);
+    int blocks = sn2_cdiv((long)p->B * p->M, 16);
     if (blocks > 512) blocks = 512;
     const size_t lds = (size_t)Acc::LDS_FLOATS * 4 * sizeof(float);
     auto kern = &sa_mfma_bwd_kernel<CF, NL, C1, C2, PASS>;

@@ -265,8 +265,26 @@ class BlockBuffers:
         return self.aux[1]
 
 
+def sa_order_len(B: int, M: int) -> int:
+    """SN2_SA_ORDER_WORDS of include/strata_hip.h."""
+    return 4 * B * M + 4
+
+
+def sa_order(cnt: torch.Tensor, B: int, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cnt (B*M) from ball_query -> the work items of the SA passes (include/strata_hip.h: sn2_sa_order): solo centroids
+    with long lists and quads of centroids with short lists, heaviest first."""
+    _chk(cnt, I32, (B * M,), "cnt")
+    n = sa_order_len(B, M)
+    if out is None:
+        out = torch.empty(n, dtype=I32, device=cnt.device)
+    else:
+        _chk(out, I32, (n,), "out order")
+    _call("sn2_sa_order", _ptr(cnt), B, M, _ptr(out), _stream())
+    return out
+
+
 def sa_desc(blocks, feat, cf, spos, cpos_aos, nbr, cnt, total, B, Nsrc, M, ext, arg, out, dout=None, dfeat=None,
-            with_grads=False) -> SA:
+            with_grads=False, order=None) -> SA:
     """feat: (B*Nsrc, >=cf) row view; spos: (B*Nsrc, >=4) row view holding x,y,z,."""
     cap = nbr.shape[1]
     cl = blocks[-1].cout
@@ -283,6 +301,9 @@ def sa_desc(blocks, feat, cf, spos, cpos_aos, nbr, cnt, total, B, Nsrc, M, ext, 
     d.B, d.Nsrc, d.M, d.cap, d.cf, d.nl = B, Nsrc, M, cap, cf, len(blocks)
     d.feat, d.feat_stride, d.spos, d.spos_stride = _ptr(feat), feat_stride, _ptr(spos), spos_stride
     d.cpos, d.nbr, d.cnt, d.total = _ptr(cpos_aos), _ptr(nbr), _ptr(cnt), _ptr(total)
+    if order is not None:
+        _chk(order, I32, (sa_order_len(B, M),), "order")
+    d.order = _ptr(order)
     for i, bb in enumerate(blocks):
         bb.fill(d.blk[i], with_grads)
     d.ext, d.arg, d.out = _ptr(ext), _ptr(arg), _ptr(out)

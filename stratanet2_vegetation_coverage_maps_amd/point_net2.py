@@ -205,6 +205,7 @@ class PointNet2(nn.Module):
         g.knn2 = (e(B * M1, 3, dt=I32), e(B * M1, 3))
         g.knn1 = (e(B * N, 3, dt=I32), e(B * N, 3))
         g.tot1, g.tot2 = g.totals[0:1], g.totals[1:2]
+        g.ord1, g.ord2 = e(ops.sa_order_len(B, M1), dt=I32), e(ops.sa_order_len(B, M2), dt=I32)
         g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S), dt=I32) if 128 <= S <= 8192 else None for S in (M2, M1))
         g.ready = None
         return g
@@ -228,6 +229,8 @@ class PointNet2(nn.Module):
             ops.fps(g.pos1_soa, M2, fps_start[1], out=(g.idx2, g.pos2_soa, g.pos2_aos, g.ws2))
             ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, g.tot2, fps_ws=g.ws2,
                            out=(g.nbr2, g.cnt2))
+            ops.sa_order(g.cnt1, B, M1, out=g.ord1)
+            ops.sa_order(g.cnt2, B, M2, out=g.ord2)
             ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
             ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[0], dst_fps_ws=g.ws2)
             ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1], dst_fps_ws=g.ws1)
@@ -240,6 +243,7 @@ class PointNet2(nn.Module):
         g.idx2, g.pos2_soa, g.pos2_aos, ws2 = ops.fps(g.pos1_soa, M2, fps_start[1], return_ws=True)
         g.nbr2, g.cnt2, g.tot2 = ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2],
                                                 fps_ws=ws2)
+        g.ord1, g.ord2 = ops.sa_order(g.cnt1, B, M1), ops.sa_order(g.cnt2, B, M2)
         pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)      # GlobalSAModule: pos = zeros (point_net2.py:40)
         g.knn3 = ops.three_nn(pos3, g.pos2_soa, 1)
         g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3, dst_fps_ws=ws2)
@@ -341,11 +345,11 @@ class PointNet2(nn.Module):
     # ---- descriptors (shared by forward and backward; gradient views are attached for the backward call)
     def _sa1_desc(self, s, dout=None, g=False):
         return ops.sa_desc(s.b_sa1, s.rows0[:, 0:8], 8, s.rows0[:, 8:12], s.pos1_aos, s.nbr1, s.cnt1, s.tot1, s.B, s.N,
-                           s.M1, s.ext1, s.arg1, s.x1, dout=dout, dfeat=None, with_grads=g)
+                           s.M1, s.ext1, s.arg1, s.x1, dout=dout, dfeat=None, with_grads=g, order=getattr(s, "ord1", None))
 
     def _sa2_desc(self, s, dout=None, dfeat=None, g=False):
         return ops.sa_desc(s.b_sa2, s.x1, 16, s.pos1_aos, s.pos2_aos, s.nbr2, s.cnt2, s.tot2, s.B, s.M1, s.M2, s.ext2,
-                           s.arg2, s.x2, dout=dout, dfeat=dfeat, with_grads=g)
+                           s.arg2, s.x2, dout=dout, dfeat=dfeat, with_grads=g, order=getattr(s, "ord2", None))
 
     def _sa3_desc(self, s, **kw):
         return ops.fp_desc(s.b_sa3, s.B, s.M2, s.M2, 32, 3, s.x2, s.h_sa3, skip=s.pos2_aos, **kw)
