@@ -109,7 +109,7 @@ typedef struct sn2_sa {
  * Item k of plot b sits at position k*B + b, i.e. heaviest first across plots.  order: SN2_SA_ORDER_WORDS(B,M) ints = 4
  * per position (solo: id | SN2_SA_SOLO_FLAG four times; quad: four ids; -1 = none) + a 4-int trailer whose first word is
  * the largest item count of any plot.  (Ball sizes at C2: median 5, mean 25, maximum 261.) */
-#define SN2_SA_SOLO_MIN 48
+#define SN2_SA_SOLO_MIN 64
 #define SN2_SA_SOLO_FLAG 0x40000000
 #define SN2_SA_ORDER_WORDS(B, M) ((size_t)4 * (B) * (M) + 4)
 int sn2_sa_order(const int *cnt, int B, int M, int *order, void *stream);
