@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the feature passes into hipGraphs")
     ap.add_argument("--serial", action="store_true",
                     help="headline = the unpipelined step (geometry and features of a batch back to back on one stream)")
-    ap.add_argument("--depth", type=int, default=2, help="geometry passes kept in flight ahead of the feature pass")
+    ap.add_argument("--depth", type=int, default=3, help="geometry passes kept in flight ahead of the feature pass")
     ap.add_argument("--split-exchange", action="store_true",
                     help="one GPU: use the multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
     a = ap.parse_args()

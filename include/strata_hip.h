@@ -131,9 +131,16 @@ typedef struct sn2_fp {
     float *dsrc; int dsrc_stride;   /* backward out: ACCUMULATED d loss / d (sa*src+sc) (B*S,dsrc_stride) or NULL */
     float *dskip; int dskip_stride; /* backward out: ACCUMULATED (B*R, >=cb) or NULL                             */
     float *du_scratch;              /* backward workspace (B*R,ca) when knn_idx and dsrc are given               */
-    float *scatter_ws;              /* backward workspace when knn_idx and dsrc are given: B*S*(ceil(R/2048)+2) + 6*B*R
+    float *scatter_ws;              /* backward workspace when knn_idx and dsrc are given: SN2_INTERP_WS_WORDS(B,R,S)
                                        32-bit words (inverted index of the 3-NN table)                           */
+    int scatter_ready;              /* non-zero: scatter_ws already holds the index (sn2_interp_index)           */
 } sn2_fp;
+/* The transpose of knn_interpolate (its backward) is done as a gather through an inverted index of the 3-NN table:
+ * source -> list of (target row, normalised weight).  The index depends on positions only, so it can be built ahead of
+ * the backward pass (in the geometry pass) with sn2_interp_index; otherwise sn2_fp_backward builds it itself. */
+#define SN2_INTERP_WS_WORDS(B, R, S) ((size_t)(B) * (S) * (((R) + 2047) / 2048 + 2) + 6 * (size_t)(B) * (R) + 64)
+int sn2_interp_index(const int *knn_idx, const float *knn_w, int B, int R_per_plot, int S_per_plot, float *ws,
+                     void *stream);
 int sn2_fp_forward(const sn2_fp *p, int training, void *stream);
 int sn2_fp_backward(const sn2_fp *p, void *stream);
 

@@ -647,6 +647,23 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
 }
 
+// the inverted index of a 3-NN table (kernels A-C above); workspace carve (32-bit words):
+// H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp]
+int build_interp_index(const int* knn_idx, const float* knn_w, int B, int Rp, int S, float* ws, hipStream_t st) {
+    if (S > 8192) return SN2_ELIMIT;
+    const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
+    int* H = reinterpret_cast<int*>(ws);
+    int* off = H + (size_t)B * SL * S;
+    int* cnt = off + (size_t)B * S;
+    int* inv_row = cnt + (size_t)B * S;
+    float* inv_w = reinterpret_cast<float*>(inv_row + (size_t)3 * B * Rp);
+    hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, H);
+    hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, H, off, cnt);
+    hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, (const int*)H,
+                       (const int*)off, inv_row, inv_w);
+    SN2_RETURN_LAUNCH();
+}
+
 template <int CA, int CB, int CO, bool KNN>
 int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     constexpr int CI = CA + CB;
@@ -704,17 +721,13 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
         if (!p->scatter_ws) return SN2_EINVAL;
         const int S = p->S_per_plot, Rp = p->R_per_plot, B = p->B;
         if (S > 8192) return SN2_ELIMIT;
+        if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, B, Rp, S, p->scatter_ws, st));
         const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
-        // workspace carve (32-bit words): H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp]
         int* H = reinterpret_cast<int*>(p->scatter_ws);
         int* off = H + (size_t)B * SL * S;
         int* cnt = off + (size_t)B * S;
         int* inv_row = cnt + (size_t)B * S;
         float* inv_w = reinterpret_cast<float*>(inv_row + (size_t)3 * B * Rp);
-        hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, p->knn_idx, p->knn_w, H);
-        hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, H, off, cnt);
-        hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, p->knn_idx, p->knn_w,
-                           (const int*)H, (const int*)off, inv_row, inv_w);
         const int n_src = B * S;
         hipLaunchKernelGGL((interp_gather_kernel<CA>), dim3(sn2_cdiv(n_src, 4)), dim3(256), 0, st, n_src, Rp, S,
                            p->dsrc_stride, (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
@@ -749,6 +762,12 @@ int check_fp(const sn2_fp* p) {
     } while (0)
 
 }  // namespace
+
+extern "C" int sn2_interp_index(const int* knn_idx, const float* knn_w, int B, int R_per_plot, int S_per_plot, float* ws,
+                                void* stream) {
+    if (!knn_idx || !knn_w || !ws || B <= 0 || R_per_plot <= 0 || S_per_plot <= 0) return SN2_EINVAL;
+    return build_interp_index(knn_idx, knn_w, B, R_per_plot, S_per_plot, ws, (hipStream_t)stream);
+}
 
 extern "C" int sn2_fp_forward(const sn2_fp* p, int training, void* stream) {
     SN2_TRY(check_fp(p));

@@ -116,7 +116,7 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void sa_order_kernel(const int* __restrict__ cnt, int B, int M, int* __restrict__ order) {
-    extern __shared__ int s_cnt[];
+    extern __shared__ __attribute__((aligned(16))) int s_cnt[];
     const int b = blockIdx.y;
     const int* cb = cnt + (size_t)b * M;
     for (int i = threadIdx.x; i < M; i += 256) s_cnt[i] = cb[i];
@@ -125,7 +125,16 @@ __global__ __launch_bounds__(256) void sa_order_kernel(const int* __restrict__ c
     if (i >= M) return;
     const int mine = s_cnt[i];
     int rank = 0, nsolo = 0;
-    for (int j = 0; j < M; ++j) {
+    int j = 0;
+    for (; j + 4 <= M; j += 4) {                        // four counts per (broadcast) LDS read
+        const int4 o = *reinterpret_cast<const int4*>(&s_cnt[j]);
+        rank += (o.x > mine || (o.x == mine && j < i)) ? 1 : 0;
+        rank += (o.y > mine || (o.y == mine && j + 1 < i)) ? 1 : 0;
+        rank += (o.z > mine || (o.z == mine && j + 2 < i)) ? 1 : 0;
+        rank += (o.w > mine || (o.w == mine && j + 3 < i)) ? 1 : 0;
+        nsolo += (o.x > SN2_SA_SOLO_MIN) + (o.y > SN2_SA_SOLO_MIN) + (o.z > SN2_SA_SOLO_MIN) + (o.w > SN2_SA_SOLO_MIN);
+    }
+    for (; j < M; ++j) {
         const int o = s_cnt[j];
         rank += (o > mine || (o == mine && j < i)) ? 1 : 0;
         nsolo += o > SN2_SA_SOLO_MIN ? 1 : 0;

@@ -323,8 +323,28 @@ def sa_backward(d: SA):
     _call("sn2_sa_backward", d, _stream(), tag=f"cf={d.cf}")
 
 
+def interp_ws_words(B: int, R_per_plot: int, S_per_plot: int) -> int:
+    """SN2_INTERP_WS_WORDS of include/strata_hip.h."""
+    return B * S_per_plot * ((R_per_plot + 2047) // 2048 + 2) + 6 * B * R_per_plot + 64
+
+
+def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inverted index of a 3-NN table (source -> list of (target row, normalised weight)): what the backward of the
+    interpolation gathers through.  Position-only, so it can be built in the geometry pass."""
+    R = B * R_per_plot
+    _chk(knn[0], I32, (R, 3), "knn_idx")
+    _chk(knn[1], F32, (R, 3), "knn_w")
+    n = interp_ws_words(B, R_per_plot, S_per_plot)
+    if out is None:
+        out = torch.empty(n, dtype=F32, device=knn[0].device)
+    else:
+        _chk(out, F32, (n,), "out index")
+    _call("sn2_interp_index", _ptr(knn[0]), _ptr(knn[1]), B, R_per_plot, S_per_plot, _ptr(out), _stream())
+    return out
+
+
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
-            dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False) -> FP:
+            dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False, interp_index=None) -> FP:
     """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view."""
     R = B * R_per_plot
     hs = (block.cout + 3) // 4 * 4
@@ -362,13 +382,17 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
         d.dsrc_stride = _chk_rows(dsrc, F32, n_src_rows, ca, "dsrc", align=1)
     if dskip is not None:
         d.dskip_stride = _chk_rows(dskip, F32, R, cb, "dskip", align=1)
-    d.scatter_ws = None
+    d.scatter_ws, d.scatter_ready = None, 0
     if du_scratch is not None:
         _chk(du_scratch, F32, (R, ca), "du_scratch")
         if knn is not None and dsrc is not None:
-            # inverted index of the 3-NN table (no initialisation needed): see fp.hip "backward (3)"
-            words = n_src_rows * ((R_per_plot + 2047) // 2048 + 2) + 6 * R + 64
-            d._scatter_ws = torch.empty(words, dtype=F32, device=src.device)
+            # inverted index of the 3-NN table: prebuilt by interp_index (geometry pass) or built by the backward call
+            words = interp_ws_words(B, R_per_plot, S_per_plot)
+            if interp_index is not None:
+                _chk(interp_index, F32, (words,), "interp_index")
+                d._scatter_ws, d.scatter_ready = interp_index, 1
+            else:
+                d._scatter_ws = torch.empty(words, dtype=F32, device=src.device)
             d.scatter_ws = _ptr(d._scatter_ws)
     d.dy, d.dsrc, d.dskip, d.du_scratch = _ptr(dy), _ptr(dsrc), _ptr(dskip), _ptr(du_scratch)
     return d

@@ -206,6 +206,7 @@ class PointNet2(nn.Module):
         g.knn1 = (e(B * N, 3, dt=I32), e(B * N, 3))
         g.tot1, g.tot2 = g.totals[0:1], g.totals[1:2]
         g.ord1, g.ord2 = e(ops.sa_order_len(B, M1), dt=I32), e(ops.sa_order_len(B, M2), dt=I32)
+        g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1)))
         g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S), dt=I32) if 128 <= S <= 8192 else None for S in (M2, M1))
         g.ready = None
         return g
@@ -234,6 +235,9 @@ class PointNet2(nn.Module):
             ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
             ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[0], dst_fps_ws=g.ws2)
             ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1], dst_fps_ws=g.ws1)
+            ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
+            ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
+            ops.interp_index(g.knn1, B, N, M1, out=g.inv1)
             return g
         g = _Saved()
         g.B, g.N, g.M1, g.M2, g.xyz = B, N, M1, M2, xyz
@@ -248,6 +252,10 @@ class PointNet2(nn.Module):
         g.knn3 = ops.three_nn(pos3, g.pos2_soa, 1)
         g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3, dst_fps_ws=ws2)
         g.knn1 = ops.three_nn(g.pos1_soa, xyz, 3, dst_fps_ws=ws1)
+        # the inverted 3-NN tables the backward pass gathers through: positions only, so they belong here
+        g.inv3 = ops.interp_index(g.knn3, B, M2, 1)
+        g.inv2 = ops.interp_index(g.knn2, B, M1, M2)
+        g.inv1 = ops.interp_index(g.knn1, B, N, M1)
         return g
 
     def prefetch_geometry(self, cloud_data):
@@ -263,8 +271,14 @@ class PointNet2(nn.Module):
             xyz_d, fs = self._stage_positions(cloud_data, dev)
             side = self._geo_stream
             side.wait_stream(torch.cuda.current_stream())
+            # staged on the current stream, read by kernels of the side stream long after this function has returned:
+            # without this the allocator may hand the start indices' memory to the next forward while FPS level 2 still
+            # has to read them
+            xyz_d.record_stream(side)
+            fs.record_stream(side)
             with torch.cuda.stream(side):
                 g = self._geometry(xyz_d, fs)
+                g.fps_start = fs
                 g.ready = torch.cuda.Event()
                 g.ready.record(side)
             g.stream = side
@@ -293,7 +307,7 @@ class PointNet2(nn.Module):
         elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
             raise ValueError("prefetched geometry does not match this batch")
         s = _Saved()
-        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws")})
+        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws", "fps_start")})
         s.xyz = xyz
         # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd and the per-workgroup statistics
         # slots (written before they are read: no zero fill)
@@ -401,15 +415,17 @@ class PointNet2(nn.Module):
         # FP1 -> d(fp2 output)
         dy2 = buf["dy2"].view(B * M1, 36)
         ops.fp_backward(self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 34, dtype=F32, device=dev),
-                                       with_grads=True))
+                                       with_grads=True, interp_index=s.inv1))
         # FP2 -> d(fp3 output), d x1
         dy3, dx1 = buf["dy3"].view(B * M2, 64), buf["dx1"].view(B * M1, 16)
         ops.fp_backward(self._fp2_desc(s, dy=dy2, dsrc=dy3, dskip=dx1,
-                                       du_scratch=torch.empty(B * M1, 64, dtype=F32, device=dev), with_grads=True))
+                                       du_scratch=torch.empty(B * M1, 64, dtype=F32, device=dev), with_grads=True,
+                                       interp_index=s.inv2))
         # FP3 -> d x3, d x2
         dx3, dx2 = buf["dx3"].view(B, 64), buf["dx2"].view(B * M2, 32)
         ops.fp_backward(self._fp3_desc(s, dy=dy3, dsrc=dx3, dskip=dx2,
-                                       du_scratch=torch.empty(B * M2, 64, dtype=F32, device=dev), with_grads=True))
+                                       du_scratch=torch.empty(B * M2, 64, dtype=F32, device=dev), with_grads=True,
+                                       interp_index=s.inv3))
         # global max pool -> SA3 rows
         dy_sa3 = buf["dy_sa3"].view(B * M2, 64)
         ops.plot_max_backward(dx3, s.arg3, B, M2, 64, dy_sa3)
