@@ -150,16 +150,31 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
                 }
         if (nmax == 0) continue;                                         // an empty position
         const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
+        // the neighbour indices of a step are fetched one step ahead: index load -> row gather -> MFMA chain is what a
+        // step waits for, and the first link does not depend on the step before
+        int jn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = eoff * t + c;
+            jn[t] = e < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
+        }
         for (int e0 = 0; e0 < nmax; e0 += estep) {
             // ---- layer 1: gather straight into the B-operand layout, 4 message tiles
             f32x4 D1[TO1][4];
             bool val[4];
+            int jc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                jc[t] = jn[t];
+                const int en = e0 + estep + eoff * t + c;
+                jn[t] = en < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + en] : 0;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int e = e0 + eoff * t + c;                         // slot in tile t's list
                 val[t] = e < nn[t];
                 const int cit = cid[t] >= 0 ? cid[t] : 0;
-                const int j = val[t] ? a.nbr[(size_t)cit * a.cap + e] : 0;
+                const int j = jc[t];
                 const size_t row = (size_t)(cit / a.M) * a.Nsrc + j;
                 float bk[KB1];
 #pragma unroll
@@ -460,17 +475,30 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
         }
         if (nmax == 0) continue;                                         // an empty position
         const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
+        int jn[4];                                                       // neighbour indices, fetched one step ahead
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = eoff * t + c;
+            jn[t] = e < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
+        }
         for (int e0 = 0; e0 < nmax; e0 += estep) {
             f32x4 D1[TO1][4];
             float bks[4][KB1];
             bool val[4];
             size_t rows[4];
+            int jc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                jc[t] = jn[t];
+                const int en = e0 + estep + eoff * t + c;
+                jn[t] = en < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + en] : 0;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int e = e0 + eoff * t + c;                         // slot in tile t's list
                 val[t] = e < nn[t];
                 const int cit = cid[t] >= 0 ? cid[t] : 0;
-                const int j = val[t] ? a.nbr[(size_t)cit * a.cap + e] : 0;
+                const int j = jc[t];
                 rows[t] = (size_t)(cit / a.M) * a.Nsrc + j;
 #pragma unroll
                 for (int kb = 0; kb < KB1 - 1; ++kb) bks[t][kb] = a.feat[rows[t] * a.feat_stride + 4 * kb + q];
