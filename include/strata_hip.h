@@ -203,6 +203,13 @@ int sn2_mosaic_merge(const float *rasters, const float *weights, const int *offs
  * KDE-mixture densities at the points' heights (the reference evaluates them on the CPU each step, :30-42; KDE fitting is
  * out of scope, so they are an input).  partials: 2*SN2_LOSS_BLOCKS fp64 workspace.  out[4] = total, absolute, NLL,
  * entropy.  Backward: grad_total = device scalar d(objective)/d(total); writes dpred (B,4), dproba (R,4). */
+/* KDE-mixture densities at the points' heights -- KdeMixture.predict, learning/kde_mixture.py:65-70 (three scipy
+ * interp1d(kind="linear") over one knot vector), which get_NLL_loss evaluates on the CPU for all B*N points every step
+ * (learning/loss_functions.py:30-42).  cloud (B,C,N) fp32, height = cloud[:, z_channel, :] * z_max formed in fp32;
+ * X (K) ascending knots and Y (3,K) the three tables, fp64; pdf (B*N,3) fp64 = what sn2_loss_* take.  Heights outside
+ * [X[0], X[K-1]] (scipy raises there) give NaN.  Fitting the KDEs (KDEpy) is out of scope: the tables are an input. */
+int sn2_kde_lookup(const float *cloud, int B, int C, int N, int z_channel, float z_max, const double *X, const double *Y,
+                   int K, double *pdf, void *stream);
 #define SN2_LOSS_BLOCKS 1024
 int sn2_loss_forward(const float *pred, const double *gt, int B, const float *proba, const double *pdf, int R, double m,
                      double e, double *partials, double *out, void *stream);

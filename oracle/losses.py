@@ -32,3 +32,19 @@ def total_loss(pred_coverages, proba_pointwise, gt, pdf_all, m: float = 0.10, e:
     l_log = nll_loss(proba_pointwise, pdf_all)
     l_e = entropy_loss(proba_pointwise)
     return l_abs + m * l_log + e * l_e, (l_abs, l_log, l_e)
+
+
+def kde_predict(X, ys, clouds, z_max):
+    """`get_NLL_loss`'s density lookup (`/root/reference/learning/loss_functions.py:30-42`) with `KdeMixture.predict`
+    (`learning/kde_mixture.py:65-70`): z = cloud[2] * z_max per plot (a float32 tensor times a python float), concatenated
+    into a float64 array, then three scipy `interp1d(kind="linear", assume_sorted=False)` -- scipy itself is the
+    checker here.  clouds (B,C,N) float32 tensor -> (B*N,3) float64."""
+    import numpy as np
+    from scipy.interpolate import interp1d
+    z_all = np.empty((0))
+    for current_cloud in clouds:
+        z = current_cloud[2] * z_max
+        z_all = np.append(z_all, z)
+    z_all = np.asarray(z_all).reshape(-1)
+    fs = [interp1d(X, y, kind="linear", assume_sorted=False) for y in ys]
+    return np.concatenate([f(z_all).reshape(-1, 1) for f in fs], 1)

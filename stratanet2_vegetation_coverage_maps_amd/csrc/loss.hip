@@ -112,6 +112,38 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     }
 }
 
+// KDE-mixture densities at the points' heights: KdeMixture.predict (learning/kde_mixture.py:65-70) = three scipy
+// interp1d(kind="linear") over one knot vector, evaluated by get_NLL_loss on the CPU for all B*N points every step
+// (learning/loss_functions.py:30-42).  Same arithmetic as scipy's _call_linear, in fp64 without contraction:
+//   i = clip(searchsorted(X, z, side="left"), 1, K-1);  slope = (y[i] - y[i-1]) / (X[i] - X[i-1]);  y = slope*(z - X[i-1]) + y[i-1]
+// z = fp64( fp32(cloud[b][zc][n]) * fp32(z_max) ) as the reference forms it (a float32 tensor times a python float).
+// Heights outside [X[0], X[K-1]] (scipy raises ValueError there) give NaN.
+__global__ __launch_bounds__(256) void kde_lookup_kernel(const float* __restrict__ cloud, int C, int N, int zc, float z_max,
+                                                         const double* __restrict__ X, const double* __restrict__ Y, int K,
+                                                         long R, double* __restrict__ pdf) {
+#pragma clang fp contract(off)
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const long b = r / N, n = r - b * N;
+    const double z = (double)(cloud[(b * C + zc) * N + n] * z_max);
+    int lo = 0, hi = K;                         // first index with X[i] >= z
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (X[mid] < z) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool inside = z >= X[0] && z <= X[K - 1];
+    int i = lo < 1 ? 1 : (lo > K - 1 ? K - 1 : lo);
+    const double x_lo = X[i - 1], x_hi = X[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double y_lo = Y[(size_t)k * K + i - 1], y_hi = Y[(size_t)k * K + i];
+        const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+        const double v = slope * (z - x_lo) + y_lo;
+        pdf[3 * r + k] = inside ? v : __longlong_as_double(0x7ff8000000000000LL);
+    }
+}
+
 inline int loss_grid(int R) {
     const int n = sn2_cdiv(R, 256);
     return n < LOSS_BLOCKS ? n : LOSS_BLOCKS;
@@ -134,5 +166,14 @@ extern "C" int sn2_loss_backward(const float* pred, const double* gt, int B, con
     if (!pred || !gt || !proba || !pdf || !grad_total || !dpred || !dproba || B <= 0 || R <= 0) return SN2_EINVAL;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(loss_grid(R)), dim3(256), 0, (hipStream_t)stream, pred, gt, B,
                        reinterpret_cast<const float4*>(proba), pdf, R, m, e, grad_total, dpred, reinterpret_cast<float4*>(dproba));
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_kde_lookup(const float* cloud, int B, int C, int N, int z_channel, float z_max, const double* X,
+                              const double* Y, int K, double* pdf, void* stream) {
+    if (!cloud || !X || !Y || !pdf || B <= 0 || C <= 0 || N <= 0 || z_channel < 0 || z_channel >= C || K < 2) return SN2_EINVAL;
+    const long R = (long)B * N;
+    hipLaunchKernelGGL(kde_lookup_kernel, dim3(sn2_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, cloud, C, N, z_channel,
+                       z_max, X, Y, K, R, pdf);
     SN2_RETURN_LAUNCH();
 }

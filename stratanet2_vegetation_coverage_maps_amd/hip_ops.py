@@ -530,6 +530,20 @@ def mosaic_merge(rasters, weights, offsets, mean, wsum, window=None):
 LOSS_BLOCKS = 1024
 
 
+def kde_lookup(clouds_dev: torch.Tensor, z_max: float, X: torch.Tensor, Y: torch.Tensor, z_channel: int = 2) -> torch.Tensor:
+    """clouds (B,C,N) fp32 on the device, X (K) / Y (3,K) fp64 interpolation tables -> pdf_all (B*N,3) fp64."""
+    B, C, N = clouds_dev.shape
+    _chk(clouds_dev, F32, (B, C, N), "clouds")
+    K = X.shape[0]
+    _chk(X, F64, (K,), "X")
+    _chk(Y, F64, (3, K), "Y")
+    if K < 2 or not (0 <= z_channel < C):
+        raise ValueError("kde_lookup: need K >= 2 knots and a valid z channel")
+    pdf = torch.empty(B * N, 3, dtype=F64, device=clouds_dev.device)
+    _call("sn2_kde_lookup", _ptr(clouds_dev), B, C, N, int(z_channel), float(z_max), _ptr(X), _ptr(Y), K, _ptr(pdf), _stream())
+    return pdf
+
+
 def loss_forward(pred, gt, proba, pdf, m: float, e: float):
     """-> out (4,) fp64 = [total, absolute, NLL, entropy] (include/strata_hip.h: sn2_loss_forward)."""
     B, R = pred.shape[0], proba.shape[0]

@@ -44,6 +44,33 @@ def total_loss_torch(pred_coverages, proba_pointwise, gt, pdf_all, m=0.10, e=0.2
     return l_abs + m * l_log + e * l_e, (l_abs, l_log, l_e)
 
 
+class KdeTables:
+    """The three linear-interpolation tables of the reference's `KdeMixture` (`learning/kde_mixture.py:62-70`: X and
+    y1, y2, y3 from `evaluate_kdes`, what `interp1d` holds) on the device.  Fitting (KDEpy FFTKDE) stays with the reference:
+    `KdeTables.from_mixture(args.kde_mixture, device)` copies the fitted tables."""
+
+    def __init__(self, X, y1, y2, y3, device):
+        import numpy as np
+        X = np.asarray(X, dtype=np.float64)
+        order = np.argsort(X, kind="stable")                      # interp1d(assume_sorted=False) sorts its knots
+        Y = np.stack([np.asarray(y, dtype=np.float64)[order] for y in (y1, y2, y3)])
+        self.X = torch.from_numpy(np.ascontiguousarray(X[order])).to(device)
+        self.Y = torch.from_numpy(np.ascontiguousarray(Y)).to(device)
+
+    @classmethod
+    def from_mixture(cls, kde_mixture, device):
+        return cls(kde_mixture.f1.x, kde_mixture.f1.y, kde_mixture.f2.y, kde_mixture.f3.y, device)
+
+
+def kde_densities(clouds_dev, z_max, tables: KdeTables):
+    """pdf_all (B*N,3) fp64 of `get_NLL_loss` (`learning/loss_functions.py:30-42`): the three KDE densities at every
+    point's height z = cloud[2] * z_max, looked up on the device instead of through scipy on the CPU each step."""
+    if not clouds_dev.is_cuda:
+        raise StrataHipError("losses.kde_densities runs on the HIP device")
+    with torch.cuda.device(clouds_dev.device):
+        return ops.kde_lookup(clouds_dev.float().contiguous(), z_max, tables.X, tables.Y)
+
+
 class _TotalLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, proba, gt, pdf, m, e):

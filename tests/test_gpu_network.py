@@ -227,3 +227,29 @@ def test_prefetched_geometry_gives_identical_results():
         geo = m.prefetch_geometry(d)
         cov_b, proba_b = m({"cloud": d["cloud"], "xyz": d["xyz"], "geometry": geo})
     assert torch.equal(cov_a, cov_b) and torch.equal(proba_a, proba_b)
+
+
+def test_kde_lookup_matches_scipy_interp1d():
+    """Device lookup of the KDE-mixture densities vs the reference's way (scipy interp1d on the CPU): fp64, same operation
+    order -> equal to the last bit on equidistant knots (FFTKDE's grid) and on irregular, unsorted ones."""
+    from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
+    rng = np.random.default_rng(3)
+    d = make_batch(3, 5000, first_plot=11)
+    z_max = 24.24
+    for irregular in (False, True):
+        K = 5000
+        X = np.linspace(-30.0, 30.0, K)
+        if irregular:
+            X = np.sort(X + rng.uniform(-0.004, 0.004, K))
+            perm = rng.permutation(K)
+        ys = [np.exp(-0.5 * ((np.abs(X) - c) / s) ** 2) + 0.01 for c, s in ((0.2, 0.3), (1.0, 0.5), (8.0, 5.0))]
+        Xin, yin = (X[perm], [y[perm] for y in ys]) if irregular else (X, ys)
+        want = losses.kde_predict(Xin, yin, d["cloud"], z_max)
+        tab = dev_losses.KdeTables(Xin, *yin, device="cuda:0")
+        got = dev_losses.kde_densities(d["cloud"].cuda(), z_max, tab).cpu().numpy()
+        assert got.shape == want.shape == (3 * 5000, 3)
+        np.testing.assert_array_equal(got, want)
+    # out of the table's range: scipy raises, the device marks the point
+    tab = dev_losses.KdeTables(np.linspace(0.0, 1.0, 10), *[np.ones(10)] * 3, device="cuda:0")
+    out = dev_losses.kde_densities(d["cloud"].cuda(), z_max, tab)
+    assert torch.isnan(out).any() and not torch.isnan(out).all()
