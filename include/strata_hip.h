@@ -197,6 +197,16 @@ int sn2_raster_project(const float *coverages, const float *cloud_xy, long plot_
 int sn2_mosaic_merge(const float *rasters, const float *weights, const int *offsets, int B, int D, int H, int W,
                      float *mean, float *wsum, int win_y0, int win_x0, int win_h, int win_w, void *stream);
 
+/* Mosaic finalisation -- finalize_merged_raster (inference/geotiff_raster.py:262-285) up to, not including, the GIS
+ * admissibility band: keep the three score bands + one weight band, insert the hard medium-vegetation band
+ * (insert_hard_med_veg_raster_band :119-144: the threshold among linspace(0,1,10001) whose hard coverage is closest to the
+ * mean soft coverage, first minimum), then NaN -> 0 wherever at least one score exists and NaN everywhere else.
+ * mean (3,H,W) and wsum (H,W) from sn2_mosaic_merge; hist_ws SN2_MOSAIC_HIST_WORDS ints, sum_ws one double (both scratch);
+ * thr_out[0] = threshold, thr_out[1] = its index; out (5,H,W) = [Vb, Vm_soft, Vh, Vm_hard, weights]. */
+#define SN2_MOSAIC_HIST_WORDS 10004
+int sn2_mosaic_finalize(const float *mean, const float *wsum, int H, int W, int *hist_ws, double *sum_ws, float *thr_out,
+                        float *out, void *stream);
+
 /* ---- loss block of the timed training step: learning/loss_functions.py:9-57 combined as learning/train.py:58-62,
  *   total = get_absolute_loss(pred, gt) + m * get_NLL_loss(proba, pdf_all) + e * get_entropy_loss(proba)
  * pred (B,4) fp32 plot-wise coverages, gt (B,4) fp64, proba (R,4) fp32 pointwise class probabilities, pdf (R,3) fp64 the

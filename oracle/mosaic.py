@@ -50,3 +50,31 @@ def mosaic(rasters, offsets, H, W, diam_pix):
         win = acc[:, oy:oy + D, ox:ox + D]
         acc[:, oy:oy + D, ox:ox + D] = merge_pair(win, img)
     return acc
+
+
+def insert_hard_med_veg_raster_band(mosaic):
+    """`/root/reference/inference/geotiff_raster.py:119-144`, operation for operation (numpy.ma replaced by isnan)."""
+    image_med_veg = mosaic[1]
+    mask = np.isnan(image_med_veg)
+    with np.errstate(invalid="ignore"):
+        target_coverage = np.nanmean(image_med_veg)
+        lin = np.linspace(0, 1, 10001)
+        delta = np.ones_like(lin)
+        for idx, threshold in enumerate(lin):
+            image_med_veg_hard = 1.0 * (image_med_veg > threshold)
+            image_med_veg_hard[mask] = np.nan
+            delta[idx] = abs(target_coverage - np.nanmean(image_med_veg_hard))
+    threshold = lin[np.argmin(delta)]
+    image_med_veg_hard = 1.0 * (image_med_veg > threshold)
+    image_med_veg_hard[mask] = np.nan
+    return np.insert(mosaic, 3, image_med_veg_hard, axis=0), threshold
+
+
+def finalize_merged_raster(mosaic):
+    """`geotiff_raster.py:262-285` without `insert_admissibility_raster` (rasterio / shapely)."""
+    mosaic = mosaic[: (3 + 1)]
+    mosaic, threshold = insert_hard_med_veg_raster_band(mosaic)
+    no_predicted_value = np.nansum(np.isnan(mosaic[:3]), axis=0) == 3
+    mosaic = np.nan_to_num(mosaic, nan=0.0, posinf=None, neginf=None)
+    mosaic[:, no_predicted_value] = np.nan
+    return mosaic, threshold

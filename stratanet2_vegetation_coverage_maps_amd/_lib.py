@@ -68,6 +68,7 @@ SIGNATURES = {
                            c_void_p],
     "sn2_mosaic_merge": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                          c_int, c_int, c_int, c_int, c_void_p],
+    "sn2_mosaic_finalize": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_kde_lookup": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "sn2_loss_forward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p,
                          c_void_p],

@@ -300,3 +300,144 @@ extern "C" int sn2_mosaic_merge(const float* rasters, const float* weights, cons
                        (hipStream_t)stream, rasters, weights, offsets, B, D, H, W, mean, wsum, win_y0, win_x0, win_h, win_w);
     SN2_RETURN_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Mosaic finalisation: finalize_merged_raster without the GIS step (inference/geotiff_raster.py:262-285 + :119-144).
+// The reference finds the hard medium-vegetation threshold by evaluating 10 001 thresholds, each over the whole image
+// (O(10^4 x pixels) in numpy).  Here every valid pixel is binned once by the number k(v) of thresholds below its value;
+// the number of pixels above threshold i is then a suffix sum of that histogram, the 10 001 deltas come from it, and the
+// first minimum is taken as numpy's argmin does.  Thresholds lin[i] = i * (1/10000) in fp64, lin[10000] = 1 (np.linspace);
+// the comparison v > lin[i] is made in fp64.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int HARD_STEPS = 10001;
+
+__device__ __forceinline__ double hard_lin(int i) { return i >= HARD_STEPS - 1 ? 1.0 : (double)i * (1.0 / 10000.0); }
+
+// ws: [0..HARD_STEPS] histogram of k, [HARD_STEPS+1] number of valid pixels; sum_ws: fp64 sum of the valid values
+__global__ __launch_bounds__(256) void hard_hist_kernel(const float* __restrict__ med, long P, int* __restrict__ ws,
+                                                        double* __restrict__ sum_ws) {
+    __shared__ double s_sum[4];
+    __shared__ int s_cnt[4];
+    double acc = 0.0;
+    int nv = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+        const float vf = med[i];
+        if (vf != vf) continue;
+        const double v = (double)vf;
+        int k = (int)floor(v * 10000.0);
+        k = k < 0 ? 0 : (k > HARD_STEPS - 1 ? HARD_STEPS - 1 : k);
+        while (k <= HARD_STEPS - 1 && hard_lin(k) < v) ++k;            // k = #{ i : lin[i] < v }
+        while (k > 0 && !(hard_lin(k - 1) < v)) --k;
+        atomicAdd(&ws[k], 1);
+        acc += v;
+        ++nv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o);
+        nv += __shfl_xor(nv, o);
+    }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = acc; s_cnt[threadIdx.x >> 6] = nv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sum_ws, (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+        atomicAdd(&ws[HARD_STEPS + 1], (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]));
+    }
+}
+
+// one workgroup: suffix sums, deltas, first minimum -> thr_out[0] = threshold (fp64 value as float), thr_out[1] = index
+__global__ __launch_bounds__(1024) void hard_threshold_kernel(const int* __restrict__ ws, const double* __restrict__ sum_ws,
+                                                              float* __restrict__ thr_out) {
+    __shared__ long long s_above[HARD_STEPS + 1];     // s_above[i] = #{pixels with k > i}
+    __shared__ double s_best[1024];
+    __shared__ int s_idx[1024];
+    const int tid = threadIdx.x;
+    // chunked suffix sum over k = HARD_STEPS .. 0: 1024 threads x 10 bins
+    constexpr int PER = (HARD_STEPS + 1 + 1023) / 1024;
+    long long loc = 0;
+    const int hi = HARD_STEPS - tid * PER;            // this thread's bins: hi, hi-1, ... (descending)
+    for (int j = 0; j < PER; ++j) {
+        const int k = hi - j;
+        if (k >= 0) loc += ws[k];
+    }
+    __shared__ long long s_chunk[1024];
+    s_chunk[tid] = loc;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int t = 0; t < 1024; ++t) { const long long c = s_chunk[t]; s_chunk[t] = run; run += c; }
+    }
+    __syncthreads();
+    long long run = s_chunk[tid];                     // pixels with k above this thread's highest bin
+    for (int j = 0; j < PER; ++j) {
+        const int k = hi - j;
+        if (k >= 0) {
+            if (k <= HARD_STEPS) s_above[k] = run;    // #{k' > k}
+            run += ws[k];
+        }
+    }
+    __syncthreads();
+    const int nvalid = ws[HARD_STEPS + 1];
+    // np.nanmean of a float32 image is a float32; the hard images are fp64 (1.0 * bool)
+    const double target = nvalid > 0 ? (double)(float)(sum_ws[0] / (double)nvalid) : __longlong_as_double(0x7ff8000000000000LL);
+    double best = INFINITY;
+    int bidx = 0x7FFFFFFF;
+    for (int i = tid; i < HARD_STEPS; i += 1024) {
+        // pixels with v > lin[i]  <=>  k(v) > i
+        const double hard_mean = nvalid > 0 ? (double)s_above[i] / (double)nvalid : __longlong_as_double(0x7ff8000000000000LL);
+        const double d = fabs(target - hard_mean);
+        if (d < best) { best = d; bidx = i; }         // ascending i per thread: first minimum kept
+    }
+    s_best[tid] = best;
+    s_idx[tid] = bidx;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double ob = s_best[tid + o];
+            const int oi = s_idx[tid + o];
+            if (ob < s_best[tid] || (ob == s_best[tid] && oi < s_idx[tid])) { s_best[tid] = ob; s_idx[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int i = s_idx[0] == 0x7FFFFFFF ? 0 : s_idx[0];   // all-NaN deltas: np.argmin returns 0
+        thr_out[0] = (float)hard_lin(i);
+        thr_out[1] = (float)i;
+    }
+}
+
+// out (5,H,W) = [Vb, Vm_soft, Vh, Vm_hard, weights] with the reference's NaN rule: NaN -> 0 wherever at least one of the
+// three scores is a number, all bands NaN elsewhere
+__global__ __launch_bounds__(256) void mosaic_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ wsum,
+                                                              long P, const float* __restrict__ thr, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float nanv = __int_as_float(0x7fc00000);
+    const float b0 = mean[i], b1 = mean[P + i], b2 = mean[2 * P + i], w = wsum[i];
+    const bool none = (b0 != b0) && (b1 != b1) && (b2 != b2);
+    const double t = hard_lin((int)thr[1]);
+    float hard = (b1 != b1) ? nanv : (((double)b1 > t) ? 1.f : 0.f);
+    auto fix = [&](float v) { return none ? nanv : (v != v ? 0.f : v); };
+    out[i] = fix(b0);
+    out[P + i] = fix(b1);
+    out[2 * P + i] = fix(b2);
+    out[3 * P + i] = fix(hard);
+    out[4 * P + i] = fix(w);
+}
+}  // namespace
+
+extern "C" int sn2_mosaic_finalize(const float* mean, const float* wsum, int H, int W, int* hist_ws, double* sum_ws,
+                                   float* thr_out, float* out, void* stream) {
+    if (!mean || !wsum || !hist_ws || !sum_ws || !thr_out || !out || H <= 0 || W <= 0) return SN2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long P = (long)H * W;
+    if (hipMemsetAsync(hist_ws, 0, (size_t)SN2_MOSAIC_HIST_WORDS * sizeof(int), st) != hipSuccess) return SN2_EINVAL;
+    if (hipMemsetAsync(sum_ws, 0, sizeof(double), st) != hipSuccess) return SN2_EINVAL;
+    int grid = sn2_cdiv(P, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(hard_hist_kernel, dim3(grid), dim3(256), 0, st, mean + P, P, hist_ws, sum_ws);
+    hipLaunchKernelGGL(hard_threshold_kernel, dim3(1), dim3(1024), 0, st, (const int*)hist_ws, (const double*)sum_ws, thr_out);
+    hipLaunchKernelGGL(mosaic_finalize_kernel, dim3(sn2_cdiv(P, 256)), dim3(256), 0, st, mean, wsum, P, (const float*)thr_out, out);
+    SN2_RETURN_LAUNCH();
+}

@@ -527,6 +527,20 @@ def mosaic_merge(rasters, weights, offsets, mean, wsum, window=None):
           y0, x0, wh, ww, _stream())
 
 
+def mosaic_finalize(mean: torch.Tensor, wsum: torch.Tensor):
+    """mean (3,H,W), wsum (H,W) -> out (5,H,W) = [Vb, Vm_soft, Vh, Vm_hard, weights], thr (2,) = threshold, its index."""
+    _, H, W = mean.shape
+    _chk(mean, F32, (3, H, W), "mean")
+    _chk(wsum, F32, (H, W), "wsum")
+    dev = mean.device
+    hist = torch.empty(10004, dtype=I32, device=dev)
+    acc = torch.empty(1, dtype=F64, device=dev)
+    thr = torch.empty(2, dtype=F32, device=dev)
+    out = torch.empty(5, H, W, dtype=F32, device=dev)
+    _call("sn2_mosaic_finalize", _ptr(mean), _ptr(wsum), H, W, _ptr(hist), _ptr(acc), _ptr(thr), _ptr(out), _stream())
+    return out, thr
+
+
 LOSS_BLOCKS = 1024
 
 

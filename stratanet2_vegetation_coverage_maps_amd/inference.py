@@ -67,6 +67,13 @@ class ParcelMosaic:
         first of the three identical weight layers)."""
         return torch.cat([self.mean, self.wsum[:1]], 0)
 
+    def finalize(self):
+        """`finalize_merged_raster` (geotiff_raster.py:262-285) without its last, GIS step (the admissibility band needs
+        rasterio sieve / shapely buffers): (5,H,W) = [Vb, Vm_soft, Vh, Vm_hard, weights] and the hard-medium-vegetation
+        threshold that `insert_hard_med_veg_raster_band` (:119-144) searches for."""
+        out, thr = ops.mosaic_finalize(self.mean.contiguous(), self.wsum[0].contiguous())
+        return out, thr
+
 
 @torch.no_grad()
 def predict_parcel(model, batches, mosaic: ParcelMosaic, args):
