@@ -85,6 +85,16 @@ int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, in
 int sn2_three_nn(const float *src_soa, int B, int S, const float *dst_soa, int T, int k, int *idx, float *w,
                  void *ws, const int *dst_fps_ws, void *stream);
 
+/* z-normalisation of a raw plot (offline preparation): z_i - min{ z_j : |xy_i - xy_j| <= radius } --
+ * normalize_z_with_minz_in_a_radius, utils/load_data.py:237-249 (sklearn kd-tree radius query in x,y + a python loop).
+ * x, y, z (n) fp32; the test is sklearn's: fp64 reduced distance dx*dx + dy*dy <= radius*radius, inclusive.
+ * x_min..y_max: bounding box of the points (the caller has it from loading the plot).  ws: SN2_ZNORM_WS_WORDS(n, cells)
+ * 32-bit words with cells = ((x_max-x_min)/radius + 2) * ((y_max-y_min)/radius + 2), 16-byte aligned.
+ * zmin (n) and/or z_out (n) = fp32(z - zmin). */
+#define SN2_ZNORM_WS_WORDS(n, cells) ((size_t)5 * (n) + 3 * (size_t)(cells) + 8)
+int sn2_znorm(const float *x, const float *y, const float *z, int n, float radius, float x_min, float y_min, float x_max,
+              float y_max, int *ws, float *zmin, float *z_out, void *stream);
+
 /* ---- set abstraction: gather + shared MLP + BN + max -- SAModule/PointConv, model/point_net2.py:19,21-29 --- */
 typedef struct sn2_sa {
     int B, Nsrc, M, cap;            /* plots, source points per plot, centroids per plot, stride of nbr        */

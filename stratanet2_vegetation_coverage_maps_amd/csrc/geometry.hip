@@ -966,3 +966,115 @@ extern "C" int sn2_three_nn(const float* src_soa, int B, int S, const float* dst
     hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, st, src_soa, S, dst_soa, T, k, idx, w);
     SN2_RETURN_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// z-normalisation of a raw plot: z_i - min{ z_j : |xy_i - xy_j| <= r }  -- normalize_z_with_minz_in_a_radius,
+// /root/reference/utils/load_data.py:237-249 (an sklearn kd-tree radius query over x,y, then a python loop over all points).
+// sklearn works on the float64 copies of the coordinates and keeps neighbours with reduced distance
+// (dx*dx + dy*dy, summed in that order) <= r*r, inclusive: the same test is made here in fp64 without contraction.
+// Points are binned into square cells of side r (counting sort through global memory: a raw plot is one variable-length
+// cloud), every point then scans the 3 x 3 cells around its own.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void znorm_cell_kernel(const float* __restrict__ x, const float* __restrict__ y, int n,
+                                                         float x0, float y0, float inv, int GX, int GY,
+                                                         int* __restrict__ cell, int* __restrict__ hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int cx = (int)((x[i] - x0) * inv), cy = (int)((y[i] - y0) * inv);
+    cx = cx < 0 ? 0 : (cx > GX - 1 ? GX - 1 : cx);
+    cy = cy < 0 ? 0 : (cy > GY - 1 ? GY - 1 : cy);
+    const int c = cy * GX + cx;
+    cell[i] = c;
+    atomicAdd(&hist[c], 1);
+}
+
+// exclusive scan of hist (ncell <= 2^20) by one workgroup; start[c], and cursor[c] = start[c] for the scatter
+__global__ __launch_bounds__(1024) void znorm_scan_kernel(const int* __restrict__ hist, int ncell, int* __restrict__ start,
+                                                          int* __restrict__ cursor) {
+    __shared__ int s_tot[1024];
+    const int tid = threadIdx.x;
+    const int per = (ncell + 1023) / 1024;
+    int sum = 0;
+    for (int k = 0; k < per; ++k) {
+        const int c = tid * per + k;
+        if (c < ncell) sum += hist[c];
+    }
+    s_tot[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 1024; ++t) { const int v = s_tot[t]; s_tot[t] = run; run += v; }
+    }
+    __syncthreads();
+    int run = s_tot[tid];
+    for (int k = 0; k < per; ++k) {
+        const int c = tid * per + k;
+        if (c < ncell) {
+            start[c] = run;
+            cursor[c] = run;
+            run += hist[c];
+        }
+    }
+    if (tid == 1023) start[ncell] = run;
+}
+
+__global__ __launch_bounds__(256) void znorm_scatter_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ z, int n, const int* __restrict__ cell,
+                                                            int* __restrict__ cursor, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = atomicAdd(&cursor[cell[i]], 1);
+    sorted[p] = make_float4(x[i], y[i], z[i], 0.f);
+}
+
+__global__ __launch_bounds__(256) void znorm_query_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ z, int n, const int* __restrict__ cell,
+                                                          const int* __restrict__ start, const float4* __restrict__ sorted,
+                                                          int GX, int GY, double r2, float* __restrict__ zmin,
+                                                          float* __restrict__ z_out) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double qx = (double)x[i], qy = (double)y[i];
+    const int c = cell[i], cx = c % GX, cy = c / GX;
+    float best = z[i];                                    // the point is its own neighbour (distance 0)
+    for (int yy = (cy > 0 ? cy - 1 : 0); yy <= (cy < GY - 1 ? cy + 1 : GY - 1); ++yy) {
+        const int c_lo = yy * GX + (cx > 0 ? cx - 1 : 0), c_hi = yy * GX + (cx < GX - 1 ? cx + 1 : GX - 1);
+        for (int p = start[c_lo]; p < start[c_hi + 1]; ++p) {     // three adjacent cells of a row are contiguous
+            const float4 s = sorted[p];
+            const double dx = qx - (double)s.x, dy = qy - (double)s.y;
+            const double d2 = dx * dx + dy * dy;
+            if (d2 <= r2) best = fminf(best, s.z);
+        }
+    }
+    if (zmin) zmin[i] = best;
+    if (z_out) z_out[i] = (float)((double)z[i] - (double)best);   // float32 array minus a python list of minima: fp64, then cast
+}
+}  // namespace
+
+extern "C" int sn2_znorm(const float* x, const float* y, const float* z, int n, float radius, float x_min, float y_min,
+                         float x_max, float y_max, int* ws, float* zmin, float* z_out, void* stream) {
+    if (!x || !y || !z || !ws || (!zmin && !z_out) || n <= 0 || !(radius > 0.f) || !(x_max >= x_min) || !(y_max >= y_min))
+        return SN2_EINVAL;
+    // cells of side >= radius (a point's neighbours are then within the 3 x 3 block around its cell)
+    const float inv = 1.0f / (radius * 1.0001f);
+    const long gx = (long)((x_max - x_min) * inv) + 1, gy = (long)((y_max - y_min) * inv) + 1;
+    if (gx * gy > (1L << 20)) return SN2_ELIMIT;
+    const int GX = (int)gx, GY = (int)gy, ncell = GX * GY;
+    hipStream_t st = (hipStream_t)stream;
+    int* cell = ws;                                  // n
+    int* hist = cell + n;                            // ncell
+    int* start = hist + ncell;                       // ncell + 1
+    int* cursor = start + ncell + 1;                 // ncell
+    float4* sorted = reinterpret_cast<float4*>(ws + (((size_t)n + 3 * (size_t)ncell + 1 + 3) & ~(size_t)3));   // 16-byte aligned
+    if (hipMemsetAsync(hist, 0, (size_t)ncell * sizeof(int), st) != hipSuccess) return SN2_EINVAL;
+    const int blocks = sn2_cdiv(n, 256);
+    hipLaunchKernelGGL(znorm_cell_kernel, dim3(blocks), dim3(256), 0, st, x, y, n, x_min, y_min, inv, GX, GY, cell, hist);
+    hipLaunchKernelGGL(znorm_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)hist, ncell, start, cursor);
+    hipLaunchKernelGGL(znorm_scatter_kernel, dim3(blocks), dim3(256), 0, st, x, y, z, n, (const int*)cell, cursor, sorted);
+    const double r2 = (double)radius * (double)radius;
+    hipLaunchKernelGGL(znorm_query_kernel, dim3(blocks), dim3(256), 0, st, x, y, z, n, (const int*)cell, (const int*)start,
+                       (const float4*)sorted, GX, GY, r2, zmin, z_out);
+    SN2_RETURN_LAUNCH();
+}

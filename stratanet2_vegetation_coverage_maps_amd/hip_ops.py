@@ -265,6 +265,24 @@ class BlockBuffers:
         return self.aux[1]
 
 
+def znorm(xyz: torch.Tensor, radius: float):
+    """xyz (3,n) fp32 of ONE raw plot on the device -> (zmin (n), z - zmin (n)): the local-minimum z-normalisation of
+    `normalize_z_with_minz_in_a_radius` (utils/load_data.py:237-249)."""
+    _, n = xyz.shape
+    _chk(xyz, F32, (3, n), "xyz")
+    if not radius > 0:
+        raise ValueError("znorm: radius must be positive")
+    lo = xyz[:2].min(1).values.tolist()          # the caller usually has the bounding box already; here one small sync
+    hi = xyz[:2].max(1).values.tolist()
+    cells = (int((hi[0] - lo[0]) / radius) + 2) * (int((hi[1] - lo[1]) / radius) + 2)
+    ws = torch.empty(5 * n + 3 * cells + 8, dtype=I32, device=xyz.device)
+    zmin = torch.empty(n, dtype=F32, device=xyz.device)
+    zout = torch.empty(n, dtype=F32, device=xyz.device)
+    _call("sn2_znorm", _ptr(xyz[0]), _ptr(xyz[1]), _ptr(xyz[2]), n, float(radius), lo[0], lo[1], hi[0], hi[1], _ptr(ws),
+          _ptr(zmin), _ptr(zout), _stream())
+    return zmin, zout
+
+
 def sa_order_len(B: int, M: int) -> int:
     """SN2_SA_ORDER_WORDS of include/strata_hip.h."""
     return 4 * B * M + 4

@@ -153,3 +153,27 @@ def test_pack_rows():
     assert torch.equal(rows[..., :8], cloud[:, 2:].permute(0, 2, 1))
     assert torch.equal(rows[..., 8:11], xyz.permute(0, 2, 1))
     assert torch.all(rows[..., 11] == 0)
+
+
+@pytest.mark.parametrize("n,r,seed", [(3000, 1.5, 0), (777, 0.7, 1), (5000, 3.0, 2)])
+def test_znorm_matches_reference_rule(n, r, seed):
+    """Local-minimum z-normalisation of a raw plot vs the restated sklearn rule (fp64 reduced distance, inclusive),
+    cross-checked against scipy's cKDTree; points exactly at distance r included (a lattice with spacing r/2)."""
+    from oracle import prepare
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(-10, 10, (n, 2)).astype(np.float32) + np.float32(650000.0 if seed == 1 else 0.0)
+    k = int(np.sqrt(n // 4))
+    lat = (np.stack(np.meshgrid(np.arange(k), np.arange(k)), -1).reshape(-1, 2) * (r / 2)).astype(np.float32)
+    xy[: len(lat)] = lat + xy[0]
+    z = rng.uniform(0, 20, n).astype(np.float32)
+    cloud = np.concatenate([xy.T, z[None], rng.random((7, n)).astype(np.float32)], 0)
+    want = prepare.normalize_z_with_minz_in_a_radius(cloud, r)[2]
+    zmin_ref = prepare.radius_neighbors_min(xy, z, r)
+    tree = cKDTree(xy.astype(np.float64))
+    nb = tree.query_ball_point(xy.astype(np.float64), r)
+    zmin_kd = np.array([z[j].min() for j in nb], dtype=np.float32)
+    assert (zmin_kd == zmin_ref).mean() > 0.999          # the kd-tree computes true distances: boundary ties may differ
+    zmin, zout = ops.znorm(torch.from_numpy(cloud[:3].copy()).to(DEV), r)
+    assert np.array_equal(zmin.cpu().numpy(), zmin_ref)
+    assert np.array_equal(zout.cpu().numpy(), want)

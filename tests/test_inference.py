@@ -146,3 +146,18 @@ def test_mosaic_finalize_vs_reference_rule(H, W, seed):
     got = got.cpu().numpy()
     assert (np.isnan(got) == np.isnan(want)).all()
     np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want.astype(np.float32)))
+
+
+def test_oracle_znorm_rule_agrees_with_kdtree():
+    """The restated sklearn rule (brute force, fp64 reduced distance <= r^2) against scipy's kd-tree on generic points."""
+    from oracle import prepare
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-10, 10, (1500, 2)).astype(np.float32)
+    z = rng.uniform(0, 20, 1500).astype(np.float32)
+    nb = cKDTree(xy.astype(np.float64)).query_ball_point(xy.astype(np.float64), 1.5)
+    want = np.array([z[j].min() for j in nb], dtype=np.float32)
+    np.testing.assert_array_equal(prepare.radius_neighbors_min(xy, z, 1.5), want)
+    cloud = np.concatenate([xy.T, z[None]], 0)
+    out = prepare.normalize_z_with_minz_in_a_radius(cloud, 1.5)
+    assert out.dtype == np.float32 and (out[2] >= 0).all() and np.array_equal(out[:2], cloud[:2])
