@@ -85,6 +85,18 @@ int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, in
 int sn2_three_nn(const float *src_soa, int B, int S, const float *dst_soa, int T, int k, int *idx, float *w,
                  void *ws, const int *dst_fps_ws, void *stream);
 
+/* Input pipeline of a batch: load_cloud of the reference DataLoader, data_loader/loader.py:73-87 --
+ * centre, append the fake ground points, keep xyz, [train: rotate about z, flip, add noise], rescale, gather the subsample --
+ * one thread per output point.  raw (10,T): the B plots' raw points side by side (rows x, y, z, red, green, blue,
+ * near_infrared, intensity, return_num, num_returns), offsets (B+1), centers (B,2); fake_xy (n_fake,2): the positions that
+ * add_fake_empty_ground_points appends to every plot; idx (B,N): the subsample of each plot, values in
+ * [0, raw points of the plot + n_fake); rot (B,2) fp64 = cos, sin of the rotation, flips (B,2); noise (6,noise_T) or NULL
+ * = the clipped gaussian noise of x, y, red, green, blue, near_infrared for every point of every plot BEFORE subsampling
+ * (fake points included), noise_offsets (B).  Outputs cloud (B,10,N), xyz (B,3,N).  All random draws are the caller's. */
+int sn2_prepare_plots(const float *raw, long T, const int *offsets, const float *centers, const float *fake_xy, int n_fake,
+                      const int *idx, int B, int N, int train, const double *rot, const int *flips, const float *noise,
+                      const long *noise_offsets, long noise_T, float z_max, float *cloud, float *xyz, void *stream);
+
 /* z-normalisation of a raw plot (offline preparation): z_i - min{ z_j : |xy_i - xy_j| <= radius } --
  * normalize_z_with_minz_in_a_radius, utils/load_data.py:237-249 (sklearn kd-tree radius query in x,y + a python loop).
  * x, y, z (n) fp32; the test is sklearn's: fp64 reduced distance dx*dx + dy*dy <= radius*radius, inclusive.

@@ -178,4 +178,85 @@ extern "C" int sn2_adam_step(float* param, const float* grad, float* exp_avg, fl
     SN2_RETURN_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Input pipeline of a batch: load_cloud of the reference DataLoader (/root/reference/data_loader/loader.py:73-87) --
+// center_cloud :127-132, add_fake_empty_ground_points :90-105, augment :161-214, rescale_cloud :135-158 and the gather of
+// sample_cloud_data :233-255 -- for all plots of a batch in one kernel, one thread per OUTPUT point.  The random draws
+// (angle, flips, subsample indices, noise) are inputs.  Arithmetic follows numpy 1.21 (the reference's pin): a float32
+// array combined with a python/np.float64 scalar stays float32; the rotation is a float64 product cast back to float32.
+// Row order of a raw point: x, y, z, red, green, blue, near_infrared, intensity, return_num, num_returns (config.py:66).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void prepare_plots_kernel(const float* __restrict__ raw, long T, const int* __restrict__ offs,
+                                                            const float* __restrict__ centers, const float* __restrict__ fake_xy,
+                                                            int n_fake, const int* __restrict__ idx, int B, int N, int train,
+                                                            const double* __restrict__ rot, const int* __restrict__ flips,
+                                                            const float* __restrict__ noise, const long* __restrict__ noise_offs,
+                                                            long noise_T, float z_max, float* __restrict__ cloud,
+                                                            float* __restrict__ xyz) {
+#pragma clang fp contract(off)
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long)B * N) return;
+    const int b = (int)(o / N), n = (int)(o - (long)b * N);
+    const int lo = offs[b], n_raw = offs[b + 1] - lo;
+    const int src = idx[o];
+    float v[10];
+    if (src < n_raw) {
+#pragma unroll
+        for (int c = 0; c < 10; ++c) v[c] = raw[(size_t)c * T + lo + src];
+        v[0] = v[0] - centers[2 * b];                     // center_cloud: before the fake points are appended
+        v[1] = v[1] - centers[2 * b + 1];
+    } else {
+        const int k = src - n_raw;                        // fake ground point k: position only, features 0
+        v[0] = k < n_fake ? fake_xy[2 * k] : 0.f;
+        v[1] = k < n_fake ? fake_xy[2 * k + 1] : 0.f;
+#pragma unroll
+        for (int c = 2; c < 10; ++c) v[c] = 0.f;
+    }
+    float px = v[0], py = v[1];
+    const float pz = v[2];                                // xyz = cloud[:3].copy(): metres, never rescaled
+    if (train) {
+        const double cs = rot[2 * b], sn = rot[2 * b + 1];    // np.dot(cloud[:2].T, [[c,-s],[s,c]]).T in float64
+        const double rx = (double)v[0] * cs + (double)v[1] * sn, ry = (double)v[0] * (-sn) + (double)v[1] * cs;
+        v[0] = px = (float)rx;
+        v[1] = py = (float)ry;
+        if (flips[2 * b]) { v[0] = -v[0]; px = -px; }
+        if (flips[2 * b + 1]) { v[1] = -v[1]; py = -py; }
+        if (noise) {                                      // noise rows: x, y, red, green, blue, nir; columns: the plot's points
+            const long q = noise_offs[b] + src;           // BEFORE subsampling (duplicates of a point share their noise)
+            v[0] += noise[q];
+            v[1] += noise[noise_T + q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[3 + c] += noise[(2 + c) * noise_T + q];
+        }
+    }
+    v[0] = v[0] / 10.f;                                   // rescale_cloud
+    v[1] = v[1] / 10.f;
+    v[2] = v[2] / z_max;
+#pragma unroll
+    for (int c = 3; c < 7; ++c) v[c] = v[c] / 65536.f;
+    v[7] = v[7] / 32768.f;
+    v[8] = (v[8] - 1.f) / 6.f;
+    v[9] = (v[9] - 1.f) / 6.f;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) cloud[((size_t)b * 10 + c) * N + n] = v[c];
+    xyz[((size_t)b * 3 + 0) * N + n] = px;
+    xyz[((size_t)b * 3 + 1) * N + n] = py;
+    xyz[((size_t)b * 3 + 2) * N + n] = pz;
+}
+}  // namespace
+
+extern "C" int sn2_prepare_plots(const float* raw, long T, const int* offsets, const float* centers, const float* fake_xy,
+                                 int n_fake, const int* idx, int B, int N, int train, const double* rot, const int* flips,
+                                 const float* noise, const long* noise_offsets, long noise_T, float z_max, float* cloud,
+                                 float* xyz, void* stream) {
+    if (!raw || !offsets || !centers || !idx || !cloud || !xyz || B <= 0 || N <= 0 || T <= 0 || !(z_max > 0.f)) return SN2_EINVAL;
+    if (n_fake > 0 && !fake_xy) return SN2_EINVAL;
+    if (train && (!rot || !flips)) return SN2_EINVAL;
+    if (noise && !noise_offsets) return SN2_EINVAL;
+    hipLaunchKernelGGL(prepare_plots_kernel, dim3(sn2_cdiv((long)B * N, 256)), dim3(256), 0, (hipStream_t)stream, raw, T, offsets,
+                       centers, fake_xy, n_fake, idx, B, N, train, rot, flips, noise, noise_offsets, noise_T, z_max, cloud, xyz);
+    SN2_RETURN_LAUNCH();
+}
+
 extern "C" int sn2_version(void) { return SN2_VERSION; }

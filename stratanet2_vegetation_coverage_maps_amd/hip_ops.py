@@ -265,6 +265,35 @@ class BlockBuffers:
         return self.aux[1]
 
 
+def prepare_plots(raw, offsets, centers, fake_xy, idx, z_max: float, rot=None, flips=None, noise=None, noise_offsets=None):
+    """include/strata_hip.h: sn2_prepare_plots.  raw (10,T) f32, offsets (B+1) i32, centers (B,2) f32, fake_xy (F,2) f32,
+    idx (B,N) i32; train iff rot (B,2) f64 and flips (B,2) i32 are given; noise (6,Tn) f32 + noise_offsets (B) i64 optional.
+    -> cloud (B,10,N), xyz (B,3,N)."""
+    C, T = raw.shape
+    B, N = idx.shape
+    _chk(raw, F32, (10, T), "raw")
+    _chk(offsets, I32, (B + 1,), "offsets")
+    _chk(centers, F32, (B, 2), "centers")
+    F = fake_xy.shape[0]
+    _chk(fake_xy, F32, (F, 2), "fake_xy")
+    _chk(idx, I32, (B, N), "idx")
+    train = rot is not None
+    if train:
+        _chk(rot, F64, (B, 2), "rot")
+        _chk(flips, I32, (B, 2), "flips")
+    Tn = 0
+    if noise is not None:
+        Tn = noise.shape[1]
+        _chk(noise, F32, (6, Tn), "noise")
+        _chk(noise_offsets, I64, (B,), "noise_offsets")
+    dev = raw.device
+    cloud = torch.empty(B, 10, N, dtype=F32, device=dev)
+    xyz = torch.empty(B, 3, N, dtype=F32, device=dev)
+    _call("sn2_prepare_plots", _ptr(raw), T, _ptr(offsets), _ptr(centers), _ptr(fake_xy), F, _ptr(idx), B, N, int(train),
+          _ptr(rot), _ptr(flips), _ptr(noise), _ptr(noise_offsets), Tn, float(z_max), _ptr(cloud), _ptr(xyz), _stream())
+    return cloud, xyz
+
+
 def znorm(xyz: torch.Tensor, radius: float):
     """xyz (3,n) fp32 of ONE raw plot on the device -> (zmin (n), z - zmin (n)): the local-minimum z-normalisation of
     `normalize_z_with_minz_in_a_radius` (utils/load_data.py:237-249)."""

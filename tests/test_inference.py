@@ -161,3 +161,50 @@ def test_oracle_znorm_rule_agrees_with_kdtree():
     cloud = np.concatenate([xy.T, z[None]], 0)
     out = prepare.normalize_z_with_minz_in_a_radius(cloud, 1.5)
     assert out.dtype == np.float32 and (out[2] >= 0).all() and np.array_equal(out[:2], cloud[:2])
+
+
+def _raw_plot(n, seed, center):
+    rng = np.random.default_rng(seed)
+    rad, th = 10 * np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    return np.stack([center[0] + rad * np.cos(th), center[1] + rad * np.sin(th), 20 * rng.random(n) ** 3,
+                     *(65535 * rng.random((4, n))), 32767 * rng.random(n), rng.integers(1, 8, n), rng.integers(1, 8, n)]
+                    ).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_device_input_pipeline_matches_load_cloud(train):
+    """One kernel for the batch vs the restated `load_cloud` per plot, same numpy random stream: rescaled features, metric
+    xyz, fake ground points, subsampling with and without replacement.  Exact, except the rotated x,y (a float64 product
+    rounded to float32: BLAS may fuse it) where one float32 ulp is allowed."""
+    from oracle import prepare
+    from stratanet2_vegetation_coverage_maps_amd import input_pipeline
+    args = make_args(subsample_size=3000)
+    centers = np.array([[650123.5, 6861234.0], [12.25, -7.5], [0.0, 0.0]], dtype=np.float32)
+    raw = [_raw_plot(n, i, centers[i]) for i, n in enumerate((5000, 1200, 2684))]       # 2684 + 316 fake = 3000 exactly
+    rs_a, rs_b = np.random.RandomState(7), np.random.RandomState(7)
+    want = [prepare.load_cloud(r, c, args, train, rs_a) for r, c in zip(raw, centers)]
+    got = input_pipeline.prepare_batch(raw, centers, args, train, rs=rs_b, device="cuda:0")
+    assert got["cloud"].shape == (3, 10, 3000) and got["xyz"].shape == (3, 3, 3000)
+    for b, (wc, wx) in enumerate(want):
+        gc, gx = got["cloud"][b].cpu().numpy(), got["xyz"][b].cpu().numpy()
+        np.testing.assert_array_equal(gc[2:], wc[2:])
+        np.testing.assert_array_equal(gx[2], wx[2])
+        if train:
+            np.testing.assert_allclose(gx[:2], wx[:2], rtol=2e-7, atol=1e-6)
+            np.testing.assert_allclose(gc[:2], wc[:2], rtol=2e-7, atol=1e-7)
+        else:
+            np.testing.assert_array_equal(gx[:2], wx[:2])
+            np.testing.assert_array_equal(gc[:2], wc[:2])
+    assert rs_a.random() == rs_b.random()                       # both sides consumed the same number of draws
+    dev_noise = input_pipeline.prepare_batch(raw, centers, args, True, rs=np.random.RandomState(1), device="cuda:0", noise="device")
+    assert torch.isfinite(dev_noise["cloud"]).all()
+
+
+def test_fake_ground_points_rule():
+    from stratanet2_vegetation_coverage_maps_amd import input_pipeline
+    from oracle import prepare
+    f = input_pipeline.fake_ground_xy(20)
+    assert f.shape == (316, 2) and f.dtype == np.float32
+    ref = prepare.add_fake_empty_ground_points(20, 10, np.zeros((10, 0), dtype=np.float32))
+    assert ref.shape == (10, 316) and np.array_equal(ref[:2].T, f) and not ref[2:].any()
