@@ -153,11 +153,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    # rehearsal knobs (never set by the driver): all ranks on one device / the gloo backend, to run the N > 1 code path on
+    # a one-GPU box
+    if os.environ.get("SN2_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("SN2_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     B = PLOTS_PER_GPU
     args = workload_args(local_rank)
