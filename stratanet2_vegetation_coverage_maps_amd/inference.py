@@ -76,15 +76,40 @@ class ParcelMosaic:
 
 
 @torch.no_grad()
-def predict_parcel(model, batches, mosaic: ParcelMosaic, args):
+def predict_parcel(model, batches, mosaic: ParcelMosaic, args, prefetch: int = 3):
     """`batches`: iterable of dicts with "cloud" (B,10,N), "xyz" (B,3,N), "plot_center" (B,2) (the reference DataLoader's
-    collate of `inference/predict_utils.py:74-82`).  Returns the number of plots processed."""
+    collate of `inference/predict_utils.py:74-82`).  Returns the number of plots processed.
+    prefetch: how many batches ahead the position-only kernels (FPS, ball query, 3-NN) run, each on its own side stream
+    (`PointNet2.prefetch_geometry`), while this batch's feature kernels, rasters and merge run.  FPS is M sequential rounds
+    in one workgroup per plot -- 64 plots keep 64 of 256 CUs busy for most of an un-overlapped batch -- so several passes
+    in flight is what fills the chip; 0 = no overlap."""
+    from collections import deque
     model.eval()
     n = 0
-    for cloud_data in batches:
-        cov, _ = model(cloud_data)
+    it = iter(batches)
+    window = deque()                       # (batch, geometry handle or None), oldest first
+    issued = 0
+
+    def fill():
+        nonlocal issued
+        while len(window) < max(1, prefetch):
+            b = next(it, None)
+            if b is None:
+                return
+            geo = model.prefetch_geometry(b, lane=issued % prefetch) if prefetch > 0 else None
+            window.append((b, geo))
+            issued += 1
+
+    fill()
+    while window:
+        cur, geo = window.popleft()
+        fill()
+        cd = dict(cur)
+        if geo is not None:
+            cd["geometry"] = geo
+        cov, _ = model(cd)
         clouds_dev = model._last_cloud_dev[1]
         rasters, _ = project_batch_to_2d_rasters(clouds_dev, cov, args)
-        mosaic.add(rasters, cloud_data["plot_center"])
+        mosaic.add(rasters, cur["plot_center"])
         n += clouds_dev.shape[0]
     return n

@@ -258,18 +258,21 @@ class PointNet2(nn.Module):
         g.inv1 = ops.interp_index(g.knn1, B, N, M1)
         return g
 
-    def prefetch_geometry(self, cloud_data):
+    def prefetch_geometry(self, cloud_data, lane: int = 0):
         """Run the position-only kernels of a batch on a side stream, ahead of time (typically for batch k+1 while
         batch k is in its backward pass: the FPS rounds are sequential and occupy one CU per plot, the feature kernels
-        fill the rest of the chip).  Returns a handle to put into `cloud_data["geometry"]` for the forward call."""
+        fill the rest of the chip).  Returns a handle to put into `cloud_data["geometry"]` for the forward call.
+        `lane` selects one of several side streams, so that the passes of several batches can be in flight at once."""
         dev = self.lin1.weight.device
         if dev.type != "cuda":
             raise StrataHipError("prefetch_geometry needs a HIP device")
         with torch.cuda.device(dev):
-            if getattr(self, "_geo_stream", None) is None:
-                self._geo_stream = torch.cuda.Stream(device=dev)
+            if getattr(self, "_geo_streams", None) is None:
+                self._geo_streams = {}
+            if lane not in self._geo_streams:
+                self._geo_streams[lane] = torch.cuda.Stream(device=dev)
             xyz_d, fs = self._stage_positions(cloud_data, dev)
-            side = self._geo_stream
+            side = self._geo_streams[lane]
             side.wait_stream(torch.cuda.current_stream())
             # staged on the current stream, read by kernels of the side stream long after this function has returned:
             # without this the allocator may hand the start indices' memory to the next forward while FPS level 2 still
