@@ -135,6 +135,7 @@ def cpu_baseline():
 
 
 def main():
+    global N_POINTS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -144,6 +145,9 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="headline = the unpipelined step (geometry and features of a batch back to back on one stream)")
     ap.add_argument("--depth", type=int, default=3, help="geometry passes kept in flight ahead of the feature pass")
+    ap.add_argument("--points", type=int, default=N_POINTS, help="points per plot (default = the metric's 32768; other "
+                    "values are extra measurements, e.g. 131072 with --plots 8 for BASELINE config 5's plot size)")
+    ap.add_argument("--plots", type=int, default=PLOTS_PER_GPU, help="plots per GPU (default = the metric's 16)")
     ap.add_argument("--split-exchange", action="store_true",
                     help="one GPU: use the multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
     a = ap.parse_args()
@@ -167,7 +171,7 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
 
-    B = PLOTS_PER_GPU
+    B, N_POINTS = a.plots, a.points
     args = workload_args(local_rank)
     torch.manual_seed(0)                       # identical initial weights on every rank
     model = PointNet2(args).train()
@@ -366,7 +370,8 @@ def main():
         out = {"metric": "plots/s fwd+bwd, 32k-pt synthetic plots, batch 16/GPU", "value": round(world * B / (ms * 1e-3), 2),
                "unit": "plots/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "C2 ref-arch: 16 plots/GPU x 32768 pts, SA npoint 1024/256 + global, r 1/2 m, "
+               "config": {"workload": ("C2 ref-arch" if (B, N_POINTS) == (16, 32768) else "ref-arch, NOT the metric's size") +
+                                      f": {B} plots/GPU x {N_POINTS} pts, SA npoint 1024/256 + global, r 1/2 m, "
                                       "train step fwd+P2+loss+bwd+Adam, inputs resident in HBM",
                           "mode": mode + ("" if a.serial else
                                           ": every step runs one geometry pass (FPS, ball query, 3-NN of a later batch, side "

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
                                                           float4* sorted, int* __restrict__ idx_out,
                                                           float* __restrict__ cpos_soa, float* __restrict__ cpos_aos) {
     constexpr int NBK = SPW * NW;
-    static_assert(SPW <= 64 && NW <= 16, "one lane per bucket slot of the wave");
+    constexpr int SL = (SPW + 63) / 64;                // bucket slots per lane: slot s = 64 h + lane, h < SL
+    static_assert(SPW <= 128 && NW <= 16, "at most two bucket slots per lane");
     __shared__ float s_box[6 * NBK];                   // bucket boxes, [component][wave][slot]: lane j reads word j of its
                                                        // wave's row => conflict-free (an AoS box layout cost 32-way conflicts)
     __shared__ float4 s_xchg[2][2][NW];                // per wave: (max distance, tie flag, -, -) and (x, y, z, sorted position)
@@ -308,10 +309,17 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
     // lane j < SPW keeps the state of bucket slot j of this wave in registers: its maximal running distance, the point
     // attaining it (lowest lane on ties) and whether several points share the maximum (then the lowest ORIGINAL index must
     // be found the slow way)
-    float mine = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
-    int bpos = 0;
-    bool tiej = false;
-    if (lane < SPW && (lane * NW + wave) * 64 < N) mine = INFINITY;
+    float mine[SL], bx[SL], by[SL], bz[SL];
+    int bpos[SL];
+    bool tiej[SL];
+#pragma unroll
+    for (int h = 0; h < SL; ++h) {
+        const int sl = 64 * h + lane;
+        mine[h] = (sl < SPW && (sl * NW + wave) * 64 < N) ? INFINITY : -1.f;
+        bx[h] = by[h] = bz[h] = 0.f;
+        bpos[h] = 0;
+        tiej[h] = false;
+    }
     int cur = start ? start[b] : 0;
     cur = cur < 0 ? 0 : (cur >= N ? N - 1 : cur);
     cur = __builtin_amdgcn_readfirstlane(cur);
@@ -331,14 +339,16 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
         const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), first));
         const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), first));
         const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), first));
-        if (lane == k) {
-            mine = m;
-            tiej = __popcll(bal) > 1;
-            bx = fx;
-            by = fy;
-            bz = fz;
-            bpos = p - lane + first;
-        }
+#pragma unroll
+        for (int h = 0; h < SL; ++h)
+            if (k == 64 * h + lane) {
+                mine[h] = m;
+                tiej[h] = __popcll(bal) > 1;
+                bx[h] = fx;
+                by[h] = fy;
+                bz[h] = fz;
+                bpos[h] = p - lane + first;
+            }
     };
 
     for (int i = 0; i < M; ++i) {
@@ -352,43 +362,70 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
         }
         if (i == M - 1) break;
         STAMP(t0);
-        // (a) which of this wave's buckets can change?  lane j tests slot j
-        bool dirty = false;
-        if (lane < SPW) {
-            dirty = sn2_box_d2(my_box[0 * NBK + lane], my_box[1 * NBK + lane], my_box[2 * NBK + lane], my_box[3 * NBK + lane],
-                               my_box[4 * NBK + lane], my_box[5 * NBK + lane], cx, cy, cz) < mine;
+        // (a) which of this wave's buckets can change?  lane j tests slots j, j + 64, ...
+        unsigned long long masks[SL];
+#pragma unroll
+        for (int h = 0; h < SL; ++h) {
+            const int sl = 64 * h + lane;
+            bool dirty = false;
+            if (sl < SPW) {
+                dirty = sn2_box_d2(my_box[0 * NBK + sl], my_box[1 * NBK + sl], my_box[2 * NBK + sl], my_box[3 * NBK + sl],
+                                   my_box[4 * NBK + sl], my_box[5 * NBK + sl], cx, cy, cz) < mine[h];
+            }
+            masks[h] = __ballot(dirty);
         }
-        unsigned long long mask = __ballot(dirty);
         STAMP(t1);
 #ifdef SN2_FPS_STAMPS
-        const int ndirty = __popcll(mask);
+        int ndirty = 0;
+#pragma unroll
+        for (int h = 0; h < SL; ++h) ndirty += __popcll(masks[h]);
 #endif
         // (b) update the dirty buckets, four at a time so that their L2 loads overlap
-        while (mask) {
-            int k[4], p[4];
-            bool on[4];
-            float4 q[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                on[u] = mask != 0;
-                k[u] = on[u] ? __ffsll((long long)mask) - 1 : 0;
-                mask &= mask - 1;   // no-op when mask == 0
-                p[u] = (k[u] * NW + wave) * 64 + lane;
-                q[u] = pts[p[u] < N ? p[u] : 0];
+        for (int h = 0; h < SL; ++h) {
+            unsigned long long mask = masks[h];
+            while (mask) {
+                int k[4], p[4];
+                bool on[4];
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    on[u] = mask != 0;
+                    k[u] = 64 * h + (on[u] ? __ffsll((long long)mask) - 1 : 0);
+                    mask &= mask - 1;   // no-op when mask == 0
+                    p[u] = (k[u] * NW + wave) * 64 + lane;
+                    q[u] = pts[p[u] < N ? p[u] : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (on[u]) update(k[u], p[u], q[u]);   // the round loop is VALU-issue bound: no duplicated work
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (on[u]) update(k[u], p[u], q[u]);   // the round loop is VALU-issue bound: no duplicated work
         }
         STAMP(t2);
         // (c) this wave's best bucket, then ONE barrier and the best of the 16 waves
-        const float wm = wave_max_dpp(lane < SPW ? mine : -1.f);
-        const unsigned long long balw = __ballot(lane < SPW && mine == wm);
-        const int slot = __ffsll((long long)balw) - 1;
-        if (lane == slot) {
-            const int wtie = (__popcll(balw) > 1) || tiej;
-            s_xchg[i & 1][0][wave] = make_float4(wm, __int_as_float(wtie), 0.f, 0.f);
-            s_xchg[i & 1][1][wave] = make_float4(bx, by, bz, __int_as_float(bpos));
+        float lm = -1.f;
+#pragma unroll
+        for (int h = 0; h < SL; ++h) lm = fmaxf(lm, mine[h]);               // invalid slots hold -1
+        const float wm = wave_max_dpp(lm);
+        int nbest = 0;
+        bool published = false;
+#pragma unroll
+        for (int h = 0; h < SL; ++h) {
+            const unsigned long long balw = __ballot(mine[h] == wm);
+            nbest += __popcll(balw);
+        }
+#pragma unroll
+        for (int h = 0; h < SL; ++h) {
+            const unsigned long long balw = __ballot(mine[h] == wm);
+            if (balw && !published) {                                        // wave-uniform: the first slot group that has it
+                const int slot = __ffsll((long long)balw) - 1;
+                if (lane == slot) {
+                    const int wtie = (nbest > 1) || tiej[h];
+                    s_xchg[i & 1][0][wave] = make_float4(wm, __int_as_float(wtie), 0.f, 0.f);
+                    s_xchg[i & 1][1][wave] = make_float4(bx[h], by[h], bz[h], __int_as_float(bpos[h]));
+                }
+                published = true;
+            }
         }
         STAMP(t3);
         __syncthreads();
@@ -408,16 +445,19 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
             // rare exact tie of the maximal distance (duplicated points): lowest ORIGINAL index among all candidates
             if (tid == 0) s_win = 0xFFFFFFFFu;
             __syncthreads();
-            unsigned long long cand = __ballot(lane < SPW && mine == V);
-            while (cand) {
-                const int kk = __ffsll((long long)cand) - 1;
-                cand &= cand - 1;
-                const int pp = (kk * NW + wave) * 64 + lane;
-                const float d = pp < N ? pts[pp].w : -1.f;
-                unsigned oi = 0xFFFFFFFFu;
-                if (d == V) oi = (unsigned)ord[pp];
-                oi = wave_min_u32_dpp(oi);
-                if (lane == 0) atomicMin(&s_win, oi);
+#pragma unroll
+            for (int h = 0; h < SL; ++h) {
+                unsigned long long cand = __ballot(mine[h] == V);
+                while (cand) {
+                    const int kk = 64 * h + __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const int pp = (kk * NW + wave) * 64 + lane;
+                    const float d = pp < N ? pts[pp].w : -1.f;
+                    unsigned oi = 0xFFFFFFFFu;
+                    if (d == V) oi = (unsigned)ord[pp];
+                    oi = wave_min_u32_dpp(oi);
+                    if (lane == 0) atomicMin(&s_win, oi);
+                }
             }
             __syncthreads();
             cur = __builtin_amdgcn_readfirstlane((int)s_win);
@@ -460,11 +500,13 @@ extern "C" int sn2_fps(const float* pos_soa, int B, int N, int M, const int* sta
     if (!pos_soa || !idx || !cpos_soa || !cpos_aos || B <= 0 || N <= 0 || M <= 0 || M > N) return SN2_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (order_ws && N > 2048 && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
-        // bucketed path (exact, see above); the running distances of a plot must fit LDS: N <= 32768
+        // bucketed path (exact, see above): up to 128 bucket slots per wave = 131 072 points per plot
         if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         if (N <= 32768) return launch_fps_bucket<32>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 65536) return launch_fps_bucket<64>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 131072) return launch_fps_bucket<128>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         return SN2_ELIMIT;
     }
     if (N <= 256) return launch_fps<1, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);

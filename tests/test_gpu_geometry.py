@@ -46,6 +46,28 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
     assert torch.equal(i_b.cpu().long(), ref)
 
 
+@pytest.mark.parametrize("B,N,M", [(1, 131072, 1024), (2, 65536, 300), (1, 100000, 257)])
+def test_bucketed_fps_on_dense_plots(B, N, M):
+    """BASELINE config 5's plot size (128k points): two bucket slots per lane.  No brute-force kernel exists above 32768
+    points, so the oracle is the checker; duplicates included."""
+    xyz, _ = _pos(B, N, first=5)
+    q = N // 8
+    xyz[:, :, N - q:] = xyz[:, :, :q]
+    start = torch.tensor([(977 * b + 13) % N for b in range(B)])
+    i_b, cs_b, ca_b, ws = ops.fps(xyz.to(DEV), M, start.to(DEV, torch.int32), return_ws=True)
+    assert ws is not None
+    ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, start)
+    assert torch.equal(i_b.cpu().long(), ref)
+    # the ball query and the 3-NN table over the same workspace, against their full scans
+    nbr_g, cnt_g, _ = ops.ball_query(xyz.to(DEV), cs_b, 1.0, 2000, fps_ws=ws)
+    nbr_f, cnt_f, _ = ops.ball_query(xyz.to(DEV), cs_b, 1.0, 2000)
+    mask = torch.arange(nbr_f.shape[1], device=DEV).unsqueeze(0) < cnt_f.unsqueeze(1)
+    assert torch.equal(cnt_g, cnt_f) and torch.equal(nbr_g[mask], nbr_f[mask])
+    a_i, a_w = ops.three_nn(cs_b, xyz.to(DEV), 3, dst_fps_ws=ws)
+    b_i, b_w = ops.three_nn(cs_b, xyz.to(DEV), 3, grid=False)
+    assert torch.equal(a_i, b_i) and torch.equal(a_w, b_w)
+
+
 def test_fps_with_duplicate_points_and_default_start():
     """sample_cloud pads small plots by sampling with replacement (loader.py:238-244) => exact ties."""
     xyz, _ = _pos(1, 500)

@@ -253,3 +253,34 @@ def test_kde_lookup_matches_scipy_interp1d():
     tab = dev_losses.KdeTables(np.linspace(0.0, 1.0, 10), *[np.ones(10)] * 3, device="cuda:0")
     out = dev_losses.kde_densities(d["cloud"].cuda(), z_max, tab)
     assert torch.isnan(out).any() and not torch.isnan(out).all()
+
+
+def test_dense_plot_128k_points_vs_oracle():
+    """BASELINE config 5's plot size through the whole network (fp32; the bf16 variant is not built): one 131 072-point
+    plot, forward + loss + backward against the oracle (kd-tree candidate search, canonical fp32 tests)."""
+    N = 131072
+    args = make_args(subsample_size=N, ratio1=1024 / N, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(1, N, first_plot=77)
+    sd = network.init_state_dict(1)
+    fs = torch.tensor([[123], [7]])
+    d["fps_start"] = fs
+    m = _model(args, sd).train()
+    cov, proba = m(d)
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+    from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
+    loss, _ = dev_losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
+    loss.backward()
+    sd_r = {k: v.clone() for k, v in sd.items()}
+    for k in network.param_keys(sd_r):
+        sd_r[k].requires_grad_(True)
+    cov_r, proba_r, _ = network.forward(sd_r, d["cloud"], d["xyz"], args, training=True, fps_start=(fs[0], fs[1]),
+                                        use_kdtree=True)
+    pred_r = projection.project_to_plotwise_coverages(cov_r, d["cloud"], args)
+    loss_r, _ = losses.total_loss(pred_r, proba_r, d["coverages"], d["pdf_all"], args.m, args.e)
+    loss_r.backward()
+    np.testing.assert_allclose(cov.detach().cpu().numpy(), cov_r.detach().numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(proba.detach().cpu().numpy(), proba_r.detach().numpy(), atol=TOL, rtol=0)
+    assert abs(loss.item() - loss_r.item()) < TOL
+    for k, p in m.named_parameters():
+        ref = sd_r[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-6 + 2e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
