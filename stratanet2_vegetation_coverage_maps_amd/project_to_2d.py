@@ -1,7 +1,6 @@
 """Drop-in for the reference `model/project_to_2d.py`: same two functions, same arguments, same results, but one
 scatter-max kernel sequence on the device instead of per-plot python loops with `torch.unique`, torch_scatter and
 device<->CPU bounces (`/root/reference/model/project_to_2d.py:7-55` and `:58-113`)."""
-import numpy as np
 import torch
 
 from . import hip_ops as ops
