@@ -119,6 +119,10 @@ def test_predict_parcel_end_to_end():
             for i in range(4):
                 rasters.append(project_to_2d_rasters(b["cloud"][i], cov_b[i], args))
             offs.append(mos.offsets(b["plot_center"]).numpy())
+    # the same parcel without any overlap of geometry and features: identical mosaic
+    mos0 = inference.ParcelMosaic(0.0, 80.0, H, W, args, torch.device("cuda:0"))
+    assert inference.predict_parcel(model, batches, mos0, args, prefetch=0) == 12
+    assert torch.equal(torch.nan_to_num(mos0.result()), torch.nan_to_num(mos.result()))
     want = omosaic.mosaic(np.stack(rasters), np.concatenate(offs), H, W, args.diam_pix)
     assert (np.isnan(got[:3]) == np.isnan(want[:3])).all()
     np.testing.assert_allclose(got[:3], want[:3], rtol=1e-5, atol=1e-6, equal_nan=True)
