@@ -67,7 +67,9 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
         "sn2_sa_backward:cf=16": 84 * e2 + 64 * e2 + 2 * 128 * m2 * B,
         # FP1: 24 B knn + 32 B skip + 3 x 144 B gathered rows (L2) read, 144 B written per point
         "sn2_fp_forward:34+8->34": (24 + 32 + 144) * N * B,
-        "sn2_fp_backward:34+8->34": (2 * 288 + 24 + 32 + 136 + 136 + 24 + 136) * N * B,
+        # FP1 backward: h + dy rows once (288 B; the BN sums come from the head's gradients), knn 24 B, skip 32 B, du written
+        # and read back 2 x 136 B, inverted-index entries 24 B, 3 gathered source rows (L2) counted once as 136 B
+        "sn2_fp_backward:34+8->34": (288 + 24 + 32 + 136 + 136 + 24 + 136) * N * B,
         "sn2_head_forward": (144 + 32) * N * B,
         "sn2_head_backward": (144 + 32 + 144) * N * B,
         "sn2_plot_project_forward": (8 + 8 + 16 + 4) * N * B + 24 * D * D * B,

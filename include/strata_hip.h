@@ -156,6 +156,8 @@ typedef struct sn2_fp {
     float *scatter_ws;              /* backward workspace when knn_idx and dsrc are given: SN2_INTERP_WS_WORDS(B,R,S)
                                        32-bit words (inverted index of the 3-NN table)                           */
     int scatter_ready;              /* non-zero: scatter_ws already holds the index (sn2_interp_index)           */
+    int bn_sums_ready;              /* non-zero: blk.dgamma / blk.dbeta already hold this BatchNorm's gradients
+                                       (sn2_head_bn_sums): sn2_fp_backward skips its pass over the rows          */
 } sn2_fp;
 /* The transpose of knn_interpolate (its backward) is done as a gather through an inverted index of the 3-NN table:
  * source -> list of (target row, normalised weight).  The index depends on positions only, so it can be built ahead of
@@ -186,6 +188,10 @@ typedef struct sn2_head {
 } sn2_head;
 int sn2_head_forward(const sn2_head *p, void *stream);
 int sn2_head_backward(const sn2_head *p, void *stream);
+/* After sn2_head_backward: the gradients of the BatchNorm whose output the head reads (FP1's), obtained from lin1's weight
+ * and bias gradients instead of a pass over all rows (derivation in fp.hip).  gamma, beta: that BatchNorm's parameters
+ * (gamma must be non-zero); dgamma, dbeta: ACCUMULATED. */
+int sn2_head_bn_sums(const sn2_head *p, const float *gamma, const float *beta, float *dgamma, float *dbeta, void *stream);
 
 /* ---- 2D projections -- model/project_to_2d.py -------------------------------------------------------------- */
 

@@ -671,7 +671,9 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     // waves per workgroup (one workgroup per CU): as many as the staging regions and 256 VGPRs per lane allow
     constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 8 <= 150 * 1024) ? 8 : ((Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : 2);
     const int R = p->B * p->R_per_plot;
-    if (R <= (1 << 16)) {
+    if (p->bn_sums_ready) {
+        // dgamma / dbeta of this block's BatchNorm were produced by the consumer (sn2_head_bn_sums): no pass over the rows
+    } else if (R <= (1 << 16)) {
         hipLaunchKernelGGL((fp_bwd_bn_small_kernel<CO>), dim3(sn2_cdiv(R, 64)), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
                            p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta);
     } else {
@@ -947,6 +949,28 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
     }
 }
 
+// dgamma / dbeta of the BatchNorm that feeds lin1, from lin1's own gradients.  With y = gamma*xhat + beta the input of lin1
+// and dy = W1^T dpre its gradient:
+//   dbeta[o]  = sum_r dy[r][o]            = sum_j W1[j][o] * db1[j]
+//   dgamma[o] = sum_r dy[r][o]*xhat[r][o] = sum_j W1[j][o] * G[j][o],   G[j][o] = sum_r dpre[r][j]*xhat[r][o]
+// and dW1[j][o] = sum_r dpre[r][j]*y[r][o] = gamma[o]*G[j][o] + beta[o]*db1[j], so G = (dW1 - beta*db1) / gamma.
+// 2 x 34 dot products of length 16 instead of a pass over all rows (0.03 ms and 150 MB at C2).  Needs gamma != 0.
+__global__ void head_bn_sums_kernel(int cin, int c1, const float* __restrict__ W1, const float* __restrict__ dW1,
+                                    const float* __restrict__ db1, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int o = threadIdx.x;
+    if (o >= cin) return;
+    double sb = 0.0, sg = 0.0;
+    const double g = (double)gamma[o], b = (double)beta[o];
+    for (int j = 0; j < c1; ++j) {
+        const double w = (double)W1[j * cin + o];
+        sb += w * (double)db1[j];
+        sg += w * ((double)dW1[j * cin + o] - b * (double)db1[j]);
+    }
+    dbeta[o] += (float)sb;
+    dgamma[o] += (float)(sg / g);
+}
+
 int check_head(const sn2_head* p) {
     if (!p || p->R <= 0 || p->cin != 34 || p->f_stride != 36) return p && p->R > 0 ? SN2_ELIMIT : SN2_EINVAL;
     if (!p->f || !p->fa || !p->fc || !p->W1 || !p->b1 || !p->W2 || !p->b2) return SN2_EINVAL;
@@ -960,6 +984,15 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     if (!p->coverages || !p->proba) return SN2_EINVAL;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f_stride,
                        p->f, p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                void* stream) {
+    SN2_TRY(check_head(p));
+    if (!p->dW1 || !p->db1 || !gamma || !beta || !dgamma || !dbeta) return SN2_EINVAL;
+    hipLaunchKernelGGL(head_bn_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->cin, 16, p->W1, (const float*)p->dW1,
+                       (const float*)p->db1, gamma, beta, dgamma, dbeta);
     SN2_RETURN_LAUNCH();
 }
 

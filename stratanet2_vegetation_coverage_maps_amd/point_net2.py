@@ -413,12 +413,15 @@ class PointNet2(nn.Module):
         # head
         dy1 = torch.empty(B * N, 36, dtype=F32, device=dev)
         hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
-        ops.head_backward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1,
-                                        grads=hg))
+        hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg)
+        ops.head_backward(hd)
+        # FP1's BatchNorm gradients fall out of lin1's (hip_ops.head_bn_sums): no extra pass over the B*N rows
+        bn1 = self.fp1_module.nn[0][2]
+        ops.head_bn_sums(hd, bn1.weight.detach(), bn1.bias.detach(), views[id(bn1.weight)], views[id(bn1.bias)])
         # FP1 -> d(fp2 output)
         dy2 = buf["dy2"].view(B * M1, 36)
         ops.fp_backward(self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 34, dtype=F32, device=dev),
-                                       with_grads=True, interp_index=s.inv1))
+                                       with_grads=True, interp_index=s.inv1, bn_sums_ready=True))
         # FP2 -> d(fp3 output), d x1
         dy3, dx1 = buf["dy3"].view(B * M2, 64), buf["dx1"].view(B * M1, 16)
         ops.fp_backward(self._fp2_desc(s, dy=dy2, dsrc=dy3, dskip=dx1,
