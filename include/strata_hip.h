@@ -192,6 +192,9 @@ int sn2_head_backward(const sn2_head *p, void *stream);
  * and bias gradients instead of a pass over all rows (derivation in fp.hip).  gamma, beta: that BatchNorm's parameters
  * (gamma must be non-zero); dgamma, dbeta: ACCUMULATED. */
 int sn2_head_bn_sums(const sn2_head *p, const float *gamma, const float *beta, float *dgamma, float *dbeta, void *stream);
+/* The same for the BatchNorm whose output an FP block interpolates (its columns 0..ca-1), after that block's
+ * sn2_fp_backward: the interpolation weights of a row sum to 1, so the identity carries over. */
+int sn2_fp_bn_sums(const sn2_fp *p, const float *gamma, const float *beta, float *dgamma, float *dbeta, void *stream);
 
 /* ---- 2D projections -- model/project_to_2d.py -------------------------------------------------------------- */
 

@@ -949,23 +949,27 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
     }
 }
 
-// dgamma / dbeta of the BatchNorm that feeds lin1, from lin1's own gradients.  With y = gamma*xhat + beta the input of lin1
-// and dy = W1^T dpre its gradient:
-//   dbeta[o]  = sum_r dy[r][o]            = sum_j W1[j][o] * db1[j]
-//   dgamma[o] = sum_r dy[r][o]*xhat[r][o] = sum_j W1[j][o] * G[j][o],   G[j][o] = sum_r dpre[r][j]*xhat[r][o]
-// and dW1[j][o] = sum_r dpre[r][j]*y[r][o] = gamma[o]*G[j][o] + beta[o]*db1[j], so G = (dW1 - beta*db1) / gamma.
-// 2 x 34 dot products of length 16 instead of a pass over all rows (0.03 ms and 150 MB at C2).  Needs gamma != 0.
-__global__ void head_bn_sums_kernel(int cin, int c1, const float* __restrict__ W1, const float* __restrict__ dW1,
-                                    const float* __restrict__ db1, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// dgamma / dbeta of a BatchNorm from the gradients of the Linear layer that consumes its output.  Let y = gamma*xhat +
+// beta be the BatchNorm's output rows and let the consumer see u[r] = sum_k w_rk * y[idx_rk] with sum_k w_rk = 1 (the head:
+// u = y; an FP block: the inverse-distance interpolation of knn_interpolate) in columns col0.. of its input.  With
+// dy = (transposed interpolation of) W^T dpre:
+//   dbeta[o]  = sum_rows dy[.][o]          = sum_j W[j][col0+o] * db[j]
+//   dgamma[o] = sum_rows dy[.][o]*xhat[.][o] = sum_j W[j][col0+o] * G[j][o],  G[j][o] = sum_r dpre[r][j] * sum_k w_rk xhat[idx_rk][o]
+// and dW[j][col0+o] = sum_r dpre[r][j]*u[r][o] = gamma[o]*G[j][o] + beta[o]*db[j], so G = (dW - beta*db) / gamma.
+// C dot products of length cout instead of a pass over all rows (FP1's BatchNorm: 0.03 ms and 150 MB at C2).  Needs
+// gamma != 0; accumulated in fp64.
+__global__ void bn_sums_from_consumer_kernel(int C, int cout, int cin, int col0, const float* __restrict__ W,
+                                             const float* __restrict__ dW, const float* __restrict__ db,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int o = threadIdx.x;
-    if (o >= cin) return;
+    if (o >= C) return;
     double sb = 0.0, sg = 0.0;
     const double g = (double)gamma[o], b = (double)beta[o];
-    for (int j = 0; j < c1; ++j) {
-        const double w = (double)W1[j * cin + o];
-        sb += w * (double)db1[j];
-        sg += w * ((double)dW1[j * cin + o] - b * (double)db1[j]);
+    for (int j = 0; j < cout; ++j) {
+        const double w = (double)W[j * cin + col0 + o];
+        sb += w * (double)db[j];
+        sg += w * ((double)dW[j * cin + col0 + o] - b * (double)db[j]);
     }
     dbeta[o] += (float)sb;
     dgamma[o] += (float)(sg / g);
@@ -991,8 +995,17 @@ extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const flo
                                 void* stream) {
     SN2_TRY(check_head(p));
     if (!p->dW1 || !p->db1 || !gamma || !beta || !dgamma || !dbeta) return SN2_EINVAL;
-    hipLaunchKernelGGL(head_bn_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->cin, 16, p->W1, (const float*)p->dW1,
-                       (const float*)p->db1, gamma, beta, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->cin, 16, p->cin, 0, p->W1,
+                       (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                              void* stream) {
+    SN2_TRY(check_fp(p));
+    if (!p->knn_idx || !p->blk.dW || !p->blk.db || !gamma || !beta || !dgamma || !dbeta || p->ca > 64) return SN2_EINVAL;
+    hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->ca, p->blk.cout, p->blk.cin, 0,
+                       (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta);
     SN2_RETURN_LAUNCH();
 }
 

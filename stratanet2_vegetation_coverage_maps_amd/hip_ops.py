@@ -447,6 +447,14 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     return d
 
 
+def fp_bn_sums(d: FP, gamma, beta, dgamma, dbeta):
+    """After fp_backward(d): dgamma/dbeta (ACCUMULATED) of the BatchNorm whose output block d interpolates, from d's own
+    weight and bias gradients (include/strata_hip.h: sn2_fp_bn_sums)."""
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk(t, F32, (d.ca,), n)
+    _call("sn2_fp_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _stream())
+
+
 def fp_forward(d: FP, training: bool):
     _call("sn2_fp_forward", d, int(training), _stream(), tag=f"{d.ca}+{d.cb}->{d.blk.cout}")
 
