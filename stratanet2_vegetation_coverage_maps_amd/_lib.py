@@ -33,7 +33,7 @@ class FP(Structure):  # sn2_fp
                 ("knn_idx", c_void_p), ("knn_w", c_void_p), ("skip", c_void_p), ("skip_stride", c_int),
                 ("blk", Block), ("h", c_void_p), ("h_stride", c_int), ("dy", c_void_p), ("dsrc", c_void_p),
                 ("dsrc_stride", c_int), ("dskip", c_void_p), ("dskip_stride", c_int), ("du_scratch", c_void_p),
-                ("scatter_ws", c_void_p), ("scatter_ready", c_int), ("bn_sums_ready", c_int)]
+                ("scatter_ws", c_void_p), ("scatter_ready", c_int), ("bn_sums_done", c_void_p)]
 
 
 class Head(Structure):  # sn2_head
@@ -64,8 +64,8 @@ SIGNATURES = {
     "sn2_plot_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "sn2_plot_max_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_head_forward": [POINTER(Head), c_void_p],
-    "sn2_fp_bn_sums": [POINTER(FP), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
-    "sn2_head_bn_sums": [POINTER(Head), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sn2_fp_bn_sums": [POINTER(FP), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sn2_head_bn_sums": [POINTER(Head), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_head_backward": [POINTER(Head), c_void_p],
     "sn2_plot_project_forward": [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p],

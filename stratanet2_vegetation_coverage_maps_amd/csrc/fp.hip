@@ -119,7 +119,8 @@ template <int CO>
 __global__ __launch_bounds__(256) void fp_bwd_bn_kernel(int R, int h_stride, const float* __restrict__ h,
                                                         const float* __restrict__ dy, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta) {
+                                                        float* __restrict__ dbeta, const int* __restrict__ done) {
+    if (done && *done == 1) return;                   // the sums already came from the consumer's gradients
     float sb[CO], sg[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) sb[o] = sg[o] = 0.f;
@@ -158,8 +159,9 @@ template <int CO>
 __global__ __launch_bounds__(256) void fp_bwd_bn_small_kernel(int R, int h_stride, const float* __restrict__ h,
                                                               const float* __restrict__ dy, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
+                                                              float* __restrict__ dbeta, const int* __restrict__ done) {
     static_assert(CO <= 64, "one lane per channel");
+    if (done && *done == 1) return;
     __shared__ float s_part[2][4][64];
     const int o = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool on = o < CO;
@@ -671,16 +673,16 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     // waves per workgroup (one workgroup per CU): as many as the staging regions and 256 VGPRs per lane allow
     constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 8 <= 150 * 1024) ? 8 : ((Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : 2);
     const int R = p->B * p->R_per_plot;
-    if (p->bn_sums_ready) {
-        // dgamma / dbeta of this block's BatchNorm were produced by the consumer (sn2_head_bn_sums): no pass over the rows
-    } else if (R <= (1 << 16)) {
+    // bn_sums_done (device int or NULL): 1 = dgamma / dbeta of this block's BatchNorm already came from the consumer's
+    // gradients (sn2_head_bn_sums / sn2_fp_bn_sums) and the pass over the rows returns at once
+    if (R <= (1 << 16)) {
         hipLaunchKernelGGL((fp_bwd_bn_small_kernel<CO>), dim3(sn2_cdiv(R, 64)), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
-                           p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta);
+                           p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta, p->bn_sums_done);
     } else {
         int g1 = pick_grid(R, 256, R >= (1 << 18) ? 8 : 1);
         if (g1 > 256) g1 = 256;
         hipLaunchKernelGGL((fp_bwd_bn_kernel<CO>), dim3(g1), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
-                           p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta);
+                           p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta, p->bn_sums_done);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -957,13 +959,21 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
 //   dgamma[o] = sum_rows dy[.][o]*xhat[.][o] = sum_j W[j][col0+o] * G[j][o],  G[j][o] = sum_r dpre[r][j] * sum_k w_rk xhat[idx_rk][o]
 // and dW[j][col0+o] = sum_r dpre[r][j]*u[r][o] = gamma[o]*G[j][o] + beta[o]*db[j], so G = (dW - beta*db) / gamma.
 // C dot products of length cout instead of a pass over all rows (FP1's BatchNorm: 0.03 ms and 150 MB at C2).  Needs
-// gamma != 0; accumulated in fp64.
+// |gamma| > 1e-4 on every channel (else the caller's ordinary pass runs: see `ok`); accumulated in fp64.
+// ok (device int): set to 1 when every |gamma| is large enough for the division and the sums were added, to 0 otherwise --
+// sn2_fp_backward then runs its ordinary pass over the rows (its BN kernels return at once when *ok == 1).
 __global__ void bn_sums_from_consumer_kernel(int C, int cout, int cin, int col0, const float* __restrict__ W,
                                              const float* __restrict__ dW, const float* __restrict__ db,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok) {
+    __shared__ int s_ok;
     const int o = threadIdx.x;
-    if (o >= C) return;
+    if (o == 0) s_ok = 1;
+    __syncthreads();
+    if (o < C && !(fabsf(gamma[o]) > 1e-4f)) s_ok = 0;          // also catches NaN
+    __syncthreads();
+    if (o == 0) *ok = s_ok;
+    if (o >= C || !s_ok) return;
     double sb = 0.0, sg = 0.0;
     const double g = (double)gamma[o], b = (double)beta[o];
     for (int j = 0; j < cout; ++j) {
@@ -992,20 +1002,20 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
 }
 
 extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                                void* stream) {
+                                int* ok, void* stream) {
     SN2_TRY(check_head(p));
-    if (!p->dW1 || !p->db1 || !gamma || !beta || !dgamma || !dbeta) return SN2_EINVAL;
+    if (!p->dW1 || !p->db1 || !gamma || !beta || !dgamma || !dbeta || !ok) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->cin, 16, p->cin, 0, p->W1,
-                       (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta);
+                       (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta, ok);
     SN2_RETURN_LAUNCH();
 }
 
 extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                              void* stream) {
+                              int* ok, void* stream) {
     SN2_TRY(check_fp(p));
-    if (!p->knn_idx || !p->blk.dW || !p->blk.db || !gamma || !beta || !dgamma || !dbeta || p->ca > 64) return SN2_EINVAL;
+    if (!p->knn_idx || !p->blk.dW || !p->blk.db || !gamma || !beta || !dgamma || !dbeta || !ok || p->ca > 64) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->ca, p->blk.cout, p->blk.cin, 0,
-                       (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta);
+                       (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta, ok);
     SN2_RETURN_LAUNCH();
 }
 

@@ -392,7 +392,7 @@ def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[to
 
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
             dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False, interp_index=None,
-            bn_sums_ready=False) -> FP:
+            bn_sums_done=None) -> FP:
     """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view."""
     R = B * R_per_plot
     hs = (block.cout + 3) // 4 * 4
@@ -431,7 +431,9 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     if dskip is not None:
         d.dskip_stride = _chk_rows(dskip, F32, R, cb, "dskip", align=1)
     d.scatter_ws, d.scatter_ready = None, 0
-    d.bn_sums_ready = int(bool(bn_sums_ready))
+    if bn_sums_done is not None:
+        _chk(bn_sums_done, I32, (1,), "bn_sums_done")
+    d.bn_sums_done = _ptr(bn_sums_done)
     if du_scratch is not None:
         _chk(du_scratch, F32, (R, ca), "du_scratch")
         if knn is not None and dsrc is not None:
@@ -447,12 +449,13 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     return d
 
 
-def fp_bn_sums(d: FP, gamma, beta, dgamma, dbeta):
+def fp_bn_sums(d: FP, gamma, beta, dgamma, dbeta, ok):
     """After fp_backward(d): dgamma/dbeta (ACCUMULATED) of the BatchNorm whose output block d interpolates, from d's own
     weight and bias gradients (include/strata_hip.h: sn2_fp_bn_sums)."""
     for t, n in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk(t, F32, (d.ca,), n)
-    _call("sn2_fp_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _stream())
+    _chk(ok, I32, (1,), "ok")
+    _call("sn2_fp_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(ok), _stream())
 
 
 def fp_forward(d: FP, training: bool):
@@ -519,11 +522,12 @@ def head_backward(d: Head):
     _call("sn2_head_backward", d, _stream())
 
 
-def head_bn_sums(d: Head, gamma, beta, dgamma, dbeta):
+def head_bn_sums(d: Head, gamma, beta, dgamma, dbeta, ok):
     """After head_backward: dgamma/dbeta (ACCUMULATED) of the BatchNorm feeding lin1, from lin1's gradients."""
     for t, n in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk(t, F32, (d.cin,), n)
-    _call("sn2_head_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _stream())
+    _chk(ok, I32, (1,), "ok")
+    _call("sn2_head_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(ok), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- projections

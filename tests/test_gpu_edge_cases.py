@@ -132,3 +132,31 @@ def test_eval_after_training_uses_running_statistics():
     np.testing.assert_allclose(cov_e.cpu().numpy(), cov_r.detach().numpy(), atol=TOL, rtol=0)
     np.testing.assert_allclose(proba_e.cpu().numpy(), proba_r.detach().numpy(), atol=TOL, rtol=0)
     assert not torch.allclose(cov_e, got[0].detach(), atol=1e-3)       # and it differs from the train-mode output
+
+
+def test_zero_batchnorm_scale_takes_the_row_pass():
+    """The BatchNorm gradients of FP1/FP2/FP3 normally come from the consuming layer's dW/db, which divides by gamma; a
+    (near-)zero gamma must fall back to the ordinary pass over the rows and still give the reference's gradients."""
+    N = 2048
+    args = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(2, N, first_plot=60)
+    fs = torch.tensor([[0, 1], [2, 3]])
+    sd = network.init_state_dict(6)
+    for name, ch, val in (("fp1_module.nn.0.2.weight", 3, 0.0), ("fp2_module.nn.0.2.weight", 7, 1e-7),
+                          ("fp3_module.nn.0.2.weight", 11, 0.0)):
+        sd[name][ch] = val
+    d = dict(d)
+    d["fps_start"] = fs
+    m = _model(args, sd).train()
+    cov, proba = m(d)
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+    loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
+    loss.backward()
+    sd_r = {k: v.clone() for k, v in sd.items()}
+    for k in network.param_keys(sd_r):
+        sd_r[k].requires_grad_(True)
+    cov_r, proba_r, _ = network.forward(sd_r, d["cloud"], d["xyz"], args, training=True, fps_start=(fs[0], fs[1]))
+    pred_r = projection.project_to_plotwise_coverages(cov_r, d["cloud"], args)
+    loss_r, _ = olosses.total_loss(pred_r, proba_r, d["coverages"], d["pdf_all"], args.m, args.e)
+    loss_r.backward()
+    _check(m, (cov, proba, pred, loss), sd_r, (cov_r, proba_r, pred_r, loss_r), grad_tol=2e-3)
