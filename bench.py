@@ -102,6 +102,21 @@ def pmc_traffic(entry):
     return (d[k]["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])) if k in d else (None, None)
 
 
+def rocprof_kernel_avg_ms(entry):
+    """Average duration of the entry point's dominant device kernel in the committed rocprofv3 --kernel-trace --stats summary
+    (profiles/*_kernel_stats.csv), for comparison with the live HIP-event time of the whole entry point."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")))
+    k = DOMINANT_KERNEL.get(entry)
+    if not files or k is None:
+        return None
+    for r in csv.DictReader(open(files[-1])):
+        if k in r["Name"]:
+            return round(float(r["AverageNs"]) * 1e-6, 4)
+    return None
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the reference path, kd-tree neighbour search, all host cores) on a bounded
     sample of the same workload: 2 plots of 32 768 points, 1 warm-up + 2 timed steps."""
@@ -360,6 +375,7 @@ def main():
                     "achieved": None if ach is None else round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "traffic_source": tsrc, "avg_ms": round(avg_ms, 4), "algorithmic_bytes": by,
+                    "dominant_device_kernel_avg_ms_rocprof": rocprof_kernel_avg_ms(entry),
                     "timing": ("HIP events inside the timed region" if mode == "serial/eager" else
                                "HIP events over 5 unpipelined eager steps right after the timed region"), "note": note}
         roof = roofline_of(dominant, "longest entry point of the feature pass, the stream that bounds the pipelined step "
