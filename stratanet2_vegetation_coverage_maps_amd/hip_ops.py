@@ -123,6 +123,13 @@ def fps_ws_words(B: int, N: int) -> int:
     return 5 * B * N + 4104 * B
 
 
+def fps_fills_ws(B: int, N: int, m: int) -> bool:
+    """Whether sn2_fps takes its bucketed path for these sizes, i.e. FILLS the workspace (Morton order, sorted table, cell
+    starts) that ball_query / three_nn may then walk.  Must mirror the condition in csrc/geometry.hip (sn2_fps): handing
+    those kernels a workspace nobody filled would send them through garbage cell lists."""
+    return N > 2048 and m > 16 and (B * N) % 4 == 0 and N <= 131072
+
+
 def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True,
         return_ws: bool = False, out=None):
     """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
@@ -136,6 +143,7 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
     if start is not None:
         _chk(start, I32, (B,), "start")
     dev = pos_soa.device
+    use_ws = bucketed and fps_fills_ws(B, N, m)
     if out is not None:
         idx, cs, ca, order = out
         _chk(idx, I32, (B, m), "out idx")
@@ -143,11 +151,13 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
         _chk(ca, F32, (B * m, 4), "out cpos_aos")
         if order is not None:
             _chk(order, I32, (fps_ws_words(B, N),), "out workspace")
+        if not use_ws:
+            order = None                      # the kernel would not fill it: nobody may read it
     else:
         idx = torch.empty(B, m, dtype=I32, device=dev)
         cs = torch.empty(B, 3, m, dtype=F32, device=dev)
         ca = torch.empty(B * m, 4, dtype=F32, device=dev)
-        order = torch.empty(fps_ws_words(B, N), dtype=I32, device=dev) if (bucketed and N > 2048) else None
+        order = torch.empty(fps_ws_words(B, N), dtype=I32, device=dev) if use_ws else None
     _call("sn2_fps", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), _stream(),
           tag=f"N={N}")
     if return_ws:

@@ -194,10 +194,10 @@ class PointNet2(nn.Module):
         g = _Saved()
         g.B, g.N, g.M1, g.M2 = B, N, M1, M2
         g.idx1, g.pos1_soa, g.pos1_aos = e(B, M1, dt=I32), e(B, 3, M1), e(B * M1, 4)
-        g.ws1 = e(ops.fps_ws_words(B, N), dt=I32) if N > 2048 else None
+        g.ws1 = e(ops.fps_ws_words(B, N), dt=I32) if ops.fps_fills_ws(B, N, M1) else None
         g.nbr1, g.cnt1 = e(B * M1, min(MAX_NEIGHBORS, N), dt=I32), e(B * M1, dt=I32)
         g.idx2, g.pos2_soa, g.pos2_aos = e(B, M2, dt=I32), e(B, 3, M2), e(B * M2, 4)
-        g.ws2 = e(ops.fps_ws_words(B, M1), dt=I32) if M1 > 2048 else None
+        g.ws2 = e(ops.fps_ws_words(B, M1), dt=I32) if ops.fps_fills_ws(B, M1, M2) else None
         g.nbr2, g.cnt2 = e(B * M2, min(MAX_NEIGHBORS, M1), dt=I32), e(B * M2, dt=I32)
         g.totals = torch.zeros(2, dtype=I64, device=dev)
         g.pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)

@@ -199,3 +199,17 @@ def test_znorm_matches_reference_rule(n, r, seed):
     zmin, zout = ops.znorm(torch.from_numpy(cloud[:3].copy()).to(DEV), r)
     assert np.array_equal(zmin.cpu().numpy(), zmin_ref)
     assert np.array_equal(zout.cpu().numpy(), want)
+
+
+def test_fps_workspace_is_only_handed_out_when_filled():
+    """sn2_fps fills its workspace on the bucketed path only (N > 2048, M > 16, B*N % 4 == 0): for other sizes the wrapper
+    must return None, or the cell-list walks of ball_query / three_nn would read garbage."""
+    for B, N, M, expect in ((1, 4096, 8, False), (1, 4099, 64, False), (2, 4098, 64, True), (1, 2048, 64, False)):
+        xyz, _ = _pos(B, N, first=3)
+        idx, cs, ca, ws = ops.fps(xyz.to(DEV), M, None, return_ws=True)
+        assert (ws is not None) == expect and ops.fps_fills_ws(B, N, M) == expect
+        nbr, cnt, _ = ops.ball_query(xyz.to(DEV), cs, 1.5, 200, fps_ws=ws)
+        nbr_f, cnt_f, _ = ops.ball_query(xyz.to(DEV), cs, 1.5, 200)
+        assert torch.equal(cnt, cnt_f)
+        ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, torch.zeros(B, dtype=torch.long))
+        assert torch.equal(idx.cpu().long(), ref)
