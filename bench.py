@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per plot (default = the metric's 32768; other "
                     "values are extra measurements, e.g. 131072 with --plots 8 for BASELINE config 5's plot size)")
     ap.add_argument("--plots", type=int, default=PLOTS_PER_GPU, help="plots per GPU (default = the metric's 16)")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="extra measurement, NOT the metric's `value` convention: every step's batch starts in pinned host "
+                         "memory and is copied (27 MB) on the side streams in front of its geometry pass")
     ap.add_argument("--split-exchange", action="store_true",
                     help="one GPU: use the multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
     a = ap.parse_args()
@@ -292,10 +295,13 @@ def main():
             pipe = TrainPipeline(model, opt, feature_step, slots, depth=a.depth, use_graph=False)
             pipe.capture()
             launch = "eager"
+        if a.host_inputs:
+            pinned = [{k: v.cpu().pin_memory() for k, v in sl.items() if k in ("cloud", "xyz", "gt", "pdf")} for sl in slots]
+            pipe.set_feeder(lambda i: pinned[i % len(pinned)])
         pipe.prime()
         for _ in range(a.warmup):
             pipe.step()
-        mode = f"pipelined depth {a.depth}/{launch}"
+        mode = f"pipelined depth {a.depth}/{launch}" + (" + H2D of every batch from pinned host memory" if a.host_inputs else "")
     log(f"mode: {mode}")
 
     barrier()

@@ -49,6 +49,7 @@ class TrainPipeline:
         self.issued = 0                           # geometry passes launched so far
         self.done = 0                             # feature passes launched so far
         self.use_graph = use_graph
+        self.feeder = None                        # optional: feeder(i) -> dict of HOST tensors for batch number i
         # exchange between the backward graph and the Adam graph (always when world > 1; can be forced on one GPU to
         # exercise exactly the launch sequence the multi-GPU run uses)
         self.split_exchange = (getattr(opt, "world_size", 1) > 1) if split_exchange is None else bool(split_exchange)
@@ -64,6 +65,11 @@ class TrainPipeline:
             st.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(st):
             d = self.inputs[k]
+            if self.feeder is not None:
+                # the next batch arrives from the host (pinned buffers): its copy into the slot rides on the side stream,
+                # in front of the geometry pass that reads it and behind the feature pass that last read the slot
+                for name, t in self.feeder(i).items():
+                    d[name].copy_(t, non_blocking=True)
             self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k])
             self.geo_ready[k].record(st)
         self.issued = max(self.issued, i + 1)
@@ -142,6 +148,12 @@ class TrainPipeline:
         while self.issued < self.done + self.depth:
             self.issue_geometry(self.issued)
         return loss
+
+    def set_feeder(self, feeder):
+        """feeder(i) -> {"cloud": ..., "xyz": ..., ...} HOST tensors (ideally pinned) for batch number i, same shapes and dtypes
+        as the slot tensors of those names; they are copied into slot i % slots on the side stream before that batch's
+        geometry pass.  None = the slots already hold the data (the resident-input mode of bench.py)."""
+        self.feeder = feeder
 
     def drain(self):
         for st in self.side:

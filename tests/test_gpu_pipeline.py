@@ -70,3 +70,35 @@ def test_pipeline_matches_plain_loop(use_graph, split):
     np.testing.assert_allclose(got, ref_losses, rtol=0, atol=1e-6)
     np.testing.assert_allclose(model2._flat_params.cpu().numpy(), ref_params.cpu().numpy(), rtol=0, atol=1e-4)
     np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(), ref_rm.cpu().numpy(), atol=1e-6)
+
+
+def test_pipeline_with_host_feeder_matches_resident_inputs():
+    """Batches fed from (pinned) host memory on the side streams give the same losses as the same batches resident in the
+    slots; the slot tensors start out zeroed, so a copy that came too late or not at all would show."""
+    N, B, depth, steps = 4096, 2, 2, 6
+    model, opt, slots, fstep = _setup(N, B, depth)
+    pipe = TrainPipeline(model, opt, fstep, slots, depth=depth, use_graph=True)
+    pipe.capture()
+    model.load_state_dict(network.init_state_dict(5))
+    opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_dev.zero_()
+    pipe.prime()
+    ref = [float(pipe.step().detach()) for _ in range(steps)]
+    pipe.drain()
+    torch.cuda.synchronize()
+
+    model2, opt2, slots2, fstep2 = _setup(N, B, depth)
+    host = [{k: v.cpu().pin_memory() for k, v in sl.items() if k in ("cloud", "xyz", "gt", "pdf")} for sl in slots2]
+    pipe2 = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=True)
+    pipe2.capture()
+    for sl in slots2:                                   # wipe the resident copies: the feeder must bring the data
+        for k in ("cloud", "xyz", "gt", "pdf"):
+            sl[k].zero_()
+    model2.load_state_dict(network.init_state_dict(5))
+    opt2.exp_avg.zero_(); opt2.exp_avg_sq.zero_(); opt2.step_dev.zero_()
+    pipe2.issued = pipe2.done = 0
+    pipe2.set_feeder(lambda i: host[i % len(host)])
+    pipe2.prime()
+    got = [float(pipe2.step().detach()) for _ in range(steps)]
+    pipe2.drain()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
