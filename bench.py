@@ -167,6 +167,10 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per plot (default = the metric's 32768; other "
                     "values are extra measurements, e.g. 131072 with --plots 8 for BASELINE config 5's plot size)")
     ap.add_argument("--plots", type=int, default=PLOTS_PER_GPU, help="plots per GPU (default = the metric's 16)")
+    ap.add_argument("--arch", choices=("ref", "3sa"), default="ref",
+                    help="ref = the reference architecture (two ball-query levels + global; parity-checked: the metric); "
+                         "3sa = the variant BASELINE config 2 names, three ball-query levels 1024/256/64 with r 1/2/4 m + "
+                         "global (not in the reference: throughput only)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="extra measurement, NOT the metric's `value` convention: every step's batch starts in pinned host "
                          "memory and is copied (27 MB) on the side streams in front of its geometry pass")
@@ -196,7 +200,13 @@ def main():
     B, N_POINTS = a.plots, a.points
     args = workload_args(local_rank)
     torch.manual_seed(0)                       # identical initial weights on every rank
-    model = PointNet2(args).train()
+    if a.arch == "3sa":
+        from stratanet2_vegetation_coverage_maps_amd.point_net2_3sa import PointNet2ThreeSA
+        args.ratio3, args.r3 = 0.25, 4.0
+        model = PointNet2ThreeSA(args).train()
+    else:
+        model = PointNet2(args).train()
+    n_fps = 3 if a.arch == "3sa" else 2
     flatten_parameters(model)
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
     # depth+1 resident batches (the pipeline's slots); batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
@@ -205,7 +215,7 @@ def main():
     for j in range(n_slots):
         host = make_batch(B, N_POINTS, first_plot=j * world * B + shard_of_rank(rank, B)[0])
         slots.append({"cloud": host["cloud"].to(dev), "xyz": host["xyz"].to(dev),
-                      "fps_start": torch.zeros(2, B, dtype=torch.int32, device=dev),
+                      "fps_start": torch.zeros(n_fps, B, dtype=torch.int32, device=dev),
                       "gt": host["coverages"].to(dev), "pdf": host["pdf_all"].to(dev)})
     data = slots[0]
 
@@ -396,8 +406,10 @@ def main():
         out = {"metric": "plots/s fwd+bwd, 32k-pt synthetic plots, batch 16/GPU", "value": round(world * B / (ms * 1e-3), 2),
                "unit": "plots/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": ("C2 ref-arch" if (B, N_POINTS) == (16, 32768) else "ref-arch, NOT the metric's size") +
-                                      f": {B} plots/GPU x {N_POINTS} pts, SA npoint 1024/256 + global, r 1/2 m, "
+               "config": {"workload": (("C2 " if (B, N_POINTS) == (16, 32768) else "NOT the metric's size, ") +
+                                       ("ref-arch" if a.arch == "ref" else "3sa-arch (not in the reference: throughput only)")) +
+                                      f": {B} plots/GPU x {N_POINTS} pts, SA npoint " +
+                                      ("1024/256 + global, r 1/2 m, " if a.arch == "ref" else "1024/256/64 + global, r 1/2/4 m, ") +
                                       "train step fwd+P2+loss+bwd+Adam, inputs resident in HBM",
                           "mode": mode + ("" if a.serial else
                                           ": every step runs one geometry pass (FPS, ball query, 3-NN of a later batch, side "

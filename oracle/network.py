@@ -143,3 +143,72 @@ def forward(sd: Dict[str, torch.Tensor], cloud: torch.Tensor, xyz: torch.Tensor,
     if details:
         ex.update(pos1=pos1, pos2=pos2, x1=x1, x2=x2, x3=x3, f3=f3, f2=f2, f1=f1, scores=scores)
     return coverages, proba, ex
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The "3sa-arch" variant (NOT in the reference: BASELINE.json's configuration 2 names three ball-query levels; SURVEY.md 8d
+# asks for it next to the reference architecture).  Same primitives, one more SAModule before the global one and one more
+# FPModule; the checker of stratanet2_vegetation_coverage_maps_amd/point_net2_3sa.py.
+# ---------------------------------------------------------------------------------------------------------------------
+LAYERS_3SA = OrderedDict([
+    ("sa1_module.conv.local_nn", [11, 16, 16]),
+    ("sa2_module.conv.local_nn", [19, 32]),
+    ("sa3_module.conv.local_nn", [35, 64]),
+    ("sa4_module.nn", [67, 64]),
+    ("fp4_module.nn", [128, 64]),
+    ("fp3_module.nn", [96, 64]),
+    ("fp2_module.nn", [80, 34]),
+    ("fp1_module.nn", [42, 34]),
+])
+
+
+def init_state_dict_3sa(seed: int = 0):
+    torch.manual_seed(seed)
+    sd = OrderedDict()
+    for prefix, ch in LAYERS_3SA.items():
+        for i in range(1, len(ch)):
+            lin, bn = torch.nn.Linear(ch[i - 1], ch[i]), torch.nn.BatchNorm1d(ch[i])
+            for k, v in lin.state_dict().items():
+                sd[f"{prefix}.{i - 1}.0.{k}"] = v.detach().clone()
+            for k, v in bn.state_dict().items():
+                sd[f"{prefix}.{i - 1}.2.{k}"] = v.detach().clone()
+    lin1, lin2 = torch.nn.Linear(34, 16), torch.nn.Linear(16, 5)
+    sd["lin1.weight"], sd["lin1.bias"] = lin1.weight.detach().clone(), lin1.bias.detach().clone()
+    sd["lin2.weight"] = lin2.weight.detach().clone()
+    sd["lin2.bias"] = torch.tensor(LIN2_BIAS)
+    return sd
+
+
+def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False):
+    B, _, N = cloud.shape
+    pos0 = xyz.permute(0, 2, 1).reshape(B * N, 3).contiguous()
+    x0 = cloud.permute(0, 2, 1).reshape(B * N, -1)[:, 2:].contiguous()
+    batch0 = torch.arange(B).repeat_interleave(N)
+    starts = [torch.zeros(B, dtype=torch.long) if fps_start is None else fps_start[i].long() for i in range(3)]
+    new_stats = {} if training else None
+    levels = [(pos0, batch0, x0, N)]
+    for lvl, (ratio, r, prefix, nb) in enumerate(((args.ratio1, args.r1, "sa1_module.conv.local_nn", 2),
+                                                  (args.ratio2, args.r2, "sa2_module.conv.local_nn", 1),
+                                                  (args.ratio3, args.r3, "sa3_module.conv.local_nn", 1))):
+        ps, bs, xs, n = levels[-1]
+        idx, M = _fps_regular(ps, B, n, ratio, starts[lvl])
+        pc, bc = ps[idx], bs[idx]
+        row, col = P.radius(ps, pc, r, bs, bc, max_num_neighbors=MAX_NUM_NEIGHBORS, use_kdtree=use_kdtree)
+        msg = _mlp(torch.cat([xs[col], ps[col] - pc[row]], dim=1), sd, prefix, nb, training, new_stats)
+        levels.append((pc, bc, P.scatter_max(msg, row, dim=0, dim_size=pc.shape[0])[0], M))
+    (pos1, batch1, x1, _), (pos2, batch2, x2, _), (pos3, batch3, x3, _) = levels[1:]
+    h = _mlp(torch.cat([x3, pos3], dim=1), sd, "sa4_module.nn", 1, training, new_stats)
+    xg = P.global_max_pool(h, batch3)
+    posg, batchg = pos3.new_zeros((B, 3)), torch.arange(B)
+    f = P.knn_interpolate(xg, posg, pos3, batchg, batch3, k=1)
+    f4 = _mlp(torch.cat([f, x3], dim=1), sd, "fp4_module.nn", 1, training, new_stats)
+    f = P.knn_interpolate(f4, pos3, pos2, batch3, batch2, k=3, use_kdtree=use_kdtree)
+    f3 = _mlp(torch.cat([f, x2], dim=1), sd, "fp3_module.nn", 1, training, new_stats)
+    f = P.knn_interpolate(f3, pos2, pos1, batch2, batch1, k=3, use_kdtree=use_kdtree)
+    f2 = _mlp(torch.cat([f, x1], dim=1), sd, "fp2_module.nn", 1, training, new_stats)
+    f = P.knn_interpolate(f2, pos1, pos0, batch1, batch0, k=3, use_kdtree=use_kdtree)
+    f1 = _mlp(torch.cat([f, x0], dim=1), sd, "fp1_module.nn", 1, training, new_stats)
+    h = F.relu(F.linear(f1, sd["lin1.weight"], sd["lin1.bias"]))
+    scores = F.linear(h, sd["lin2.weight"], sd["lin2.bias"])
+    proba = torch.softmax(scores[:, :4], dim=1)
+    return proba * torch.sigmoid(scores[:, 4:5]), proba, {"new_stats": new_stats}

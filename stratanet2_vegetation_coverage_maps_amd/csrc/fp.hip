@@ -689,10 +689,11 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     float* du_out0 = KNN ? p->du_scratch : p->dsrc;
     if (KNN && p->dsrc && !p->du_scratch) return SN2_EINVAL;
     if (KNN && !p->dsrc) du_out0 = nullptr;
-    const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS;
+    using AccS = OuterAcc<16, CI + 1>;
+    constexpr size_t lb = (size_t)(64 * AccS::QS + 4 * 64 * 16 + 4 * 64 * (CI | 1)) * 4;
+    // the 64-row x 4-channel-group kernel when the layer is small and its staging fits LDS (CI = 128 does not)
+    const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS && lb <= 150 * 1024;
     if (small) {
-        using AccS = OuterAcc<16, CI + 1>;
-        constexpr size_t lb = (size_t)(64 * AccS::QS + 4 * 64 * 16 + 4 * 64 * (CI | 1)) * 4;
         auto ks = &fp_bwd_split_kernel<CA, CB, CO, KNN>;
         if (lb > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
@@ -762,6 +763,9 @@ int check_fp(const sn2_fp* p) {
         if (knn && p->ca == 64 && p->cb == 32 && p->blk.cout == 64) return FN<64, 32, 64, true>(__VA_ARGS__);     \
         if (knn && p->ca == 64 && p->cb == 16 && p->blk.cout == 34) return FN<64, 16, 34, true>(__VA_ARGS__);     \
         if (knn && p->ca == 34 && p->cb == 8 && p->blk.cout == 34) return FN<34, 8, 34, true>(__VA_ARGS__);       \
+        /* the two extra blocks of the 3sa-arch variant: global SA on [x3 | pos3], FP4 on [global | x3] */       \
+        if (!knn && p->ca == 64 && p->cb == 3 && p->blk.cout == 64) return FN<64, 3, 64, false>(__VA_ARGS__);     \
+        if (knn && p->ca == 64 && p->cb == 64 && p->blk.cout == 64) return FN<64, 64, 64, true>(__VA_ARGS__);     \
         return SN2_ELIMIT;                                                                                        \
     } while (0)
 

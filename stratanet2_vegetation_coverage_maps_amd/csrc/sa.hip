@@ -70,7 +70,9 @@ int check(const sn2_sa* p) {
     const bool sa1 = p->cf == 8 && p->nl == 2 && p->blk[0].cin == 11 && p->blk[0].cout == 16 && p->blk[1].cin == 16 &&
                      p->blk[1].cout == 16;
     const bool sa2 = p->cf == 16 && p->nl == 1 && p->blk[0].cin == 19 && p->blk[0].cout == 32;
-    return (sa1 || sa2) ? 0 : SN2_ELIMIT;
+    // a third ball-query level, MLP[35,64]: not in the reference (BASELINE config 2 names it: the "3sa-arch" variant)
+    const bool sa3 = p->cf == 32 && p->nl == 1 && p->blk[0].cin == 35 && p->blk[0].cout == 64;
+    return (sa1 || sa2 || sa3) ? 0 : SN2_ELIMIT;
 }
 
 template <int CF, int NL, int C1, int C2>
@@ -163,6 +165,7 @@ extern "C" int sn2_sa_order(const int* cnt, int B, int M, int* order, void* stre
 extern "C" int sn2_sa_forward(const sn2_sa* p, int training, void* stream) {
     SN2_TRY(check(p));
     if (p->nl == 2) return forward_t<8, 2, 16, 16>(p, training, (hipStream_t)stream);
+    if (p->cf == 32) return forward_t<32, 1, 64, 64>(p, training, (hipStream_t)stream);
     return forward_t<16, 1, 32, 32>(p, training, (hipStream_t)stream);
 }
 
@@ -170,5 +173,6 @@ extern "C" int sn2_sa_backward(const sn2_sa* p, void* stream) {
     SN2_TRY(check(p));
     if (!p->dout) return SN2_EINVAL;
     if (p->nl == 2) return backward_t<8, 2, 16, 16>(p, (hipStream_t)stream);
+    if (p->cf == 32) return backward_t<32, 1, 64, 64>(p, (hipStream_t)stream);
     return backward_t<16, 1, 32, 32>(p, (hipStream_t)stream);
 }

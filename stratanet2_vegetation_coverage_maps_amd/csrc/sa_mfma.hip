@@ -741,6 +741,7 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
 template int sa_mfma_launch_fwd<8, 2, 16, 16, 0>(const sn2_sa*, int, hipStream_t, int*);
 template int sa_mfma_launch_fwd<8, 2, 16, 16, 1>(const sn2_sa*, int, hipStream_t, int*);
 template int sa_mfma_launch_fwd<16, 1, 32, 32, 1>(const sn2_sa*, int, hipStream_t, int*);
+template int sa_mfma_launch_fwd<32, 1, 64, 64, 1>(const sn2_sa*, int, hipStream_t, int*);   // third ball-query level (3sa-arch)
 
 template <int CF, int NL, int C1, int C2, int PASS>
 int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
@@ -772,3 +773,4 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
 template int sa_mfma_launch_bwd<8, 2, 16, 16, 2>(const sn2_sa*, hipStream_t);
 template int sa_mfma_launch_bwd<8, 2, 16, 16, 3>(const sn2_sa*, hipStream_t);
 template int sa_mfma_launch_bwd<16, 1, 32, 32, 3>(const sn2_sa*, hipStream_t);
+template int sa_mfma_launch_bwd<32, 1, 64, 64, 3>(const sn2_sa*, hipStream_t);
