@@ -488,6 +488,14 @@ __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot
     }
 }
 
+// LDS of fp_bwd_split_kernel: inputs [64][QS] + per-wave dp [4][64][16] + the input-gradient slab(s) [1 or 4][64][CI|1]
+template <int CI>
+constexpr size_t fp_split_lds_bytes(int slabs) {
+    return (size_t)(64 * OuterAcc<16, CI + 1>::QS + 4 * 64 * 16 + slabs * 64 * (CI | 1)) * 4;
+}
+template <int CI>
+constexpr bool fp_split_du_seq() { return fp_split_lds_bytes<CI>(4) > 150 * 1024; }   // one slab, the waves take turns
+
 template <int CA, int CB, int CO, bool KNN>
 __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     int R, int R_per_plot, int S_per_plot, int src_stride, int skip_stride, int h_stride, int dskip_stride, int du_stride,
@@ -500,6 +508,7 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     constexpr int CI = CA + CB, COG = (CO + 3) / 4;
     using Acc = OuterAcc<16, CI + 1>;
     constexpr int QS = Acc::QS, TK = Acc::TK, CIP = CI | 1;
+    constexpr bool DU_SEQ = fp_split_du_seq<CI>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_q = smem;                       // [64][QS]  the rows' inputs | 1, shared by the four waves
     float* s_p = s_q + 64 * QS;              // [4][64][16] per-wave d pre-activation of its channel group
@@ -563,28 +572,40 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
                 const int t = 4 * kb + qq, o = g * COG + t, col = 16 * jt + cc;
                 Wb[kb][jt] = (t < COG && o < CO && col < CI) ? W[o * CI + col] : 0.f;
             }
+        // DU_SEQ (wide inputs: CI = 128): one slab for the workgroup, the four waves add their partial products in turn
+        // (four slabs would not fit LDS); otherwise one slab per wave, summed at write-out
+        for (int turn = 0; turn < (DU_SEQ ? 4 : 1); ++turn) {
+            if (!DU_SEQ || g == turn) {
 #pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
-            f32x4 D[TJ];
+                for (int tile = 0; tile < 4; ++tile) {
+                    f32x4 D[TJ];
 #pragma unroll
-            for (int jt = 0; jt < TJ; ++jt) D[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int jt = 0; jt < TJ; ++jt) D[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const float av = s_p[(g * 64 + 16 * tile + cc) * 16 + 4 * kb + qq];
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const float av = s_p[(g * 64 + 16 * tile + cc) * 16 + 4 * kb + qq];
 #pragma unroll
-                for (int jt = 0; jt < TJ; ++jt) D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wb[kb][jt], D[jt], 0, 0, 0);
-            }
+                        for (int jt = 0; jt < TJ; ++jt)
+                            D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wb[kb][jt], D[jt], 0, 0, 0);
+                    }
 #pragma unroll
-            for (int jt = 0; jt < TJ; ++jt)
+                    for (int jt = 0; jt < TJ; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int col = 16 * jt + cc;
-                    if (col < CI) s_du[(g * 64 + 16 * tile + 4 * qq + r) * CIP + col] = D[jt][r];
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = 16 * jt + cc;
+                            if (col < CI) {
+                                float* dst = &s_du[((DU_SEQ ? 0 : g) * 64 + 16 * tile + 4 * qq + r) * CIP + col];
+                                *dst = (DU_SEQ && turn > 0) ? *dst + D[jt][r] : D[jt][r];
+                            }
+                        }
                 }
+            }
+            if (DU_SEQ) __syncthreads();
         }
     }
     __syncthreads();
     auto du_sum = [&](int row, int k) {
+        if (DU_SEQ) return s_du[row * CIP + k];
         return (s_du[(0 * 64 + row) * CIP + k] + s_du[(1 * 64 + row) * CIP + k]) +
                (s_du[(2 * 64 + row) * CIP + k] + s_du[(3 * 64 + row) * CIP + k]);
     };
@@ -689,10 +710,9 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     float* du_out0 = KNN ? p->du_scratch : p->dsrc;
     if (KNN && p->dsrc && !p->du_scratch) return SN2_EINVAL;
     if (KNN && !p->dsrc) du_out0 = nullptr;
-    using AccS = OuterAcc<16, CI + 1>;
-    constexpr size_t lb = (size_t)(64 * AccS::QS + 4 * 64 * 16 + 4 * 64 * (CI | 1)) * 4;
-    // the 64-row x 4-channel-group kernel when the layer is small and its staging fits LDS (CI = 128 does not)
-    const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS && lb <= 150 * 1024;
+    constexpr size_t lb = fp_split_lds_bytes<CI>(fp_split_du_seq<CI>() ? 1 : 4);
+    static_assert(lb <= 150 * 1024, "fp_bwd_split_kernel staging must fit LDS");
+    const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS;   // the 64-row x 4-channel-group kernel for small layers
     if (small) {
         auto ks = &fp_bwd_split_kernel<CA, CB, CO, KNN>;
         if (lb > 48 * 1024)
