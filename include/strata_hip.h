@@ -152,14 +152,21 @@ typedef struct sn2_fp {
     const float *dy;                /* backward in : d loss / d (a*h+c)  (B*R,h_stride)                          */
     float *dsrc; int dsrc_stride;   /* backward out: ACCUMULATED d loss / d (sa*src+sc) (B*S,dsrc_stride) or NULL */
     float *dskip; int dskip_stride; /* backward out: ACCUMULATED (B*R, >=cb) or NULL                             */
-    float *du_scratch;              /* backward workspace (B*R,ca) when knn_idx and dsrc are given               */
+    float *du_scratch;              /* backward workspace (B*R, max(ca, h_stride)) when knn_idx and dsrc are given */
     float *scatter_ws;              /* backward workspace when knn_idx and dsrc are given: SN2_INTERP_WS_WORDS(B,R,S)
                                        32-bit words (inverted index of the 3-NN table)                           */
     int scatter_ready;              /* non-zero: scatter_ws already holds the index (sn2_interp_index)           */
     const int *bn_sums_done;        /* device int or NULL: 1 = blk.dgamma / blk.dbeta already hold this BatchNorm's
                                        gradients (sn2_head_bn_sums / sn2_fp_bn_sums): the pass over the rows that
                                        sn2_fp_backward launches for them returns at once                         */
+    float *src_ws;                  /* workspace SN2_FP_SRC_WS_WORDS(B,S,cout) floats or NULL.  Given with knn_idx on a
+                                       layer of more than 64*SN2_STAT_SLOTS rows with cb % 4 == 0 (the per-point layer),
+                                       everything linear in the interpolation is done once per SOURCE row: forward
+                                       gathers rows of T = W_A (sa*src+sc) kept here; backward keeps G[s] = sum of
+                                       w * d pre-activation over the rows interpolating s here (dsrc += G W_A,
+                                       dW_A += G^T (sa*src+sc)).  NULL: every row rebuilds its interpolated input.     */
 } sn2_fp;
+#define SN2_FP_SRC_WS_WORDS(B, S, cout) ((size_t)(B) * (S) * ((((cout) + 3) / 4) * 4))
 /* The transpose of knn_interpolate (its backward) is done as a gather through an inverted index of the 3-NN table:
  * source -> list of (target row, normalised weight).  The index depends on positions only, so it can be built ahead of
  * the backward pass (in the geometry pass) with sn2_interp_index; otherwise sn2_fp_backward builds it itself. */

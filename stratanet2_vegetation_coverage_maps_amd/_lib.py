@@ -33,7 +33,7 @@ class FP(Structure):  # sn2_fp
                 ("knn_idx", c_void_p), ("knn_w", c_void_p), ("skip", c_void_p), ("skip_stride", c_int),
                 ("blk", Block), ("h", c_void_p), ("h_stride", c_int), ("dy", c_void_p), ("dsrc", c_void_p),
                 ("dsrc_stride", c_int), ("dskip", c_void_p), ("dskip_stride", c_int), ("du_scratch", c_void_p),
-                ("scatter_ws", c_void_p), ("scatter_ready", c_int), ("bn_sums_done", c_void_p)]
+                ("scatter_ws", c_void_p), ("scatter_ready", c_int), ("bn_sums_done", c_void_p), ("src_ws", c_void_p)]
 
 
 class Head(Structure):  # sn2_head

@@ -21,6 +21,20 @@
 
 static inline int sn2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// compute units of the current device (256 on MI355X), for the grids of the persistent kernels
+static inline int sn2_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 // ---- wave-uniform read-only tables (weights, BN constants) -------------------------------------------------------
 // `cfp` = the same global memory viewed through the CONSTANT address space: uniform loads from it always become
 // s_load (the memory is not written while the kernel runs).  `opaque()` hides a pointer's provenance from the

@@ -435,6 +435,356 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(int n_src, int R_per
     if (on) dsrc[(size_t)s * dsrc_stride + lane] += (g0 + g1) + (g2 + g3);
 }
 
+// ---------------------------------------------------------------------------------------------- source-side form
+// The per-point layer (FP1: 524 288 rows interpolating 16 384 source rows) spent most of its time on work that is linear
+// in the interpolation and can be done once per SOURCE row instead of once per target row:
+//   W_A u_r = W_A (a o sum_j w_rj src[i_rj] + c) = sum_j w_rj T[i_rj],   T[s] = W_A (a o src[s] + c)      (sum_j w_rj = 1)
+//   dsrc[s] = sum_{r,j: i_rj = s} w_rj dp_r W_A = G[s] W_A,              G[s] = sum_{r,j: i_rj = s} w_rj dp_r
+//   dW_A    = sum_r dp_r^T u_r = sum_s G[s]^T (a o src[s] + c)
+// so the row side keeps only the skip columns (CB = 8 of 42 inputs: 5x fewer multiply-adds) and becomes a streaming pass:
+//   forward : T (n_src x CO, one small kernel), then per row 3 gathers of T rows + W_B skip + b -> relu -> h, statistics
+//   backward: rows: dp = BN/ReLU backward of dy (stored once), dW_B | db;  sources: G (gather of dp rows through the
+//             inverted index), dsrc += G W_A;  dW_A += G^T (a o src + c) on the matrix cores over the n_src rows.
+// The row kernels use QH = ceil(CO/4) consecutive lanes per row, one float4 quad each: a load or store instruction covers
+// 64/QH whole rows = ~1 KB of consecutive bytes, and nothing but the lane's own quad constants lives in registers.
+// Results differ from the row-per-lane form by fp32 re-association only.
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256) void fp_src_table_kernel(int n_src, int src_stride, const float* __restrict__ src,
+                                                           const float* __restrict__ src_a, const float* __restrict__ src_c,
+                                                           const float* __restrict__ Wg, float* __restrict__ T) {
+    constexpr int CI = CA + CB, HS = 4 * ((CO + 3) / 4);
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const size_t ss = s < n_src ? (size_t)s : 0;
+    const cfp W = opaque(as_const(Wg));
+    float x[CA];
+    const float4* sr = reinterpret_cast<const float4*>(src + ss * src_stride);
+#pragma unroll
+    for (int q4 = 0; q4 < (CA + 3) / 4; ++q4) {
+        const float4 a = sr[q4];
+        const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * q4 + t < CA) x[4 * q4 + t] = v[t];
+    }
+    if (src_a) {
+        const cfp sa = opaque(as_const(src_a)), sc = opaque(as_const(src_c));
+#pragma unroll
+        for (int k = 0; k < CA; ++k) x[k] = fmaf(sa[k], x[k], sc[k]);
+    }
+    float* out = T + ss * HS;
+#pragma unroll
+    for (int o4 = 0; o4 < HS; o4 += 4) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float acc = 0.f;
+            if (o4 + t < CO) {
+#pragma unroll
+                for (int k = 0; k < CA; ++k) acc = fmaf(W[(o4 + t) * CI + k], x[k], acc);
+            }
+            v[t] = acc;
+        }
+        if (s < n_src) *reinterpret_cast<float4*>(out + o4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot, int S_per_plot, int skip_stride,
+                                                          const float* __restrict__ T, const int* __restrict__ knn_idx,
+                                                          const float* __restrict__ knn_w, const float* __restrict__ skip,
+                                                          const float* __restrict__ Wg, const float* __restrict__ biasg,
+                                                          float* __restrict__ h, float* __restrict__ slots) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 2;
+    static_assert(CB > 0 && CB % 4 == 0, "skip quads");
+    __shared__ float s_part[8][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % QH, g = lane / QH;
+    const bool on = lane < G * QH;
+    float wB[4][CB], b4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int o = 4 * q + t;
+        b4[t] = o < CO ? biasg[o] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) wB[t][k] = o < CO ? Wg[o * CI + CA + k] : 0.f;
+    }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    const long n_grp = ((long)R + G - 1) / G;
+    const long n_waves = (long)gridDim.x * 4;
+    for (long grp0 = ((long)blockIdx.x * 4 + wave) * U; grp0 < n_grp; grp0 += n_waves * U) {
+        unsigned rr[U];
+        bool valid[U];
+        int i0[U], i1[U], i2[U];
+        float w0[U], w1[U], w2[U];
+        float4 sk[U][QB], ta[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = (grp0 + u) * G + g;
+            valid[u] = on && row < R;
+            rr[u] = valid[u] ? (unsigned)row : 0u;
+            i0[u] = knn_idx[rr[u] * 3 + 0], i1[u] = knn_idx[rr[u] * 3 + 1], i2[u] = knn_idx[rr[u] * 3 + 2];
+            w0[u] = knn_w[rr[u] * 3 + 0], w1[u] = knn_w[rr[u] * 3 + 1], w2[u] = knn_w[rr[u] * 3 + 2];
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+                sk[u][b] = reinterpret_cast<const float4*>(skip + (size_t)rr[u] * skip_stride)[b];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned base = (rr[u] / (unsigned)R_per_plot) * (unsigned)S_per_plot;
+            ta[u][0] = reinterpret_cast<const float4*>(T + (size_t)(base + i0[u]) * HS)[q];
+            ta[u][1] = reinterpret_cast<const float4*>(T + (size_t)(base + i1[u]) * HS)[q];
+            ta[u][2] = reinterpret_cast<const float4*>(T + (size_t)(base + i2[u]) * HS)[q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float inv = 1.0f / ((w0[u] + w1[u]) + w2[u]);
+            const float4 a = ta[u][0], b = ta[u][1], c = ta[u][2];
+            float v[4] = {((a.x * w0[u] + b.x * w1[u]) + c.x * w2[u]) * inv, ((a.y * w0[u] + b.y * w1[u]) + c.y * w2[u]) * inv,
+                          ((a.z * w0[u] + b.z * w1[u]) + c.z * w2[u]) * inv, ((a.w * w0[u] + b.w * w1[u]) + c.w * w2[u]) * inv};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float acc = v[t] + b4[t];
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    acc = fmaf(wB[t][4 * b + 0], sk[u][b].x, acc);
+                    acc = fmaf(wB[t][4 * b + 1], sk[u][b].y, acc);
+                    acc = fmaf(wB[t][4 * b + 2], sk[u][b].z, acc);
+                    acc = fmaf(wB[t][4 * b + 3], sk[u][b].w, acc);
+                }
+                acc = (valid[u] && 4 * q + t < CO) ? fmaxf(acc, 0.f) : 0.f;
+                ssum[t] += acc;
+                ssq[t] = fmaf(acc, acc, ssq[t]);
+                v[t] = acc;
+            }
+            if (valid[u]) reinterpret_cast<float4*>(h + (size_t)rr[u] * HS)[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (!slots) return;
+    // batch statistics: per-lane partials -> LDS -> one slot per workgroup ([sum(C) | sumsq(C)], as stats_to_slot)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s_part[t][threadIdx.x] = on ? ssum[t] : 0.f;
+        s_part[4 + t][threadIdx.x] = on ? ssq[t] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * CO; e += 256) {
+        const int which = e / CO, c = e - which * CO, cq = c >> 2, ct = c & 3;
+        float acc = 0.f;
+        for (int w = 0; w < 4; ++w)
+            for (int gg = 0; gg < G; ++gg) acc += s_part[which * 4 + ct][w * 64 + cq + QH * gg];
+        slots[(size_t)blockIdx.x * 2 * CO + e] = acc;
+    }
+}
+
+// rows: dp = relu'/BN backward of dy (stored, row stride HS, pad channels 0), dW_B | db
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256) void fp_bwd_rows_kernel(int R, int skip_stride, float invR, const float* __restrict__ skip,
+                                                          const float* __restrict__ gammag, const float* __restrict__ meang,
+                                                          const float* __restrict__ invstdg, const float* __restrict__ dgammag,
+                                                          const float* __restrict__ dbetag, const float* __restrict__ h,
+                                                          const float* __restrict__ dy, float* __restrict__ dp_out,
+                                                          float* __restrict__ dW, float* __restrict__ db) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 2, NV = 4 * (CB + 1);
+    static_assert(CB > 0 && CB % 4 == 0, "skip quads");
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NV][256]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % QH, g = lane / QH;
+    const bool on = lane < G * QH;
+    float c_is[4], c_mu[4], c_gis[4], c_dbR[4], c_dg[4];
+    bool ch[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int o = 4 * q + t;
+        ch[t] = o < CO;
+        const int oo = ch[t] ? o : 0;
+        c_is[t] = invstdg[oo];
+        c_mu[t] = meang[oo];
+        c_gis[t] = gammag[oo] * c_is[t];
+        c_dbR[t] = dbetag[oo] * invR;
+        c_dg[t] = dgammag[oo];
+    }
+    float aW[4][CB], ab[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ab[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) aW[t][k] = 0.f;
+    }
+    const long n_grp = ((long)R + G - 1) / G;
+    const long n_waves = (long)gridDim.x * 4;
+    for (long grp0 = ((long)blockIdx.x * 4 + wave) * U; grp0 < n_grp; grp0 += n_waves * U) {
+        float4 hv[U], dv[U], sk[U][QB];
+        bool valid[U];
+        unsigned rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = (grp0 + u) * G + g;
+            valid[u] = on && row < R;
+            rr[u] = valid[u] ? (unsigned)row : 0u;
+            hv[u] = reinterpret_cast<const float4*>(h + (size_t)rr[u] * HS)[q];
+            dv[u] = reinterpret_cast<const float4*>(dy + (size_t)rr[u] * HS)[q];
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+                sk[u][b] = reinterpret_cast<const float4*>(skip + (size_t)rr[u] * skip_stride)[b];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float hh[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+            float d4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float xh = (hh[t] - c_mu[t]) * c_is[t];
+                const float dh = c_gis[t] * (dd[t] - c_dbR[t] - xh * c_dg[t] * invR);
+                d4[t] = (valid[u] && ch[t] && hh[t] > 0.f) ? dh : 0.f;
+                ab[t] += d4[t];
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    aW[t][4 * b + 0] = fmaf(d4[t], sk[u][b].x, aW[t][4 * b + 0]);
+                    aW[t][4 * b + 1] = fmaf(d4[t], sk[u][b].y, aW[t][4 * b + 1]);
+                    aW[t][4 * b + 2] = fmaf(d4[t], sk[u][b].z, aW[t][4 * b + 2]);
+                    aW[t][4 * b + 3] = fmaf(d4[t], sk[u][b].w, aW[t][4 * b + 3]);
+                }
+            }
+            if (valid[u]) reinterpret_cast<float4*>(dp_out + (size_t)rr[u] * HS)[q] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+        }
+    }
+    // per-lane partials -> LDS (plain stores) -> one sum per element and workgroup -> global atomics
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int k = 0; k < CB; ++k) smem[(t * (CB + 1) + k) * 256 + threadIdx.x] = on ? aW[t][k] : 0.f;
+        smem[(t * (CB + 1) + CB) * 256 + threadIdx.x] = on ? ab[t] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CO * (CB + 1); e += 256) {
+        const int o = e / (CB + 1), k = e - o * (CB + 1), oq = o >> 2, ot = o & 3;
+        float acc = 0.f;
+        for (int w = 0; w < 4; ++w)
+            for (int gg = 0; gg < G; ++gg) acc += smem[(ot * (CB + 1) + k) * 256 + w * 64 + oq + QH * gg];
+        if (acc != 0.f) atomicAdd(k < CB ? &dW[o * CI + CA + k] : &db[o], acc);
+    }
+    (void)NV;
+}
+
+// sources: G[s] = sum over the inverted list of w * dp[row] (QH lanes per entry, 64/QH entries per load instruction),
+// stored for the dW_A pass; dsrc[s] += G[s] W_A
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_plot, int S, int dsrc_stride,
+                                                         const int* __restrict__ off, const int* __restrict__ cnt,
+                                                         const int* __restrict__ inv_row, const float* __restrict__ inv_w,
+                                                         const float* __restrict__ dp, const float* __restrict__ Wg,
+                                                         float* __restrict__ Gout, float* __restrict__ dsrc) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, STEPS = 64 / G, CH = G * STEPS;
+    __shared__ float s_W[CO * CA];
+    __shared__ __attribute__((aligned(16))) float s_part[4][G][HS];
+    __shared__ float s_G[4][HS];
+    for (int i = threadIdx.x; i < CO * CA; i += 256) s_W[i] = Wg[(i / CA) * CI + (i % CA)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % QH, g = lane / QH;
+    const bool on = lane < G * QH;
+    for (int s = blockIdx.x * 4 + wave; s < n_src; s += gridDim.x * 4) {
+        const int b = s / S;
+        const int n = cnt[s], st = off[s];
+        const float* dpb = dp + (size_t)b * R_per_plot * HS;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = 0; base < n; base += CH) {
+            const int m = (n - base) < CH ? (n - base) : CH;
+            const int rj = lane < m ? inv_row[st + base + lane] : 0;       // entries past the end: row 0 with weight 0
+            const float wj = lane < m ? inv_w[st + base + lane] : 0.f;
+            float4 v[STEPS];
+            float wv[STEPS];
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) {
+                const int e = G * j + g;
+                const int r = __shfl(rj, e);
+                const float w = __shfl(wj, e);
+                wv[j] = on ? w : 0.f;
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (G * j < m) v[j] = reinterpret_cast<const float4*>(dpb + (size_t)r * HS)[q];
+            }
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) {
+                acc[0] = fmaf(wv[j], v[j].x, acc[0]);
+                acc[1] = fmaf(wv[j], v[j].y, acc[1]);
+                acc[2] = fmaf(wv[j], v[j].z, acc[2]);
+                acc[3] = fmaf(wv[j], v[j].w, acc[3]);
+            }
+        }
+        if (on) *reinterpret_cast<float4*>(&s_part[wave][g][4 * q]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < HS) {
+            float gk = 0.f;
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) gk += s_part[wave][gg][lane];
+            s_G[wave][lane] = gk;
+            Gout[(size_t)s * HS + lane] = gk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < CA) {
+            float d = 0.f;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) d = fmaf(s_G[wave][o], s_W[o * CA + lane], d);
+            dsrc[(size_t)s * dsrc_stride + lane] += d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// dW_A += sum_s G[s]^T (a o src[s] + c): one source row per lane, rows = MFMA K
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256) void fp_bwd_src_dw_kernel(int n_src, int src_stride, const float* __restrict__ src,
+                                                            const float* __restrict__ src_a, const float* __restrict__ src_c,
+                                                            const float* __restrict__ Gin, float* __restrict__ dW) {
+    constexpr int CI = CA + CB, HS = 4 * ((CO + 3) / 4);
+    using Acc = OuterAcc<CO, CA, 32>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds = smem + (threadIdx.x >> 6) * Acc::LDS_FLOATS;
+    Acc acc;
+    acc.init(lds);
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = s < n_src;
+    const size_t ss = valid ? (size_t)s : 0;
+    float p[CO], x[CA];
+    const float4* gr = reinterpret_cast<const float4*>(Gin + ss * HS);
+#pragma unroll
+    for (int q4 = 0; q4 < (CO + 3) / 4; ++q4) {
+        const float4 a = gr[q4];
+        const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * q4 + t < CO) p[4 * q4 + t] = valid ? v[t] : 0.f;
+    }
+    const float4* sr = reinterpret_cast<const float4*>(src + ss * src_stride);
+#pragma unroll
+    for (int q4 = 0; q4 < (CA + 3) / 4; ++q4) {
+        const float4 a = sr[q4];
+        const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * q4 + t < CA) x[4 * q4 + t] = v[t];
+    }
+    if (src_a) {
+        const cfp sa = opaque(as_const(src_a)), sc = opaque(as_const(src_c));
+#pragma unroll
+        for (int k = 0; k < CA; ++k) x[k] = fmaf(sa[k], x[k], sc[k]);
+    }
+    acc.add(lds, p, x);
+    float* red = smem;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CO * CA; i += 256) red[i] = 0.f;
+    __syncthreads();
+    acc.flush_lds(red);
+    __syncthreads();
+    for (int i = threadIdx.x; i < CO * CA; i += 256) {
+        const float v = red[i];
+        if (v != 0.f) atomicAdd(&dW[(i / CA) * CI + (i % CA)], v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- small layers
 // Layers with few rows (SA3, FP3, FP2: 4k-16k rows, up to 96 -> 64 channels) gain nothing from one long FMA stream per
 // lane: 4096 rows are only 64 waves on a 1024-SIMD chip and each wave would issue >6000 dependent FMAs (the first
@@ -648,6 +998,14 @@ int pick_grid(long R, int threads, int rows_per_lane) {
     return (int)g;
 }
 
+// the source-side form applies: workspace given, quads aligned, 32-bit row offsets
+template <int CA, int CO>
+bool fp_source_side_ok(const sn2_fp* p) {
+    const long R = (long)p->B * p->R_per_plot;
+    return p->src_ws && p->knn_idx && (p->skip_stride & 3) == 0 && p->src_stride >= 4 * ((CA + 3) / 4) &&
+           p->h_stride == 4 * ((CO + 3) / 4) && R * 3 < (1L << 31);
+}
+
 template <int CA, int CB, int CO, bool KNN>
 int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     const int R = p->B * p->R_per_plot;
@@ -659,6 +1017,22 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
         hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return (int)e0;
         return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
+    }
+    if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) {
+        if (fp_source_side_ok<CA, CO>(p)) {               // the per-point layer: source-side form
+            const int n_src = p->B * p->S_per_plot;
+            hipLaunchKernelGGL((fp_src_table_kernel<CA, CB, CO>), dim3(sn2_cdiv(n_src, 256)), dim3(256), 0, st, n_src,
+                               p->src_stride, p->src, p->src_a, p->src_c, p->blk.W, p->src_ws);
+            const long n_grp = sn2_cdiv(R, 64 / ((CO + 3) / 4));
+            int grid = sn2_cdiv(n_grp, 8);
+            if (grid > SN2_STAT_SLOTS) grid = SN2_STAT_SLOTS;
+            hipLaunchKernelGGL((fp_fwd_rows_kernel<CA, CB, CO>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
+                               p->skip_stride, (const float*)p->src_ws, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.b, p->h,
+                               training ? p->blk.stat_slots : (float*)nullptr);
+            hipError_t e1 = hipGetLastError();
+            if (e1 != hipSuccess) return (int)e1;
+            return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
+        }
     }
     int grid = pick_grid(R, 256, 4);
     if (grid > SN2_STAT_SLOTS) grid = SN2_STAT_SLOTS;
@@ -724,6 +1098,38 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
                            (const float*)p->blk.dbeta, (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out0, p->dskip);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
+    }
+    if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) {
+        if (!small && fp_source_side_ok<CA, CO>(p) && p->dsrc && !p->dskip && p->du_scratch && p->scatter_ws) {
+            const int S = p->S_per_plot, Rp = p->R_per_plot, B = p->B, n_src = B * S;
+            if (S > 8192) return SN2_ELIMIT;
+            hipLaunchKernelGGL((fp_bwd_rows_kernel<CA, CB, CO>), dim3(2 * sn2_cu_count()), dim3(256),
+                               (size_t)4 * (CB + 1) * 256 * sizeof(float), st, R, p->skip_stride, 1.0f / (float)R, p->skip,
+                               p->blk.gamma, (const float*)p->blk.mean, (const float*)p->blk.invstd,
+                               (const float*)p->blk.dgamma, (const float*)p->blk.dbeta, (const float*)p->h, p->dy,
+                               p->du_scratch, p->blk.dW, p->blk.db);
+            if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, B, Rp, S, p->scatter_ws, st));
+            const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
+            int* H = reinterpret_cast<int*>(p->scatter_ws);
+            int* off = H + (size_t)B * SL * S;
+            int* cnt = off + (size_t)B * S;
+            int* inv_row = cnt + (size_t)B * S;
+            float* inv_w = reinterpret_cast<float*>(inv_row + (size_t)3 * B * Rp);
+            int gs = sn2_cdiv(n_src, 4);
+            if (gs > 8 * sn2_cu_count()) gs = 8 * sn2_cu_count();
+            hipLaunchKernelGGL((fp_bwd_src_kernel<CA, CB, CO>), dim3(gs), dim3(256), 0, st, n_src, Rp, S, p->dsrc_stride,
+                               (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
+                               (const float*)p->du_scratch, p->blk.W, p->src_ws, p->dsrc);
+            using AccD = OuterAcc<CO, CA, 32>;
+            constexpr size_t db3 = (size_t)AccD::LDS_FLOATS * 4 * 4;
+            static_assert(db3 >= (size_t)CO * CA * 4, "reduction image fits the staging regions");
+            auto k3 = &fp_bwd_src_dw_kernel<CA, CB, CO>;
+            if (db3 > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)db3);
+            hipLaunchKernelGGL(k3, dim3(sn2_cdiv(n_src, 256)), dim3(256), db3, st, n_src, p->src_stride, p->src, p->src_a,
+                               p->src_c, (const float*)p->src_ws, p->blk.dW);
+            SN2_RETURN_LAUNCH();
+        }
     }
     constexpr size_t lds_bytes = (size_t)Acc::LDS_FLOATS * 4 * WAVES;
     auto kern = &fp_bwd_main_kernel<CA, CB, CO, KNN, WAVES>;

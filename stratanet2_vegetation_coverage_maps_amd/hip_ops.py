@@ -400,6 +400,9 @@ def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[to
     return out
 
 
+SOURCE_SIDE = True     # False: never hand out src_ws, i.e. every row rebuilds its interpolated input (tests compare both)
+
+
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
             dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False, interp_index=None,
             bn_sums_done=None) -> FP:
@@ -444,8 +447,13 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     if bn_sums_done is not None:
         _chk(bn_sums_done, I32, (1,), "bn_sums_done")
     d.bn_sums_done = _ptr(bn_sums_done)
+    # source-side workspace of the per-point layer (include/strata_hip.h: src_ws); scratch, so one per descriptor
+    d._src_ws = None
+    if SOURCE_SIDE and knn is not None and 0 < cb <= 16 and cb % 4 == 0 and R > 64 * _lib.STAT_SLOTS:
+        d._src_ws = torch.empty(B * S_per_plot * hs, dtype=F32, device=src.device)
+    d.src_ws = _ptr(d._src_ws)
     if du_scratch is not None:
-        _chk(du_scratch, F32, (R, ca), "du_scratch")
+        _chk(du_scratch, F32, (R, max(ca, hs)), "du_scratch")
         if knn is not None and dsrc is not None:
             # inverted index of the 3-NN table: prebuilt by interp_index (geometry pass) or built by the backward call
             words = interp_ws_words(B, R_per_plot, S_per_plot)

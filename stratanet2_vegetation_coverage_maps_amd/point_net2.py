@@ -421,7 +421,7 @@ class PointNet2(nn.Module):
         ops.head_bn_sums(hd, bn1.weight.detach(), bn1.bias.detach(), views[id(bn1.weight)], views[id(bn1.bias)], bn_ok[0:1])
         # FP1 -> d(fp2 output)
         dy2 = buf["dy2"].view(B * M1, 36)
-        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 34, dtype=F32, device=dev), with_grads=True,
+        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 36, dtype=F32, device=dev), with_grads=True,
                             interp_index=s.inv1, bn_sums_done=bn_ok[0:1])
         ops.fp_backward(d1)
         bn2 = self.fp2_module.nn[0][2]      # FP2's BatchNorm feeds FP1's interpolation: its gradients from FP1's dW, db

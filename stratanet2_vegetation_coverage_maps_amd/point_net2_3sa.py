@@ -234,7 +234,7 @@ class PointNet2ThreeSA(PointNet2):
         dy2, dy3, dy4 = buf["dy2"].view(B * M1, 36), buf["dy3"].view(B * M2, 64), buf["dy4"].view(B * M3, 64)
         dx1, dx2, dx3 = buf["dx1"].view(B * M1, 16), buf["dx2"].view(B * M2, 32), buf["dx3"].view(B * M3, 64)
         dxg, dy_sa4 = buf["dxg"].view(B, 64), buf["dy_sa4"].view(B * M3, 64)
-        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=e(B * N, 34), with_grads=True, interp_index=s.inv1,
+        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=e(B * N, 36), with_grads=True, interp_index=s.inv1,
                             bn_sums_done=bn_ok[0:1])
         ops.fp_backward(d1)
         sums(ops.fp_bn_sums, d1, bn_of(self.fp2_module), 1)
