@@ -170,9 +170,12 @@ typedef struct sn2_fp {
 /* The transpose of knn_interpolate (its backward) is done as a gather through an inverted index of the 3-NN table:
  * source -> list of (target row, normalised weight).  The index depends on positions only, so it can be built ahead of
  * the backward pass (in the geometry pass) with sn2_interp_index; otherwise sn2_fp_backward builds it itself. */
-#define SN2_INTERP_WS_WORDS(B, R, S) ((size_t)(B) * (S) * (((R) + 2047) / 2048 + 2) + 6 * (size_t)(B) * (R) + 64)
-int sn2_interp_index(const int *knn_idx, const float *knn_w, int B, int R_per_plot, int S_per_plot, float *ws,
-                     void *stream);
+#define SN2_INTERP_WS_WORDS(B, R, S) ((size_t)(B) * (S) * (((R) + 2047) / 2048 + 6) + 6 * (size_t)(B) * (R) + 64)
+/* src_pos: (B*S,4) x,y,z,- rows of the SOURCE positions or NULL.  Given, the index also holds the sources of every plot
+ * in Morton order, and the source-side backward (sn2_fp.src_ws) walks them in that order, one stretch per XCD, so that
+ * target rows shared by neighbouring sources stay in that XCD's L2. */
+int sn2_interp_index(const int *knn_idx, const float *knn_w, const float *src_pos, int B, int R_per_plot,
+                     int S_per_plot, float *ws, void *stream);
 int sn2_fp_forward(const sn2_fp *p, int training, void *stream);
 int sn2_fp_backward(const sn2_fp *p, void *stream);
 

@@ -58,7 +58,7 @@ SIGNATURES = {
     "sn2_sa_order": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sn2_sa_forward": [POINTER(SA), c_int, c_void_p],
     "sn2_sa_backward": [POINTER(SA), c_void_p],
-    "sn2_interp_index": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sn2_interp_index": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_fp_forward": [POINTER(FP), c_int, c_void_p],
     "sn2_fp_backward": [POINTER(FP), c_void_p],
     "sn2_plot_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],

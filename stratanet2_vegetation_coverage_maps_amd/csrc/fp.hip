@@ -396,6 +396,83 @@ __global__ __launch_bounds__(1024) void inv_fill_kernel(int R_per_plot, int S, c
     }
 }
 
+// E  the plot's sources along a Morton curve (identity without positions): items[plot*S + rank] = {source id, list offset,
+//    list length, -}: one load tells a wave of the source-side kernel all about its source.  The source-side kernels walk
+//    the sources in this order, one contiguous stretch of it per XCD, so that the target rows shared by neighbouring
+//    sources (every target row is on the lists of its three nearest sources) are fetched into that XCD's L2 once.
+//    Keys: 10 bits per axis inside the plot's bounding box; ranks by comparison counting in LDS (ties by id).
+__device__ __forceinline__ unsigned spread10(unsigned v) {
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(1024) void inv_order_kernel(const float4* __restrict__ pos, int S, const int* __restrict__ off,
+                                                         const int* __restrict__ cnt, int4* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned s_key[];   // [S rounded up to 4] + 6 floats of bounding box
+    __shared__ float s_lo[3][16], s_hi[3][16];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* pb = pos + (size_t)b * S;
+    if (!pos) {                                                        // no positions: identity
+        for (int i = threadIdx.x; i < S; i += 1024) {
+            const int id = b * S + i;
+            items[id] = make_int4(id, off[id], cnt[id], 0);
+        }
+        return;
+    }
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = threadIdx.x; i < S; i += 1024) {
+        const float4 p = pb[i];
+        lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+        }
+        if (lane == 0) s_lo[a][wave] = lo[a], s_hi[a][wave] = hi[a];
+    }
+    __syncthreads();
+    float sc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = s_lo[a][0], h = s_hi[a][0];
+        for (int w = 1; w < 16; ++w) l = fminf(l, s_lo[a][w]), h = fmaxf(h, s_hi[a][w]);
+        lo[a] = l;
+        sc[a] = h > l ? 1023.999f / (h - l) : 0.f;
+    }
+    const int S4 = (S + 3) & ~3;
+    for (int i = threadIdx.x; i < S4; i += 1024) {
+        unsigned key = 0xFFFFFFFFu;                                    // padding sorts last
+        if (i < S) {
+            const float4 p = pb[i];
+            const unsigned qx = (unsigned)((p.x - lo[0]) * sc[0]), qy = (unsigned)((p.y - lo[1]) * sc[1]),
+                           qz = (unsigned)((p.z - lo[2]) * sc[2]);
+            key = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += 1024) {
+        const unsigned mine = s_key[i];
+        int rank = 0;
+        for (int j = 0; j < S4; j += 4) {
+            const uint4 o = *reinterpret_cast<const uint4*>(&s_key[j]);
+            rank += (o.x < mine || (o.x == mine && j < i)) ? 1 : 0;
+            rank += (o.y < mine || (o.y == mine && j + 1 < i)) ? 1 : 0;
+            rank += (o.z < mine || (o.z == mine && j + 2 < i)) ? 1 : 0;
+            rank += (o.w < mine || (o.w == mine && j + 3 < i)) ? 1 : 0;
+        }
+        const int id = b * S + i;
+        items[(size_t)b * S + rank] = make_int4(id, off[id], cnt[id], 0);
+    }
+}
+
 template <int CA>
 __global__ __launch_bounds__(256) void interp_gather_kernel(int n_src, int R_per_plot, int S, int dsrc_stride,
                                                             const int* __restrict__ off, const int* __restrict__ cnt,
@@ -452,8 +529,9 @@ template <int CA, int CB, int CO>
 __global__ __launch_bounds__(256) void fp_src_table_kernel(int n_src, int src_stride, const float* __restrict__ src,
                                                            const float* __restrict__ src_a, const float* __restrict__ src_c,
                                                            const float* __restrict__ Wg, float* __restrict__ T) {
-    constexpr int CI = CA + CB, HS = 4 * ((CO + 3) / 4);
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    // 64 source rows per workgroup, wave g = output channels [g*QH, (g+1)*QH): 4x the waves, 4x shorter FMA chains
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH;
+    const int s = blockIdx.x * 64 + (threadIdx.x & 63), grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const size_t ss = s < n_src ? (size_t)s : 0;
     const cfp W = opaque(as_const(Wg));
     float x[CA];
@@ -471,21 +549,40 @@ __global__ __launch_bounds__(256) void fp_src_table_kernel(int n_src, int src_st
 #pragma unroll
         for (int k = 0; k < CA; ++k) x[k] = fmaf(sa[k], x[k], sc[k]);
     }
-    float* out = T + ss * HS;
+    float* out = T + ss * HS + grp * QH;
 #pragma unroll
-    for (int o4 = 0; o4 < HS; o4 += 4) {
-        float v[4];
+    for (int j = 0; j < QH; ++j) {
+        const int o = grp * QH + j;                     // wave-uniform
+        float acc = 0.f;
+        if (o < CO) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float acc = 0.f;
-            if (o4 + t < CO) {
-#pragma unroll
-                for (int k = 0; k < CA; ++k) acc = fmaf(W[(o4 + t) * CI + k], x[k], acc);
-            }
-            v[t] = acc;
+            for (int k = 0; k < CA; ++k) acc = fmaf(W[o * CI + k], x[k], acc);
         }
-        if (s < n_src) *reinterpret_cast<float4*>(out + o4) = make_float4(v[0], v[1], v[2], v[3]);
+        if (s < n_src) out[j] = acc;
     }
+}
+
+// what a (row, quad) lane of the row kernels reads ahead of its gathers: the row's 3-NN entry and skip columns
+template <int QB>
+struct FpRowIn {
+    unsigned rr;
+    bool valid;
+    int i0, i1, i2;
+    float w0, w1, w2;
+    float4 sk[QB];
+};
+template <int QB>
+__device__ __forceinline__ FpRowIn<QB> fp_row_in(long row, bool on, int R, const int* __restrict__ knn_idx,
+                                                 const float* __restrict__ knn_w, const float* __restrict__ skip,
+                                                 int skip_stride) {
+    FpRowIn<QB> in;
+    in.valid = on && row < R;
+    in.rr = in.valid ? (unsigned)row : 0u;
+    in.i0 = knn_idx[in.rr * 3 + 0], in.i1 = knn_idx[in.rr * 3 + 1], in.i2 = knn_idx[in.rr * 3 + 2];
+    in.w0 = knn_w[in.rr * 3 + 0], in.w1 = knn_w[in.rr * 3 + 1], in.w2 = knn_w[in.rr * 3 + 2];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) in.sk[b] = reinterpret_cast<const float4*>(skip + (size_t)in.rr * skip_stride)[b];
+    return in;
 }
 
 template <int CA, int CB, int CO>
@@ -511,52 +608,48 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     const long n_grp = ((long)R + G - 1) / G;
     const long n_waves = (long)gridDim.x * 4;
-    for (long grp0 = ((long)blockIdx.x * 4 + wave) * U; grp0 < n_grp; grp0 += n_waves * U) {
-        unsigned rr[U];
-        bool valid[U];
-        int i0[U], i1[U], i2[U];
-        float w0[U], w1[U], w2[U];
-        float4 sk[U][QB], ta[U][3];
+    long grp0 = ((long)blockIdx.x * 4 + wave) * U;
+    // the 3-NN entries and skip columns run one iteration ahead of the gathers that depend on them
+    FpRowIn<QB> nx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nx[u] = fp_row_in<QB>((grp0 + u) * G + g, on && grp0 < n_grp, R, knn_idx, knn_w, skip, skip_stride);
+    for (; grp0 < n_grp; grp0 += n_waves * U) {
+        FpRowIn<QB> in[U];
+        float4 ta[U][3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long row = (grp0 + u) * G + g;
-            valid[u] = on && row < R;
-            rr[u] = valid[u] ? (unsigned)row : 0u;
-            i0[u] = knn_idx[rr[u] * 3 + 0], i1[u] = knn_idx[rr[u] * 3 + 1], i2[u] = knn_idx[rr[u] * 3 + 2];
-            w0[u] = knn_w[rr[u] * 3 + 0], w1[u] = knn_w[rr[u] * 3 + 1], w2[u] = knn_w[rr[u] * 3 + 2];
-#pragma unroll
-            for (int b = 0; b < QB; ++b)
-                sk[u][b] = reinterpret_cast<const float4*>(skip + (size_t)rr[u] * skip_stride)[b];
+            in[u] = nx[u];
+            const unsigned base = (in[u].rr / (unsigned)R_per_plot) * (unsigned)S_per_plot;
+            ta[u][0] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i0) * HS)[q];
+            ta[u][1] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i1) * HS)[q];
+            ta[u][2] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i2) * HS)[q];
         }
+        const long grp1 = grp0 + n_waves * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) nx[u] = fp_row_in<QB>((grp1 + u) * G + g, on && grp1 < n_grp, R, knn_idx, knn_w, skip, skip_stride);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const unsigned base = (rr[u] / (unsigned)R_per_plot) * (unsigned)S_per_plot;
-            ta[u][0] = reinterpret_cast<const float4*>(T + (size_t)(base + i0[u]) * HS)[q];
-            ta[u][1] = reinterpret_cast<const float4*>(T + (size_t)(base + i1[u]) * HS)[q];
-            ta[u][2] = reinterpret_cast<const float4*>(T + (size_t)(base + i2[u]) * HS)[q];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float inv = 1.0f / ((w0[u] + w1[u]) + w2[u]);
+            const float w0 = in[u].w0, w1 = in[u].w1, w2 = in[u].w2;
+            const float inv = 1.0f / ((w0 + w1) + w2);
             const float4 a = ta[u][0], b = ta[u][1], c = ta[u][2];
-            float v[4] = {((a.x * w0[u] + b.x * w1[u]) + c.x * w2[u]) * inv, ((a.y * w0[u] + b.y * w1[u]) + c.y * w2[u]) * inv,
-                          ((a.z * w0[u] + b.z * w1[u]) + c.z * w2[u]) * inv, ((a.w * w0[u] + b.w * w1[u]) + c.w * w2[u]) * inv};
+            float v[4] = {((a.x * w0 + b.x * w1) + c.x * w2) * inv, ((a.y * w0 + b.y * w1) + c.y * w2) * inv,
+                          ((a.z * w0 + b.z * w1) + c.z * w2) * inv, ((a.w * w0 + b.w * w1) + c.w * w2) * inv};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float acc = v[t] + b4[t];
 #pragma unroll
-                for (int b = 0; b < QB; ++b) {
-                    acc = fmaf(wB[t][4 * b + 0], sk[u][b].x, acc);
-                    acc = fmaf(wB[t][4 * b + 1], sk[u][b].y, acc);
-                    acc = fmaf(wB[t][4 * b + 2], sk[u][b].z, acc);
-                    acc = fmaf(wB[t][4 * b + 3], sk[u][b].w, acc);
+                for (int b2 = 0; b2 < QB; ++b2) {
+                    acc = fmaf(wB[t][4 * b2 + 0], in[u].sk[b2].x, acc);
+                    acc = fmaf(wB[t][4 * b2 + 1], in[u].sk[b2].y, acc);
+                    acc = fmaf(wB[t][4 * b2 + 2], in[u].sk[b2].z, acc);
+                    acc = fmaf(wB[t][4 * b2 + 3], in[u].sk[b2].w, acc);
                 }
-                acc = (valid[u] && 4 * q + t < CO) ? fmaxf(acc, 0.f) : 0.f;
+                acc = (in[u].valid && 4 * q + t < CO) ? fmaxf(acc, 0.f) : 0.f;
                 ssum[t] += acc;
                 ssq[t] = fmaf(acc, acc, ssq[t]);
                 v[t] = acc;
             }
-            if (valid[u]) reinterpret_cast<float4*>(h + (size_t)rr[u] * HS)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            if (in[u].valid) reinterpret_cast<float4*>(h + (size_t)in[u].rr * HS)[q] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     if (!slots) return;
@@ -577,8 +670,8 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
 }
 
 // rows: dp = relu'/BN backward of dy (stored, row stride HS, pad channels 0), dW_B | db
-template <int CA, int CB, int CO>
-__global__ __launch_bounds__(256) void fp_bwd_rows_kernel(int R, int skip_stride, float invR, const float* __restrict__ skip,
+template <int CA, int CB, int CO, int NT>
+__global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride, float invR, const float* __restrict__ skip,
                                                           const float* __restrict__ gammag, const float* __restrict__ meang,
                                                           const float* __restrict__ invstdg, const float* __restrict__ dgammag,
                                                           const float* __restrict__ dbetag, const float* __restrict__ h,
@@ -586,7 +679,7 @@ __global__ __launch_bounds__(256) void fp_bwd_rows_kernel(int R, int skip_stride
                                                           float* __restrict__ dW, float* __restrict__ db) {
     constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 2, NV = 4 * (CB + 1);
     static_assert(CB > 0 && CB % 4 == 0, "skip quads");
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NV][256]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NV][NT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane % QH, g = lane / QH;
     const bool on = lane < G * QH;
@@ -611,8 +704,8 @@ __global__ __launch_bounds__(256) void fp_bwd_rows_kernel(int R, int skip_stride
         for (int k = 0; k < CB; ++k) aW[t][k] = 0.f;
     }
     const long n_grp = ((long)R + G - 1) / G;
-    const long n_waves = (long)gridDim.x * 4;
-    for (long grp0 = ((long)blockIdx.x * 4 + wave) * U; grp0 < n_grp; grp0 += n_waves * U) {
+    const long n_waves = (long)gridDim.x * (NT / 64);
+    for (long grp0 = ((long)blockIdx.x * (NT / 64) + wave) * U; grp0 < n_grp; grp0 += n_waves * U) {
         float4 hv[U], dv[U], sk[U][QB];
         bool valid[U];
         unsigned rr[U];
@@ -652,15 +745,15 @@ __global__ __launch_bounds__(256) void fp_bwd_rows_kernel(int R, int skip_stride
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int k = 0; k < CB; ++k) smem[(t * (CB + 1) + k) * 256 + threadIdx.x] = on ? aW[t][k] : 0.f;
-        smem[(t * (CB + 1) + CB) * 256 + threadIdx.x] = on ? ab[t] : 0.f;
+        for (int k = 0; k < CB; ++k) smem[(t * (CB + 1) + k) * NT + threadIdx.x] = on ? aW[t][k] : 0.f;
+        smem[(t * (CB + 1) + CB) * NT + threadIdx.x] = on ? ab[t] : 0.f;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < CO * (CB + 1); e += 256) {
+    for (int e = threadIdx.x; e < CO * (CB + 1); e += NT) {
         const int o = e / (CB + 1), k = e - o * (CB + 1), oq = o >> 2, ot = o & 3;
         float acc = 0.f;
-        for (int w = 0; w < 4; ++w)
-            for (int gg = 0; gg < G; ++gg) acc += smem[(ot * (CB + 1) + k) * 256 + w * 64 + oq + QH * gg];
+        for (int w = 0; w < NT / 64; ++w)
+            for (int gg = 0; gg < G; ++gg) acc += smem[(ot * (CB + 1) + k) * NT + w * 64 + oq + QH * gg];
         if (acc != 0.f) atomicAdd(k < CB ? &dW[o * CI + CA + k] : &db[o], acc);
     }
     (void)NV;
@@ -670,22 +763,37 @@ __global__ __launch_bounds__(256) void fp_bwd_rows_kernel(int R, int skip_stride
 // stored for the dW_A pass; dsrc[s] += G[s] W_A
 template <int CA, int CB, int CO>
 __global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_plot, int S, int dsrc_stride,
-                                                         const int* __restrict__ off, const int* __restrict__ cnt,
-                                                         const int* __restrict__ inv_row, const float* __restrict__ inv_w,
-                                                         const float* __restrict__ dp, const float* __restrict__ Wg,
-                                                         float* __restrict__ Gout, float* __restrict__ dsrc) {
+                                                         const int4* __restrict__ items, const int* __restrict__ inv_row,
+                                                         const float* __restrict__ inv_w, const float* __restrict__ dp,
+                                                         const float* __restrict__ Wg, float* __restrict__ Gout,
+                                                         float* __restrict__ dsrc) {
     constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, STEPS = 64 / G, CH = G * STEPS;
     __shared__ float s_W[CO * CA];
     __shared__ __attribute__((aligned(16))) float s_part[4][G][HS];
     __shared__ float s_G[4][HS];
-    for (int i = threadIdx.x; i < CO * CA; i += 256) s_W[i] = Wg[(i / CA) * CI + (i % CA)];
-    __syncthreads();
+    constexpr int WREG = (CO * CA + 255) / 256;
+    float wreg[WREG];                                   // W_A on its way to LDS: only the last phase needs it
+#pragma unroll
+    for (int i = 0; i < WREG; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        wreg[i] = e < CO * CA ? Wg[(e / CA) * CI + (e % CA)] : 0.f;
+    }
+    bool w_staged = false;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane % QH, g = lane / QH;
     const bool on = lane < G * QH;
-    for (int s = blockIdx.x * 4 + wave; s < n_src; s += gridDim.x * 4) {
+    // workgroups go to the XCDs round-robin: XCD x walks the stretch [x, x+1) * n_src/8 of the Morton order, its
+    // workgroups side by side (gridDim.x is a multiple of 8)
+    const int xcd = blockIdx.x & 7, wg_x = blockIdx.x >> 3, n_wg_x = gridDim.x >> 3;
+    const int p_lo = (int)((long)n_src * xcd / 8), p_hi = (int)((long)n_src * (xcd + 1) / 8);
+    for (int pp0 = p_lo + wg_x * 4; pp0 < p_hi; pp0 += n_wg_x * 4) {   // the same trip count for the four waves
+        const int pp = pp0 + wave;
+        const bool active = pp < p_hi;
+        const int4 item = active ? items[pp] : make_int4(0, 0, 0, 0);
+        const int s = __builtin_amdgcn_readfirstlane(item.x), st = __builtin_amdgcn_readfirstlane(item.y),
+                  n = __builtin_amdgcn_readfirstlane(item.z);
         const int b = s / S;
-        const int n = cnt[s], st = off[s];
+        const float d_old = (lane < CA && active) ? dsrc[(size_t)s * dsrc_stride + lane] : 0.f;   // early: off the chain
         const float* dpb = dp + (size_t)b * R_per_plot * HS;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int base = 0; base < n; base += CH) {
@@ -719,15 +827,24 @@ __global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_pl
 #pragma unroll
             for (int gg = 0; gg < G; ++gg) gk += s_part[wave][gg][lane];
             s_G[wave][lane] = gk;
-            Gout[(size_t)s * HS + lane] = gk;
+            if (active) Gout[(size_t)s * HS + lane] = gk;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < CA) {
+        if (!w_staged) {
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) {
+                const int e = threadIdx.x + 256 * i;
+                if (e < CO * CA) s_W[e] = wreg[i];
+            }
+            __syncthreads();
+            w_staged = true;
+        }
+        if (lane < CA && active) {
             float d = 0.f;
 #pragma unroll
             for (int o = 0; o < CO; ++o) d = fmaf(s_G[wave][o], s_W[o * CA + lane], d);
-            dsrc[(size_t)s * dsrc_stride + lane] += d;
+            dsrc[(size_t)s * dsrc_stride + lane] = d_old + d;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1021,7 +1138,7 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) {
         if (fp_source_side_ok<CA, CO>(p)) {               // the per-point layer: source-side form
             const int n_src = p->B * p->S_per_plot;
-            hipLaunchKernelGGL((fp_src_table_kernel<CA, CB, CO>), dim3(sn2_cdiv(n_src, 256)), dim3(256), 0, st, n_src,
+            hipLaunchKernelGGL((fp_src_table_kernel<CA, CB, CO>), dim3(sn2_cdiv(n_src, 64)), dim3(256), 0, st, n_src,
                                p->src_stride, p->src, p->src_a, p->src_c, p->blk.W, p->src_ws);
             const long n_grp = sn2_cdiv(R, 64 / ((CO + 3) / 4));
             int grid = sn2_cdiv(n_grp, 8);
@@ -1044,20 +1161,35 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
 }
 
-// the inverted index of a 3-NN table (kernels A-C above); workspace carve (32-bit words):
-// H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp]
-int build_interp_index(const int* knn_idx, const float* knn_w, int B, int Rp, int S, float* ws, hipStream_t st) {
+// the inverted index of a 3-NN table (kernels A-C, E above); workspace carve (32-bit words):
+// H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp] | (16-byte aligned) items [B*S] int4
+struct InterpIndex {
+    int *H, *off, *cnt, *inv_row;
+    int4* items;
+    float* inv_w;
+};
+InterpIndex carve_interp_index(float* ws, int B, int Rp, int S) {
+    const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
+    InterpIndex x;
+    x.H = reinterpret_cast<int*>(ws);
+    x.off = x.H + (size_t)B * SL * S;
+    x.cnt = x.off + (size_t)B * S;
+    x.inv_row = x.cnt + (size_t)B * S;
+    x.inv_w = reinterpret_cast<float*>(x.inv_row + (size_t)3 * B * Rp);
+    x.items = reinterpret_cast<int4*>((reinterpret_cast<uintptr_t>(x.inv_w + (size_t)3 * B * Rp) + 15) & ~(uintptr_t)15);
+    return x;
+}
+int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_pos, int B, int Rp, int S, float* ws,
+                       hipStream_t st) {
     if (S > 8192) return SN2_ELIMIT;
     const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
-    int* H = reinterpret_cast<int*>(ws);
-    int* off = H + (size_t)B * SL * S;
-    int* cnt = off + (size_t)B * S;
-    int* inv_row = cnt + (size_t)B * S;
-    float* inv_w = reinterpret_cast<float*>(inv_row + (size_t)3 * B * Rp);
-    hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, H);
-    hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, H, off, cnt);
-    hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, (const int*)H,
-                       (const int*)off, inv_row, inv_w);
+    const InterpIndex x = carve_interp_index(ws, B, Rp, S);
+    hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, x.H);
+    hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, x.H, x.off, x.cnt);
+    hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, (const int*)x.H,
+                       (const int*)x.off, x.inv_row, x.inv_w);
+    hipLaunchKernelGGL(inv_order_kernel, dim3(B), dim3(1024), (size_t)((S + 3) & ~3) * 4, st,
+                       reinterpret_cast<const float4*>(src_pos), S, (const int*)x.off, (const int*)x.cnt, x.items);
     SN2_RETURN_LAUNCH();
 }
 
@@ -1103,22 +1235,23 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
         if (!small && fp_source_side_ok<CA, CO>(p) && p->dsrc && !p->dskip && p->du_scratch && p->scatter_ws) {
             const int S = p->S_per_plot, Rp = p->R_per_plot, B = p->B, n_src = B * S;
             if (S > 8192) return SN2_ELIMIT;
-            hipLaunchKernelGGL((fp_bwd_rows_kernel<CA, CB, CO>), dim3(2 * sn2_cu_count()), dim3(256),
-                               (size_t)4 * (CB + 1) * 256 * sizeof(float), st, R, p->skip_stride, 1.0f / (float)R, p->skip,
+            constexpr int NT = 512;                       // 2 workgroups x 8 waves per CU; [4 (CB + 1)][NT] floats of LDS each
+            constexpr size_t lb1 = (size_t)4 * (CB + 1) * NT * sizeof(float);
+            auto k1 = &fp_bwd_rows_kernel<CA, CB, CO, NT>;
+            if (lb1 > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb1);
+            hipLaunchKernelGGL(k1, dim3(2 * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
                                p->blk.gamma, (const float*)p->blk.mean, (const float*)p->blk.invstd,
                                (const float*)p->blk.dgamma, (const float*)p->blk.dbeta, (const float*)p->h, p->dy,
                                p->du_scratch, p->blk.dW, p->blk.db);
-            if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, B, Rp, S, p->scatter_ws, st));
-            const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
-            int* H = reinterpret_cast<int*>(p->scatter_ws);
-            int* off = H + (size_t)B * SL * S;
-            int* cnt = off + (size_t)B * S;
-            int* inv_row = cnt + (size_t)B * S;
-            float* inv_w = reinterpret_cast<float*>(inv_row + (size_t)3 * B * Rp);
+            if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, nullptr, B, Rp, S, p->scatter_ws, st));
+            const InterpIndex x = carve_interp_index(p->scatter_ws, B, Rp, S);
+            // one source per wave (two per wave in half as many workgroups ran 30 % longer: the lists differ in length)
             int gs = sn2_cdiv(n_src, 4);
-            if (gs > 8 * sn2_cu_count()) gs = 8 * sn2_cu_count();
+            if (gs > 65536) gs = 65536;
+            gs = (gs + 7) & ~7;                           // the same number of workgroups on each of the 8 XCDs
             hipLaunchKernelGGL((fp_bwd_src_kernel<CA, CB, CO>), dim3(gs), dim3(256), 0, st, n_src, Rp, S, p->dsrc_stride,
-                               (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
+                               (const int4*)x.items, (const int*)x.inv_row, (const float*)x.inv_w,
                                (const float*)p->du_scratch, p->blk.W, p->src_ws, p->dsrc);
             using AccD = OuterAcc<CO, CA, 32>;
             constexpr size_t db3 = (size_t)AccD::LDS_FLOATS * 4 * 4;
@@ -1152,13 +1285,12 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
         if (!p->scatter_ws) return SN2_EINVAL;
         const int S = p->S_per_plot, Rp = p->R_per_plot, B = p->B;
         if (S > 8192) return SN2_ELIMIT;
-        if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, B, Rp, S, p->scatter_ws, st));
-        const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
-        int* H = reinterpret_cast<int*>(p->scatter_ws);
-        int* off = H + (size_t)B * SL * S;
-        int* cnt = off + (size_t)B * S;
-        int* inv_row = cnt + (size_t)B * S;
-        float* inv_w = reinterpret_cast<float*>(inv_row + (size_t)3 * B * Rp);
+        if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, nullptr, B, Rp, S, p->scatter_ws, st));
+        const InterpIndex x = carve_interp_index(p->scatter_ws, B, Rp, S);
+        const int* off = x.off;
+        const int* cnt = x.cnt;
+        const int* inv_row = x.inv_row;
+        const float* inv_w = x.inv_w;
         const int n_src = B * S;
         hipLaunchKernelGGL((interp_gather_kernel<CA>), dim3(sn2_cdiv(n_src, 4)), dim3(256), 0, st, n_src, Rp, S,
                            p->dsrc_stride, (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
@@ -1197,10 +1329,10 @@ int check_fp(const sn2_fp* p) {
 
 }  // namespace
 
-extern "C" int sn2_interp_index(const int* knn_idx, const float* knn_w, int B, int R_per_plot, int S_per_plot, float* ws,
-                                void* stream) {
+extern "C" int sn2_interp_index(const int* knn_idx, const float* knn_w, const float* src_pos, int B, int R_per_plot,
+                                int S_per_plot, float* ws, void* stream) {
     if (!knn_idx || !knn_w || !ws || B <= 0 || R_per_plot <= 0 || S_per_plot <= 0) return SN2_EINVAL;
-    return build_interp_index(knn_idx, knn_w, B, R_per_plot, S_per_plot, ws, (hipStream_t)stream);
+    return build_interp_index(knn_idx, knn_w, src_pos, B, R_per_plot, S_per_plot, ws, (hipStream_t)stream);
 }
 
 extern "C" int sn2_fp_forward(const sn2_fp* p, int training, void* stream) {

@@ -382,12 +382,17 @@ def sa_backward(d: SA):
 
 def interp_ws_words(B: int, R_per_plot: int, S_per_plot: int) -> int:
     """SN2_INTERP_WS_WORDS of include/strata_hip.h."""
-    return B * S_per_plot * ((R_per_plot + 2047) // 2048 + 2) + 6 * B * R_per_plot + 64
+    return B * S_per_plot * ((R_per_plot + 2047) // 2048 + 6) + 6 * B * R_per_plot + 64
 
 
-def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[torch.Tensor] = None,
+                 src_pos: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Inverted index of a 3-NN table (source -> list of (target row, normalised weight)): what the backward of the
-    interpolation gathers through.  Position-only, so it can be built in the geometry pass."""
+    interpolation gathers through.  Position-only, so it can be built in the geometry pass.  src_pos (B*S,4): the
+    source positions; given, the index also orders every plot's sources along a Morton curve (L2 locality of the
+    source-side backward)."""
+    if src_pos is not None:
+        _chk(src_pos, F32, (B * S_per_plot, 4), "src_pos")
     R = B * R_per_plot
     _chk(knn[0], I32, (R, 3), "knn_idx")
     _chk(knn[1], F32, (R, 3), "knn_w")
@@ -396,7 +401,7 @@ def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[to
         out = torch.empty(n, dtype=F32, device=knn[0].device)
     else:
         _chk(out, F32, (n,), "out index")
-    _call("sn2_interp_index", _ptr(knn[0]), _ptr(knn[1]), B, R_per_plot, S_per_plot, _ptr(out), _stream())
+    _call("sn2_interp_index", _ptr(knn[0]), _ptr(knn[1]), _ptr(src_pos), B, R_per_plot, S_per_plot, _ptr(out), _stream())
     return out
 
 

@@ -237,7 +237,7 @@ class PointNet2(nn.Module):
             ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1], dst_fps_ws=g.ws1)
             ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
             ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
-            ops.interp_index(g.knn1, B, N, M1, out=g.inv1)
+            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
             return g
         g = _Saved()
         g.B, g.N, g.M1, g.M2, g.xyz = B, N, M1, M2, xyz
@@ -255,7 +255,7 @@ class PointNet2(nn.Module):
         # the inverted 3-NN tables the backward pass gathers through: positions only, so they belong here
         g.inv3 = ops.interp_index(g.knn3, B, M2, 1)
         g.inv2 = ops.interp_index(g.knn2, B, M1, M2)
-        g.inv1 = ops.interp_index(g.knn1, B, N, M1)
+        g.inv1 = ops.interp_index(g.knn1, B, N, M1, src_pos=g.pos1_aos)
         return g
 
     def prefetch_geometry(self, cloud_data, lane: int = 0):

@@ -113,7 +113,7 @@ class PointNet2ThreeSA(PointNet2):
         ops.interp_index(g.knn4, B, M3, 1, out=g.inv4)
         ops.interp_index(g.knn3, B, M2, M3, out=g.inv3)
         ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
-        ops.interp_index(g.knn1, B, N, M1, out=g.inv1)
+        ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
         return g
 
     def _stage_positions(self, cloud_data, dev):
