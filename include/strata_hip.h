@@ -46,7 +46,13 @@ typedef struct sn2_block {
                                       partials; no initialisation needed)                                       */
     float *dW, *db, *dgamma, *dbeta; /* backward outputs, ACCUMULATED; must be ZERO on entry of the backward call
                                         (dgamma/dbeta are read back inside it)                                   */
+    int grad_replicas, grad_replica_stride; /* > 1: (dW, db) exist as grad_replicas zeroed images, image r at
+                                        + r * grad_replica_stride floats; a workgroup adds into ONE image, so that the
+                                        float atomics spread over the memory channels.  The gradient is the sum of the
+                                        images (sn2_grad_reduce).  dgamma / dbeta always have one image.  0 or 1: one. */
 } sn2_block;
+/* flat[i] += sum_{r=1..replicas-1} flat[r*stride + i], i < n: folds the images of a flat gradient vector into image 0 */
+int sn2_grad_reduce(float *flat, int n, int replicas, int stride, void *stream);
 
 /* ---- geometry -------------------------------------------------------------------------------------------- */
 
@@ -196,6 +202,7 @@ typedef struct sn2_head {
     const float *dcoverages, *dproba; /* backward in (R,4) each, either may be NULL                              */
     float *dy;                      /* backward out: d loss / d (fa*f+fc) (R,f_stride)                           */
     float *dW1, *db1, *dW2, *db2;   /* ACCUMULATED                                                               */
+    int grad_replicas, grad_replica_stride; /* images of the four gradients, as in sn2_block                            */
 } sn2_head;
 int sn2_head_forward(const sn2_head *p, void *stream);
 int sn2_head_backward(const sn2_head *p, void *stream);

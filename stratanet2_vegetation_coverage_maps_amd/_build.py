@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libstrata_hip.so")
 SOURCES = ["geometry.hip", "sa.hip", "sa_mfma.hip", "fp.hip", "project.hip", "loss.hip", "misc.hip"]
 HEADERS = ["common.h", "mlp.h", os.path.join("..", "..", "include", "strata_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("SN2_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

@@ -16,7 +16,8 @@ class Block(Structure):  # sn2_block
     _fields_ = [("cin", c_int), ("cout", c_int), ("W", c_void_p), ("b", c_void_p), ("gamma", c_void_p),
                 ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("a", c_void_p),
                 ("c", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("stat_slots", c_void_p),
-                ("dW", c_void_p), ("db", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
+                ("dW", c_void_p), ("db", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
+                ("grad_replicas", c_int), ("grad_replica_stride", c_int)]
 
 
 class SA(Structure):  # sn2_sa
@@ -40,7 +41,8 @@ class Head(Structure):  # sn2_head
     _fields_ = [("R", c_int), ("cin", c_int), ("f_stride", c_int), ("f", c_void_p), ("fa", c_void_p),
                 ("fc", c_void_p), ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
                 ("coverages", c_void_p), ("proba", c_void_p), ("dcoverages", c_void_p), ("dproba", c_void_p),
-                ("dy", c_void_p), ("dW1", c_void_p), ("db1", c_void_p), ("dW2", c_void_p), ("db2", c_void_p)]
+                ("dy", c_void_p), ("dW1", c_void_p), ("db1", c_void_p), ("dW2", c_void_p), ("db2", c_void_p),
+                ("grad_replicas", c_int), ("grad_replica_stride", c_int)]
 
 
 # name -> argtypes; every entry point returns int (0 ok, >0 hipError_t, <0 argument error)
@@ -58,6 +60,7 @@ SIGNATURES = {
     "sn2_sa_order": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sn2_sa_forward": [POINTER(SA), c_int, c_void_p],
     "sn2_sa_backward": [POINTER(SA), c_void_p],
+    "sn2_grad_reduce": [c_void_p, c_int, c_int, c_int, c_void_p],
     "sn2_interp_index": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_fp_forward": [POINTER(FP), c_int, c_void_p],
     "sn2_fp_backward": [POINTER(FP), c_void_p],

@@ -19,6 +19,22 @@
         if (r__ != 0) return r__;    \
     } while (0)
 
+// every gradient sum that leaves a kernel through a global float atomic goes through this macro (one place to count them)
+#ifdef SN2_NO_FLUSH   /* timing experiments only: the adds are kept alive but never executed */
+#define SN2_FLUSH_ADD(ptr, v) do { if ((v) == 12345.678f) atomicAdd((ptr), (v)); } while (0)
+#else
+#define SN2_FLUSH_ADD(ptr, v) atomicAdd((ptr), (v))
+#endif
+
+// sn2_block.grad_replicas images of (dW, db), grad_replica_stride floats apart: a workgroup adds into image
+// blockIdx.x % replicas.  Thousands of workgroups adding the same few KB serialise at the memory-side atomic units (the
+// float atomics run at full rate only when spread over many channels): 100 us per training step went into these tails.
+#ifdef __HIPCC__
+__device__ __forceinline__ int sn2_grad_image(int replicas, int stride) {
+    return replicas > 1 ? (int)(blockIdx.x % (unsigned)replicas) * stride : 0;
+}
+#endif
+
 static inline int sn2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // compute units of the current device (256 on MI355X), for the grids of the persistent kernels

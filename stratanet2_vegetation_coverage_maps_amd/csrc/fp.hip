@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
     const float* __restrict__ invstdg, const float* __restrict__ dgammag, const float* __restrict__ dbetag,
     const float* __restrict__ h, const float* __restrict__ dy, float* __restrict__ dW, float* __restrict__ db,
     float* __restrict__ du_out /* KNN: (R,CA) scratch; else ACCUMULATED rows (R,du_stride) */,
-    float* __restrict__ dskip) {
+    float* __restrict__ dskip, int rep_k, int rep_stride) {
     constexpr int CI = CA + CB;
     using Acc = OuterAcc<CO, CI + 1, 32>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -298,9 +298,9 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
     for (int i = threadIdx.x; i < CO * (CI + 1); i += WAVES * 64) {
         const float v = red[i];
         if (v == 0.f) continue;
-        const int o = i / (CI + 1), k = i - o * (CI + 1);
-        if (k < CI) atomicAdd(&dW[o * CI + k], v);
-        else atomicAdd(&db[o], v);
+        const int o = i / (CI + 1), k = i - o * (CI + 1), img = sn2_grad_image(rep_k, rep_stride);
+        if (k < CI) SN2_FLUSH_ADD(&dW[img + o * CI + k], v);
+        else SN2_FLUSH_ADD(&db[img + o], v);
     }
 }
 
@@ -676,7 +676,8 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
                                                           const float* __restrict__ invstdg, const float* __restrict__ dgammag,
                                                           const float* __restrict__ dbetag, const float* __restrict__ h,
                                                           const float* __restrict__ dy, float* __restrict__ dp_out,
-                                                          float* __restrict__ dW, float* __restrict__ db) {
+                                                          float* __restrict__ dW, float* __restrict__ db, int rep_k,
+                                                          int rep_stride) {
     constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 2, NV = 4 * (CB + 1);
     static_assert(CB > 0 && CB % 4 == 0, "skip quads");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [NV][NT]
@@ -754,7 +755,8 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
         float acc = 0.f;
         for (int w = 0; w < NT / 64; ++w)
             for (int gg = 0; gg < G; ++gg) acc += smem[(ot * (CB + 1) + k) * NT + w * 64 + oq + QH * gg];
-        if (acc != 0.f) atomicAdd(k < CB ? &dW[o * CI + CA + k] : &db[o], acc);
+        const int img = sn2_grad_image(rep_k, rep_stride);
+        if (acc != 0.f) SN2_FLUSH_ADD(k < CB ? &dW[img + o * CI + CA + k] : &db[img + o], acc);
     }
     (void)NV;
 }
@@ -855,7 +857,8 @@ __global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_pl
 template <int CA, int CB, int CO>
 __global__ __launch_bounds__(256) void fp_bwd_src_dw_kernel(int n_src, int src_stride, const float* __restrict__ src,
                                                             const float* __restrict__ src_a, const float* __restrict__ src_c,
-                                                            const float* __restrict__ Gin, float* __restrict__ dW) {
+                                                            const float* __restrict__ Gin, float* __restrict__ dW,
+                                                            int rep_k, int rep_stride) {
     constexpr int CI = CA + CB, HS = 4 * ((CO + 3) / 4);
     using Acc = OuterAcc<CO, CA, 32>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(256) void fp_bwd_src_dw_kernel(int n_src, int src_s
     __syncthreads();
     for (int i = threadIdx.x; i < CO * CA; i += 256) {
         const float v = red[i];
-        if (v != 0.f) atomicAdd(&dW[(i / CA) * CI + (i % CA)], v);
+        if (v != 0.f) SN2_FLUSH_ADD(&dW[sn2_grad_image(rep_k, rep_stride) + (i / CA) * CI + (i % CA)], v);
     }
 }
 
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
     const float* __restrict__ h, const float* __restrict__ dy, float* __restrict__ dW, float* __restrict__ db,
-    float* __restrict__ du_out, float* __restrict__ dskip) {
+    float* __restrict__ du_out, float* __restrict__ dskip, int rep_k, int rep_stride) {
     constexpr int CI = CA + CB, COG = (CO + 3) / 4;
     using Acc = OuterAcc<16, CI + 1>;
     constexpr int QS = Acc::QS, TK = Acc::TK, CIP = CI | 1;
@@ -1094,15 +1097,15 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
         }
     }
     {
-        const int r4 = lane >> 4, c16 = lane & 15;
+        const int r4 = lane >> 4, c16 = lane & 15, img = sn2_grad_image(rep_k, rep_stride);
 #pragma unroll
         for (int c = 0; c < TK; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int t = r4 * 4 + q, o = g * COG + t, k = c * 16 + c16;
                 if (t < COG && o < CO) {
-                    if (k < CI) atomicAdd(&dW[o * CI + k], acc[c][q]);
-                    else if (k == CI) atomicAdd(&db[o], acc[c][q]);
+                    if (k < CI) SN2_FLUSH_ADD(&dW[img + o * CI + k], acc[c][q]);
+                    else if (k == CI) SN2_FLUSH_ADD(&db[img + o], acc[c][q]);
                 }
             }
     }
@@ -1227,7 +1230,8 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
                            p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src,
                            p->src_a, p->src_c, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma,
                            (const float*)p->blk.mean, (const float*)p->blk.invstd, (const float*)p->blk.dgamma,
-                           (const float*)p->blk.dbeta, (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out0, p->dskip);
+                           (const float*)p->blk.dbeta, (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out0, p->dskip,
+                           p->blk.grad_replicas, p->blk.grad_replica_stride);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
@@ -1243,7 +1247,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             hipLaunchKernelGGL(k1, dim3(2 * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
                                p->blk.gamma, (const float*)p->blk.mean, (const float*)p->blk.invstd,
                                (const float*)p->blk.dgamma, (const float*)p->blk.dbeta, (const float*)p->h, p->dy,
-                               p->du_scratch, p->blk.dW, p->blk.db);
+                               p->du_scratch, p->blk.dW, p->blk.db, p->blk.grad_replicas, p->blk.grad_replica_stride);
             if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, nullptr, B, Rp, S, p->scatter_ws, st));
             const InterpIndex x = carve_interp_index(p->scatter_ws, B, Rp, S);
             // one source per wave (two per wave in half as many workgroups ran 30 % longer: the lists differ in length)
@@ -1260,7 +1264,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             if (db3 > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)db3);
             hipLaunchKernelGGL(k3, dim3(sn2_cdiv(n_src, 256)), dim3(256), db3, st, n_src, p->src_stride, p->src, p->src_a,
-                               p->src_c, (const float*)p->src_ws, p->blk.dW);
+                               p->src_c, (const float*)p->src_ws, p->blk.dW, p->blk.grad_replicas, p->blk.grad_replica_stride);
             SN2_RETURN_LAUNCH();
         }
     }
@@ -1278,7 +1282,8 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
                        p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src, p->src_a, p->src_c,
                        p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma, (const float*)p->blk.mean,
                        (const float*)p->blk.invstd, (const float*)p->blk.dgamma, (const float*)p->blk.dbeta,
-                       (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out, p->dskip);
+                       (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out, p->dskip, p->blk.grad_replicas,
+                       p->blk.grad_replica_stride);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (KNN && p->dsrc) {
@@ -1419,7 +1424,7 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
                                                        const float* __restrict__ dcov, const float* __restrict__ dproba,
                                                        float* __restrict__ dy, float* __restrict__ dW1,
                                                        float* __restrict__ db1, float* __restrict__ dW2,
-                                                       float* __restrict__ db2) {
+                                                       float* __restrict__ db2, int rep_k, int rep_stride) {
     using Acc2 = OuterAcc<16, 17, 32>;  // rows 0..4 = d scores, rest zero;  Q = [z1 | 1]
     using Acc1 = OuterAcc<16, 35, 32>;  // d pre-activation of lin1;          Q = [y | 1]
     // 16 waves per workgroup (4 per SIMD: the row loads are 144-byte strided, only occupancy hides them); the two
@@ -1503,12 +1508,13 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
     for (int i = threadIdx.x; i < N2 + N1; i += HEAD_BWD_THREADS) {
         const float v = red[i];
         if (v == 0.f) continue;
+        const int img = sn2_grad_image(rep_k, rep_stride);
         if (i < N2) {
             const int o = i / 17, k = i - o * 17;
-            if (o < 5) atomicAdd(k < 16 ? &dW2[o * 16 + k] : &db2[o], v);
+            if (o < 5) SN2_FLUSH_ADD(k < 16 ? &dW2[img + o * 16 + k] : &db2[img + o], v);
         } else {
             const int j = i - N2, o = j / 35, k = j - o * 35;
-            atomicAdd(k < 34 ? &dW1[o * 34 + k] : &db1[o], v);
+            SN2_FLUSH_ADD(k < 34 ? &dW1[img + o * 34 + k] : &db1[img + o], v);
         }
     }
 }
@@ -1527,7 +1533,8 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
 __global__ void bn_sums_from_consumer_kernel(int C, int cout, int cin, int col0, const float* __restrict__ W,
                                              const float* __restrict__ dW, const float* __restrict__ db,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok) {
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok,
+                                             int rep_k, int rep_stride) {
     __shared__ int s_ok;
     const int o = threadIdx.x;
     if (o == 0) s_ok = 1;
@@ -1538,10 +1545,16 @@ __global__ void bn_sums_from_consumer_kernel(int C, int cout, int cin, int col0,
     if (o >= C || !s_ok) return;
     double sb = 0.0, sg = 0.0;
     const double g = (double)gamma[o], b = (double)beta[o];
+    const int images = rep_k > 1 ? rep_k : 1;                   // the consumer's (dW, db) images are summed on the fly
     for (int j = 0; j < cout; ++j) {
         const double w = (double)W[j * cin + col0 + o];
-        sb += w * (double)db[j];
-        sg += w * ((double)dW[j * cin + col0 + o] - b * (double)db[j]);
+        float dbj = 0.f, dwj = 0.f;
+        for (int r = 0; r < images; ++r) {
+            dbj += db[(size_t)r * rep_stride + j];
+            dwj += dW[(size_t)r * rep_stride + j * cin + col0 + o];
+        }
+        sb += w * (double)dbj;
+        sg += w * ((double)dwj - b * (double)dbj);
     }
     dbeta[o] += (float)sb;
     dgamma[o] += (float)(sg / g);
@@ -1568,7 +1581,8 @@ extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const flo
     SN2_TRY(check_head(p));
     if (!p->dW1 || !p->db1 || !gamma || !beta || !dgamma || !dbeta || !ok) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->cin, 16, p->cin, 0, p->W1,
-                       (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta, ok);
+                       (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta, ok, p->grad_replicas,
+                       p->grad_replica_stride);
     SN2_RETURN_LAUNCH();
 }
 
@@ -1577,7 +1591,8 @@ extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* 
     SN2_TRY(check_fp(p));
     if (!p->knn_idx || !p->blk.dW || !p->blk.db || !gamma || !beta || !dgamma || !dbeta || !ok || p->ca > 64) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p->ca, p->blk.cout, p->blk.cin, 0,
-                       (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta, ok);
+                       (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta, ok,
+                       p->blk.grad_replicas, p->blk.grad_replica_stride);
     SN2_RETURN_LAUNCH();
 }
 
@@ -1592,6 +1607,6 @@ extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
                        p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
-                       p->db2);
+                       p->db2, p->grad_replicas, p->grad_replica_stride);
     SN2_RETURN_LAUNCH();
 }

@@ -260,3 +260,29 @@ extern "C" int sn2_prepare_plots(const float* raw, long T, const int* offsets, c
 }
 
 extern "C" int sn2_version(void) { return SN2_VERSION; }
+
+
+// ---- images of a flat gradient vector -> image 0 (sn2_block.grad_replicas) ---------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void grad_reduce_kernel(float* __restrict__ flat, int n, int replicas, int stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 1;
+    for (; r + 4 <= replicas; r += 4) {                   // four independent loads in flight
+        s0 += flat[(size_t)r * stride + i];
+        s1 += flat[(size_t)(r + 1) * stride + i];
+        s2 += flat[(size_t)(r + 2) * stride + i];
+        s3 += flat[(size_t)(r + 3) * stride + i];
+    }
+    for (; r < replicas; ++r) s0 += flat[(size_t)r * stride + i];
+    flat[i] += (s0 + s1) + (s2 + s3);
+}
+}  // namespace
+
+extern "C" int sn2_grad_reduce(float* flat, int n, int replicas, int stride, void* stream) {
+    if (!flat || n <= 0 || replicas < 1 || (replicas > 1 && stride < n)) return SN2_EINVAL;
+    if (replicas == 1) return 0;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(sn2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, flat, n, replicas, stride);
+    SN2_RETURN_LAUNCH();
+}

@@ -329,6 +329,7 @@ struct SaBwdArgs {
     const float* dout;
     const int* arg;
     float *dW0, *db0, *dW1, *db1, *dgamma0_out, *dbeta0_out;   // accumulated (atomics)
+    int rep_k, rep_stride;                                     // images of (dW, db): sn2_block.grad_replicas
     float* dfeat;
 };
 
@@ -696,23 +697,24 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
             }
     }
     __syncthreads();
+    const int img = sn2_grad_image(a.rep_k, a.rep_stride);
     for (int i = threadIdx.x; i < NW + NB + NG; i += 256) {
         const float v = red[i];
         if (v == 0.f) continue;
         if (i < NW) {
             if constexpr (LAST2) {
-                atomicAdd(&a.dW1[i], v);
+                SN2_FLUSH_ADD(&a.dW1[img + i], v);
             } else {
                 const int o = i / QK, k = i - o * QK;   // block 0: columns = inputs | bias
-                if (k < CIN) atomicAdd(&a.dW0[o * CIN + k], v);
-                else atomicAdd(&a.db0[o], v);
+                if (k < CIN) SN2_FLUSH_ADD(&a.dW0[img + o * CIN + k], v);
+                else SN2_FLUSH_ADD(&a.db0[img + o], v);
             }
         } else if (i < NW + NB) {
-            atomicAdd(&a.db1[i - NW], v);
+            SN2_FLUSH_ADD(&a.db1[img + i - NW], v);
         } else if (i < NW + NB + C1) {
-            atomicAdd(&a.dbeta0_out[i - NW - NB], v);
+            SN2_FLUSH_ADD(&a.dbeta0_out[i - NW - NB], v);
         } else {
-            atomicAdd(&a.dgamma0_out[i - NW - NB - C1], v);
+            SN2_FLUSH_ADD(&a.dgamma0_out[i - NW - NB - C1], v);
         }
     }
 }
@@ -759,6 +761,7 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
     a.dbeta1 = k1.dbeta;
     a.dout = p->dout; a.arg = p->arg;
     a.dW0 = k0.dW; a.db0 = k0.db; a.dW1 = k1.dW; a.db1 = k1.db; a.dgamma0_out = k0.dgamma; a.dbeta0_out = k0.dbeta;
+    a.rep_k = k0.grad_replicas; a.rep_stride = k0.grad_replica_stride;
     a.dfeat = p->dfeat;
     int blocks = sn2_cdiv((long)p->B * p->M, 16);
     if (blocks > 512) blocks = 512;

@@ -246,6 +246,7 @@ class BlockBuffers:
         _chk(self.aux, F32, (4, self.cout), "aux")
         _chk(self.stats, F32, (_lib.STAT_SLOTS * 2 * self.cout,), "stat_slots")
         self.grads = None                                                 # (dW, db, dgamma, dbeta) views, set per backward
+        self.grad_images = (1, 0)                                         # (replicas, stride in floats) of dW / db
 
     def fill(self, blk: Block, with_grads: bool = False):
         for t, n in ((self.lin.weight, "weight"), (self.lin.bias, "bias"), (self.bn.weight, "bn.weight"),
@@ -263,8 +264,10 @@ class BlockBuffers:
             for t, ref in ((dW, self.lin.weight), (db, self.lin.bias), (dg, self.bn.weight), (dbeta, self.bn.bias)):
                 _chk(t, F32, ref.shape, "grad view")
             blk.dW, blk.db, blk.dgamma, blk.dbeta = _ptr(dW), _ptr(db), _ptr(dg), _ptr(dbeta)
+            blk.grad_replicas, blk.grad_replica_stride = self.grad_images
         else:
             blk.dW = blk.db = blk.dgamma = blk.dbeta = None
+            blk.grad_replicas, blk.grad_replica_stride = 1, 0
 
     @property
     def a(self):
@@ -508,7 +511,8 @@ def plot_max_backward(dout, arg, B, R_per_plot, C, dy):
     _call("sn2_plot_max_backward", _ptr(dout), _ptr(arg), B, R_per_plot, C, _ptr(dy), _stream())
 
 
-def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dproba=None, dy=None, grads=None) -> Head:
+def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dproba=None, dy=None, grads=None,
+              grad_images=(1, 0)) -> Head:
     R = f.shape[0]
     _chk(f, F32, (R, 36), "f")
     _chk(fa, F32, (34,), "fa")
@@ -532,9 +536,31 @@ def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dpro
         for t, ref in zip(grads, (lin1.weight, lin1.bias, lin2.weight, lin2.bias)):
             _chk(t, F32, ref.shape, "head grad view")
         d.dW1, d.db1, d.dW2, d.db2 = (_ptr(t) for t in grads)
+        d.grad_replicas, d.grad_replica_stride = grad_images
     else:
         d.dW1 = d.db1 = d.dW2 = d.db2 = None
+        d.grad_replicas, d.grad_replica_stride = 1, 0
     return d
+
+
+GRAD_IMAGES = 32       # images of the flat parameter gradient the backward kernels spread their atomics over
+
+
+def grad_images_alloc(n_flat: int, device, extra_words: int = 0):
+    """One zero-filled arena: GRAD_IMAGES images of the flat gradient (image stride = n_flat rounded up to 64 floats)
+    followed by `extra_words` floats.  Returns (arena, image 0 view (n_flat), (replicas, stride), extra view)."""
+    stride = (n_flat + 63) // 64 * 64
+    arena = torch.zeros(GRAD_IMAGES * stride + extra_words, dtype=F32, device=device)
+    return arena, arena[:n_flat], (GRAD_IMAGES, stride), arena[GRAD_IMAGES * stride:]
+
+
+def grad_reduce(arena, n_flat: int, images):
+    """include/strata_hip.h: sn2_grad_reduce -- fold the images into image 0 (arena[:n_flat])."""
+    replicas, stride = images
+    _chk(arena, F32, None, "arena")
+    if arena.numel() < replicas * stride:
+        raise ValueError("grad_reduce: arena smaller than its images")
+    _call("sn2_grad_reduce", _ptr(arena), n_flat, replicas, stride, _stream())
 
 
 def head_forward(d: Head):

@@ -387,24 +387,14 @@ class PointNet2(nn.Module):
         dev = s.xyz.device
         B, N, M1, M2 = s.B, s.N, s.M1, s.M2
         params = list(self.parameters())
-        n_flat = sum(p.numel() for p in params)
         # one zero-filled arena: flat parameter gradient + every accumulate-into buffer of the backward chain
-        sizes = OrderedDict(flat=n_flat, dy2=B * M1 * 36, dy3=B * M2 * 64, dx1=B * M1 * 16, dx2=B * M2 * 32,
-                            dx3=B * 64, dy_sa3=B * M2 * 64)
-        offs, tot = {}, 0
-        for k, n in sizes.items():
-            offs[k] = tot
-            tot += (n + 3) // 4 * 4
-        arena = torch.zeros(tot, dtype=F32, device=dev)
-        buf = {k: arena[offs[k]:offs[k] + n] for k, n in sizes.items()}
-        flat = buf["flat"]
-        views, o = {}, 0
-        for p in params:
-            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
-            o += p.numel()
+        sizes = OrderedDict(dy2=B * M1 * 36, dy3=B * M2 * 64, dx1=B * M1 * 16, dx2=B * M2 * 32, dx3=B * 64,
+                            dy_sa3=B * M2 * 64)
+        flat, buf, views, images, arena = self._grad_arena(params, sizes, dev)
 
         def attach(bb):
             bb.grads = (views[id(bb.lin.weight)], views[id(bb.lin.bias)], views[id(bb.bn.weight)], views[id(bb.bn.bias)])
+            bb.grad_images = images
 
         for bb in s.b_sa1 + s.b_sa2 + [s.b_sa3, s.b_fp3, s.b_fp2, s.b_fp1]:
             attach(bb)
@@ -413,7 +403,8 @@ class PointNet2(nn.Module):
         # head
         dy1 = torch.empty(B * N, 36, dtype=F32, device=dev)
         hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
-        hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg)
+        hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg,
+                           grad_images=images)
         ops.head_backward(hd)
         # FP1's BatchNorm gradients fall out of lin1's (hip_ops.head_bn_sums): no extra pass over the B*N rows
         bn1 = self.fp1_module.nn[0][2]
@@ -445,9 +436,28 @@ class PointNet2(nn.Module):
         # SA2 -> d x1 ; SA1
         ops.sa_backward(self._sa2_desc(s, dout=dx2, dfeat=dx1, g=True))
         ops.sa_backward(self._sa1_desc(s, dout=dx1, g=True))
+        ops.grad_reduce(arena, flat.numel(), images)      # the images of (dW, db) -> image 0 = `flat`
         s.flat_grad = flat
         self._last_flat_grad = flat
         return [views[id(p)] for p in params]
+
+    @staticmethod
+    def _grad_arena(params, sizes, dev):
+        """One zero-filled arena per backward: the images of the flat parameter gradient (hip_ops.grad_images_alloc) and
+        every accumulate-into buffer of the backward chain.  -> (flat = image 0, buffers, per-parameter views of image
+        0, (replicas, stride), arena)."""
+        n_flat = sum(p.numel() for p in params)
+        offs, tot = {}, 0
+        for k, n in sizes.items():
+            offs[k] = tot
+            tot += (n + 3) // 4 * 4
+        arena, flat, images, extra = ops.grad_images_alloc(n_flat, dev, tot)
+        buf = {k: extra[offs[k]:offs[k] + n] for k, n in sizes.items()}
+        views, o = {}, 0
+        for p in params:
+            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        return flat, buf, views, images, arena
 
     # ------------------------------------------------------------------------------------------ layout helpers
     @staticmethod

@@ -199,28 +199,19 @@ class PointNet2ThreeSA(PointNet2):
         dev = s.xyz.device
         B, N, M1, M2, M3 = s.B, s.N, s.M1, s.M2, s.M3
         params = list(self.parameters())
-        n_flat = sum(p.numel() for p in params)
-        sizes = OrderedDict(flat=n_flat, dy2=B * M1 * 36, dy3=B * M2 * 64, dy4=B * M3 * 64, dx1=B * M1 * 16, dx2=B * M2 * 32,
+        sizes = OrderedDict(dy2=B * M1 * 36, dy3=B * M2 * 64, dy4=B * M3 * 64, dx1=B * M1 * 16, dx2=B * M2 * 32,
                             dx3=B * M3 * 64, dxg=B * 64, dy_sa4=B * M3 * 64)
-        offs, tot = {}, 0
-        for k, n in sizes.items():
-            offs[k] = tot
-            tot += (n + 3) // 4 * 4
-        arena = torch.zeros(tot, dtype=F32, device=dev)
-        buf = {k: arena[offs[k]:offs[k] + n] for k, n in sizes.items()}
-        flat = buf["flat"]
-        views, o = {}, 0
-        for p in params:
-            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
-            o += p.numel()
+        flat, buf, views, images, arena = self._grad_arena(params, sizes, dev)
         for bb in s.b_sa1 + s.b_sa2 + s.b_sa3 + [s.b_sa4, s.b_fp4, s.b_fp3, s.b_fp2, s.b_fp1]:
             bb.grads = (views[id(bb.lin.weight)], views[id(bb.lin.bias)], views[id(bb.bn.weight)], views[id(bb.bn.bias)])
+            bb.grad_images = images
         dcov = None if dcov is None else dcov.contiguous()
         dproba = None if dproba is None else dproba.contiguous()
         e = lambda *shape: torch.empty(*shape, dtype=F32, device=dev)                  # noqa: E731
         dy1 = e(B * N, 36)
         hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
-        hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg)
+        hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg,
+                           grad_images=images)
         ops.head_backward(hd)
         bn_ok = torch.empty(4, dtype=I32, device=dev)
 
@@ -253,6 +244,7 @@ class PointNet2ThreeSA(PointNet2):
         ops.sa_backward(self._sa3l_desc(s, dout=dx3, dfeat=dx2, g=True))
         ops.sa_backward(self._sa2_desc(s, dout=dx2, dfeat=dx1, g=True))
         ops.sa_backward(self._sa1_desc(s, dout=dx1, g=True))
+        ops.grad_reduce(arena, flat.numel(), images)
         s.flat_grad = flat
         self._last_flat_grad = flat
         return [views[id(p)] for p in params]
