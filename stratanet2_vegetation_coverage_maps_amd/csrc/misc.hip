@@ -20,13 +20,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
     double acc = 0.0;
     if (training && g < G) {
         int k = g;
-        for (; k + 3 * G < nslots; k += 4 * G) {      // four independent loads in flight
-            const float v0 = slots[(size_t)k * W2 + col], v1 = slots[(size_t)(k + G) * W2 + col],
-                        v2 = slots[(size_t)(k + 2 * G) * W2 + col], v3 = slots[(size_t)(k + 3 * G) * W2 + col];
-            acc += (double)v0;
-            acc += (double)v1;
-            acc += (double)v2;
-            acc += (double)v3;
+        for (; k + 7 * G < nslots; k += 8 * G) {      // eight independent loads in flight, added in slot order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slots[(size_t)(k + u * G) * W2 + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
         }
         for (; k < nslots; k += G) acc += (double)slots[(size_t)k * W2 + col];
     }
@@ -91,8 +90,23 @@ __global__ __launch_bounds__(256) void plot_max_kernel(const float* __restrict__
     int bi = 0x7FFFFFFF;
     if (g < G) {
         const float aa = a[ch], cc = c[ch];
-        for (int r = g; r < R; r += G) {
-            const float v = fmaf(aa, h[((size_t)b * R + r) * hs + ch], cc);
+        const float* hb = h + (size_t)b * R * hs + ch;
+        int r = g;
+        for (; r + 7 * G < R; r += 8 * G) {          // eight independent row loads in flight (one at a time: 18 us of latency)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = hb[(size_t)(r + u * G) * hs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float y = fmaf(aa, v[u], cc);
+                if (y > best) {
+                    best = y;
+                    bi = r + u * G;
+                }
+            }
+        }
+        for (; r < R; r += G) {
+            const float v = fmaf(aa, hb[(size_t)r * hs], cc);
             if (v > best) {
                 best = v;
                 bi = r;

@@ -39,7 +39,20 @@ __global__ __launch_bounds__(1024) void plot_minmax_kernel(const float* __restri
     const float* x = xy + (size_t)b * plot_stride;
     const float* y = x + N;
     float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
-    for (int i = threadIdx.x; i < N; i += 1024) {
+    int i = threadIdx.x;
+    for (; i + 7 * 1024 < N; i += 8 * 1024) {        // sixteen independent loads in flight
+        float a[8], c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = x[i + u * 1024], c[u] = y[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            xmn = fminf(xmn, a[u]);
+            xmx = fmaxf(xmx, a[u]);
+            ymn = fminf(ymn, c[u]);
+            ymx = fmaxf(ymx, c[u]);
+        }
+    }
+    for (; i < N; i += 1024) {
         const float a = x[i], c = y[i];
         xmn = fminf(xmn, a);
         xmx = fmaxf(xmx, a);
