@@ -918,43 +918,125 @@ __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot
                                                            const float* __restrict__ skip, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ h,
                                                            float* __restrict__ slots) {
-    constexpr int CI = CA + CB, COG = (CO + 3) / 4;
-    __shared__ float s_red[2 * CO];
+    // 64 rows per workgroup.  The four waves first build the rows' inputs [u | 1] together in LDS (wave g: the channel
+    // quads q = g mod 4 of the interpolated part and of the skip part), then wave g computes the 16 output channels
+    // [16 g, 16 g + 16) of all 64 rows on the matrix cores: A[row][k] from the staged inputs, B[k][o] = W^T | bias in
+    // registers ((CI + 1)/4 values per lane).  As per-lane FMA chains with scalar-loaded weights (16 x 96 per lane for FP3,
+    // every wave rebuilding the whole input) these layers took 15-30 us each for 4-16k rows.
+    constexpr int CI = CA + CB, CK = CI + 1, KB = (CK + 3) / 4, QA = (CA + 3) / 4, NG = (CO + 15) / 16;
+    constexpr int QS = OuterAcc<16, CK>::QS;
+    static_assert(NG <= 4 && 4 * KB <= QS, "fp_fwd_split_kernel shapes");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_q = smem;                       // [64][QS]
+    float* s_red = smem + 64 * QS;           // [2 * 16 * NG]
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long r = (long)blockIdx.x * 64 + lane;
     const bool valid = r < R;
     const size_t rr = valid ? (size_t)r : (size_t)(R - 1);
-    float u[CI + 1];
-    build_input<CA, CB, KNN>(src, src_stride, as_const(src_a), as_const(src_c), knn_idx, knn_w, skip, skip_stride, rr,
-                             (rr / R_per_plot) * S_per_plot, u);
-    float* hr = h + rr * h_stride;
+    for (int i = threadIdx.x; i < 64 * QS; i += 256) s_q[i] = 0.f;
+    __syncthreads();
+    {
+        float* uq = s_q + lane * QS;
+        const cfp sa = as_const(src_a), sc = as_const(src_c);
+        if constexpr (KNN) {
+            const size_t base = (rr / R_per_plot) * S_per_plot;
+            const int i0 = knn_idx[rr * 3 + 0], i1 = knn_idx[rr * 3 + 1], i2 = knn_idx[rr * 3 + 2];
+            const float w0 = knn_w[rr * 3 + 0], w1 = knn_w[rr * 3 + 1], w2 = knn_w[rr * 3 + 2];
+            const float inv = 1.0f / ((w0 + w1) + w2);
+            const float4* s0 = reinterpret_cast<const float4*>(src + (base + i0) * src_stride);
+            const float4* s1 = reinterpret_cast<const float4*>(src + (base + i1) * src_stride);
+            const float4* s2 = reinterpret_cast<const float4*>(src + (base + i2) * src_stride);
 #pragma unroll
-    for (int t = 0; t < COG; ++t) {
-        const int o = g * COG + t;
-        if (o < CO) {
-            float acc = bias[o];
+            for (int q0 = 0; q0 < QA; q0 += 4) {
+                const int q = q0 + g;
+                if (q < QA) {
+                    const float4 a = s0[q], b = s1[q], c = s2[q];
+                    float v[4] = {((a.x * w0 + b.x * w1) + c.x * w2) * inv, ((a.y * w0 + b.y * w1) + c.y * w2) * inv,
+                                  ((a.z * w0 + b.z * w1) + c.z * w2) * inv, ((a.w * w0 + b.w * w1) + c.w * w2) * inv};
 #pragma unroll
-            for (int k = 0; k < CI; ++k) acc = fmaf(W[o * CI + k], u[k], acc);
-            acc = fmaxf(acc, 0.f);
-            if (valid) hr[o] = acc;
-            if (slots) {
-                const float v = valid ? acc : 0.f;
-                const float s1 = wave_sum(v), s2 = wave_sum(v * v);
-                if (lane == 0) {
-                    s_red[o] = s1;
-                    s_red[CO + o] = s2;
+                    for (int t = 0; t < 4; ++t)
+                        if (4 * q + t < CA) uq[4 * q + t] = src_a ? fmaf(sa[4 * q + t], v[t], sc[4 * q + t]) : v[t];
+                }
+            }
+        } else {
+            const float4* s0 = reinterpret_cast<const float4*>(src + rr * src_stride);
+#pragma unroll
+            for (int q0 = 0; q0 < QA; q0 += 4) {
+                const int q = q0 + g;
+                if (q < QA) {
+                    const float4 a = s0[q];
+                    const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (4 * q + t < CA) uq[4 * q + t] = src_a ? fmaf(sa[4 * q + t], v[t], sc[4 * q + t]) : v[t];
                 }
             }
         }
-    }
-    if (g == 3 && valid) {
+        if constexpr (CB > 0 && CB % 4 == 0) {
+            const float4* sk = reinterpret_cast<const float4*>(skip + rr * skip_stride);
 #pragma unroll
-        for (int o = CO; o < ((CO + 3) & ~3); ++o) hr[o] = 0.f;
+            for (int q0 = 0; q0 < CB / 4; q0 += 4) {
+                const int q = q0 + g;
+                if (q < CB / 4) {
+                    const float4 a = sk[q];
+                    uq[CA + 4 * q + 0] = a.x, uq[CA + 4 * q + 1] = a.y, uq[CA + 4 * q + 2] = a.z, uq[CA + 4 * q + 3] = a.w;
+                }
+            }
+        } else if constexpr (CB > 0) {
+            if (g == 1) {
+#pragma unroll
+                for (int k = 0; k < CB; ++k) uq[CA + k] = skip[rr * skip_stride + k];
+            }
+        }
+        if (g == 3) uq[CI] = 1.0f;           // the bias column
+    }
+    // B operand: lane (qq, cc) keeps [W | bias][o = 16 g + cc][k = 4 kb + qq]
+    const int qq = lane >> 4, cc = lane & 15;
+    const int o = 16 * g + cc;
+    float Wb[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int k = 4 * kb + qq;
+        Wb[kb] = (g < NG && o < CO) ? (k < CI ? W[o * CI + k] : (k == CI ? bias[o] : 0.f)) : 0.f;
+    }
+    __syncthreads();
+    float ssum = 0.f, ssq = 0.f;
+    if (g < NG) {
+        f32x4 D[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) D[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                D[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_q[(16 * t + cc) * QS + 4 * kb + qq], Wb[kb], D[t], 0, 0, 0);
+        }
+        // D[t][j]: row 16 t + 4 qq + j, channel o
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long row = (long)blockIdx.x * 64 + 16 * t + 4 * qq + j;
+                const float v = (row < R && o < CO) ? fmaxf(D[t][j], 0.f) : 0.f;
+                ssum += v;
+                ssq = fmaf(v, v, ssq);
+                if (row < R && o < h_stride) h[(size_t)row * h_stride + o] = v;      // pad channels: 0
+            }
+        // the four row groups (qq) of a channel
+        ssum += __shfl_xor(ssum, 16);
+        ssq += __shfl_xor(ssq, 16);
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (qq == 0) {
+            s_red[o] = ssum;
+            s_red[16 * NG + o] = ssq;
+        }
     }
     if (slots) {
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * CO; i += 256) slots[(size_t)blockIdx.x * 2 * CO + i] = s_red[i];
+        for (int i = threadIdx.x; i < 2 * CO; i += 256)
+            slots[(size_t)blockIdx.x * 2 * CO + i] = i < CO ? s_red[i] : s_red[16 * NG + (i - CO)];
     }
 }
 
@@ -1131,7 +1213,9 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     const int R = p->B * p->R_per_plot;
     if (sn2_cdiv(R, 64) <= SN2_STAT_SLOTS) {   // small layer: 64 rows x 4 channel groups per workgroup
         const int grid = sn2_cdiv(R, 64);
-        hipLaunchKernelGGL((fp_fwd_split_kernel<CA, CB, CO, KNN>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot,
+        constexpr size_t lf = (size_t)(64 * OuterAcc<16, CA + CB + 1>::QS + 2 * 16 * ((CO + 15) / 16)) * sizeof(float);
+        static_assert(lf <= 48 * 1024, "fp_fwd_split_kernel staging");
+        hipLaunchKernelGGL((fp_fwd_split_kernel<CA, CB, CO, KNN>), dim3(grid), dim3(256), lf, st, R, p->R_per_plot,
                            p->S_per_plot, p->src_stride, p->skip_stride, p->h_stride, p->src, p->src_a, p->src_c, p->knn_idx,
                            p->knn_w, p->skip, p->blk.W, p->blk.b, p->h, training ? p->blk.stat_slots : (float*)nullptr);
         hipError_t e0 = hipGetLastError();

@@ -550,7 +550,11 @@ def grad_images_alloc(n_flat: int, device, extra_words: int = 0):
     """One zero-filled arena: GRAD_IMAGES images of the flat gradient (image stride = n_flat rounded up to 64 floats)
     followed by `extra_words` floats.  Returns (arena, image 0 view (n_flat), (replicas, stride), extra view)."""
     stride = (n_flat + 63) // 64 * 64
-    arena = torch.zeros(GRAD_IMAGES * stride + extra_words, dtype=F32, device=device)
+    # zero-filled by a fill KERNEL, not torch.zeros: for a tensor this size torch.zeros is a hipMemsetAsync, and float
+    # atomics (executed at the memory side, past the L2) issued right behind that memset lost part of their sums on this
+    # part -- alternating runs of the same step disagreed by ~1 % in every dW (scripts/debug_grad_images.py)
+    arena = torch.empty(GRAD_IMAGES * stride + extra_words, dtype=F32, device=device)
+    arena.fill_(0.0)
     return arena, arena[:n_flat], (GRAD_IMAGES, stride), arena[GRAD_IMAGES * stride:]
 
 
