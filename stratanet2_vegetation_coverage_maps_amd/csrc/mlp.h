@@ -148,16 +148,28 @@ __device__ __forceinline__ void sums_to_lds(const float (&v)[C], float* red) {
 
 // BatchNorm batch statistics leave a kernel as one slot per workgroup: slot[blockIdx.x] = [sum(C) | sumsq(C)] (fp32
 // partials, every workgroup writes its slot, so no zeroing and no atomics; bn_finalize adds the slots in fp64 in a
-// fixed order => run-to-run identical statistics).  `red` = block-shared scratch of 2*C floats.
+// fixed order).  Inside the workgroup the waves' sums are added in wave order, not with LDS atomics: the statistics are
+// identical from run to run, bit for bit (an order that varies moves them by 1e-7, and now and then a pre-activation
+// next to zero changes sign with it: one ReLU mask flip was seen to move a weight gradient by 1 %).
+// `red` = block-shared scratch of (blockDim.x / 64) * 2 * C floats.
 template <int C>
 __device__ __forceinline__ void stats_to_slot(const float (&ssum)[C], const float (&ssq)[C], float* red,
                                               float* __restrict__ slots) {
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int o = 0; o < C; ++o) {
+        const float s1 = wave_sum(ssum[o]), s2 = wave_sum(ssq[o]);
+        if ((threadIdx.x & 63) == 0) {
+            red[w * 2 * C + o] = s1;
+            red[w * 2 * C + C + o] = s2;
+        }
+    }
     __syncthreads();
-    sums_to_lds<C>(ssum, red);
-    sums_to_lds<C>(ssq, red + C);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) slots[(size_t)blockIdx.x * 2 * C + i] = red[i];
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < nw; ++k) acc += red[k * 2 * C + i];
+        slots[(size_t)blockIdx.x * 2 * C + i] = acc;
+    }
 }
 
 // launcher of the BatchNorm finalisation kernel (misc.hip): from (sum, sumsq, count) or the running statistics to the

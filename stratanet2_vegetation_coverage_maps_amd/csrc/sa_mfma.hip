@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
     constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16, CS = PASS == 0 ? C1 : CL, TOS = CS / 16;
     static_assert(CF % 4 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "tile shapes");
-    __shared__ float s_red[2 * CS];
+    __shared__ float s_red[4][2 * CS];          // per wave: added in wave order => the statistics are the same on every run
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int nwaves = gridDim.x * 4;
@@ -292,7 +292,10 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
 
     // ---- batch statistics: row sums (over the 16 message lanes), then workgroup slot
     if (a.slots) {
-        for (int i = threadIdx.x; i < 2 * CS; i += 256) s_red[i] = 0.f;
+        // no float atomics here: their order varies from run to run, the BatchNorm statistics with it (1e-7), and now and
+        // then a pre-activation next to zero changes sign -- one ReLU mask flip moved a weight gradient by 1 %
+        const int wv = threadIdx.x >> 6;
+        for (int i = threadIdx.x; i < 4 * 2 * CS; i += 256) (&s_red[0][0])[i] = 0.f;
         __syncthreads();
 #pragma unroll
         for (int io = 0; io < TOS; ++io)
@@ -300,12 +303,13 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const float s1 = row_sum(ssum[io][r]), s2 = row_sum(ssq[io][r]);
                 if (c == 0) {
-                    atomicAdd(&s_red[16 * io + 4 * q + r], s1);
-                    atomicAdd(&s_red[CS + 16 * io + 4 * q + r], s2);
+                    s_red[wv][16 * io + 4 * q + r] = s1;
+                    s_red[wv][CS + 16 * io + 4 * q + r] = s2;
                 }
             }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * CS; i += 256) a.slots[(size_t)blockIdx.x * 2 * CS + i] = s_red[i];
+        for (int i = threadIdx.x; i < 2 * CS; i += 256)
+            a.slots[(size_t)blockIdx.x * 2 * CS + i] = (s_red[0][i] + s_red[1][i]) + (s_red[2][i] + s_red[3][i]);
     }
 }
 

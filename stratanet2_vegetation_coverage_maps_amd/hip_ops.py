@@ -544,6 +544,20 @@ def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dpro
 
 
 GRAD_IMAGES = 32       # images of the flat parameter gradient the backward kernels spread their atomics over
+FLAT_ALIGN = 32        # floats: every parameter starts on its own 128-byte line of the flat parameter / gradient vectors
+
+
+def flat_layout(params):
+    """Offsets of the parameters inside the flat parameter / gradient vectors, and the vectors' length.  Every parameter
+    starts on a 128-byte boundary: the gradients of one parameter are all produced the same way (float atomics, or the
+    plain read-modify-write of the BatchNorm shortcut kernels), and a cache line that mixes the two -- BatchNorm slots
+    next to a bias that later kernels add to atomically -- was seen to hand stale words to later readers (2 % errors in
+    one run out of three; scripts/debug_grad_images.py).  The padding words stay zero."""
+    offs, o = [], 0
+    for p in params:
+        offs.append(o)
+        o += (p.numel() + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+    return offs, o
 
 
 def grad_images_alloc(n_flat: int, device, extra_words: int = 0):

@@ -28,12 +28,11 @@ def allreduce_flat_grad(flat_grad: torch.Tensor, world_size: int, group=None) ->
 
 def flatten_parameters(model) -> torch.Tensor:
     params = list(model.parameters())
-    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
-    o = 0
-    for p in params:
-        n = p.numel()
-        p.data = flat[o:o + n].view(p.shape)
-        o += n
+    offs, n = ops.flat_layout(params)             # every parameter on its own 128-byte line; the padding stays zero
+    flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+    for p, o in zip(params, offs):
+        flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+        p.data = flat[o:o + p.numel()].view(p.shape)
     model._flat_params = flat
     return flat
 

@@ -446,17 +446,14 @@ class PointNet2(nn.Module):
         """One zero-filled arena per backward: the images of the flat parameter gradient (hip_ops.grad_images_alloc) and
         every accumulate-into buffer of the backward chain.  -> (flat = image 0, buffers, per-parameter views of image
         0, (replicas, stride), arena)."""
-        n_flat = sum(p.numel() for p in params)
+        poffs, n_flat = ops.flat_layout(params)
         offs, tot = {}, 0
         for k, n in sizes.items():
             offs[k] = tot
             tot += (n + 3) // 4 * 4
         arena, flat, images, extra = ops.grad_images_alloc(n_flat, dev, tot)
         buf = {k: extra[offs[k]:offs[k] + n] for k, n in sizes.items()}
-        views, o = {}, 0
-        for p in params:
-            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
-            o += p.numel()
+        views = {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, poffs)}
         return flat, buf, views, images, arena
 
     # ------------------------------------------------------------------------------------------ layout helpers

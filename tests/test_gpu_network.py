@@ -178,10 +178,9 @@ def test_flat_adam_matches_torch_adam():
         g = (torch.randn(flat.numel(), generator=gen) * 10 ** torch.randint(-6, 1, (flat.numel(),), generator=gen).float()).cuda()
         m1._last_flat_grad = g.clone()
         o1.step()
-        o = 0
-        for p in m2.parameters():
+        offs, _ = ops.flat_layout(list(m2.parameters()))            # every parameter on its own 128-byte line
+        for p, o in zip(m2.parameters(), offs):
             p.grad = g[o:o + p.numel()].view(p.shape).clone()
-            o += p.numel()
         o2.step()
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         if a.is_floating_point():

@@ -43,6 +43,17 @@ def _setup(N, B, depth):
     return model, opt, slots, feature_step
 
 
+def _assert_same_losses(got, ref):
+    """The forward pass is bit-reproducible, the backward pass adds its weight gradients with float atomics, so the two
+    loops carry weights that differ by ~1e-10 after the first update.  That is far below 1e-6 in the loss -- until a
+    pre-activation that sits next to zero lands on different sides in the two loops: one ReLU mask flip moves the next
+    losses by a few 1e-6 (seen: 4.8e-6 from step 4 on).  So: the first three steps (every slot's first use: geometry hand-
+    over, input copies, graph replays) to 1e-6, the later ones (slot reuse; a stale or late buffer there means another
+    batch's data and shows as 1e-2) to 1e-4."""
+    np.testing.assert_allclose(got[:3], ref[:3], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("use_graph,split", [(False, False), (True, False), (True, True)])
 def test_pipeline_matches_plain_loop(use_graph, split):
     N, B, depth, steps = 4096, 2, 2, 7
@@ -68,12 +79,15 @@ def test_pipeline_matches_plain_loop(use_graph, split):
         got.append(float(pipe.step().detach()))
     pipe.drain()
     torch.cuda.synchronize()
-    # same kernels on the same data; only the order of a few fp32 atomic adds (dW flushes) may differ.  Losses: 1e-6;
-    # parameters 1e-4 (with Adam's default eps a near-zero gradient's rounding noise moved 66 of 14 997 weights by 3.4e-5
+    # same kernels on the same data; only the order of a few fp32 atomic adds (dW flushes) may differ.  Losses: see
+    # _assert_same_losses; parameters 1e-4 (with Adam's default eps a near-zero gradient's rounding noise moved 66 of 14 997 weights by 3.4e-5
     # in 7 steps; see _setup).
-    np.testing.assert_allclose(got, ref_losses, rtol=0, atol=1e-6)
-    np.testing.assert_allclose(model2._flat_params.cpu().numpy(), ref_params.cpu().numpy(), rtol=0, atol=1e-4)
-    np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(), ref_rm.cpu().numpy(), atol=1e-6)
+    _assert_same_losses(got, ref_losses)
+    # parameters: a missed, doubled or misordered update would move EVERY weight by a fraction of lr = 1e-3; a ReLU mask
+    # flip (see _assert_same_losses) moves ~5 % of them by up to ~3e-4
+    dp = np.abs(model2._flat_params.cpu().numpy() - ref_params.cpu().numpy())
+    assert dp.max() < 2e-3 and (dp < 1e-5).mean() > 0.9, (dp.max(), (dp < 1e-5).mean())
+    np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(), ref_rm.cpu().numpy(), atol=5e-4)   # one update more or less: 1e-2
 
 
 def test_pipeline_with_host_feeder_matches_resident_inputs():
@@ -105,4 +119,4 @@ def test_pipeline_with_host_feeder_matches_resident_inputs():
     got = [float(pipe2.step().detach()) for _ in range(steps)]
     pipe2.drain()
     torch.cuda.synchronize()
-    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    _assert_same_losses(got, ref)
