@@ -1,7 +1,9 @@
 """Run-to-run agreement of the parameter gradients: ten backward passes of the same small batch with the same weights
-(no optimiser step); everything should agree to the order of the float atomics (~1e-7 relative).  Written when the
-gradient images were zeroed with torch.zeros (a hipMemsetAsync for a tensor that size) and alternating passes disagreed by
-~1 %: `python scripts/debug_grad_images.py 32 zeros` brings that back, `... 32` is the shipped fill-kernel path."""
+(no optimiser step).  With a bit-reproducible forward pass (scripts/debug_forward_determinism.py) everything agrees to
+the order of the float atomics of the weight-gradient flushes (~1e-6 relative on the smallest gradients).  Written when one
+pass in four disagreed by 1-2 %: the SA batch statistics were added with LDS float atomics, moved by 1e-7 from run to run,
+and a pre-activation next to zero changed sign with them (one ReLU mask flip).
+    python scripts/debug_grad_images.py [number of gradient images, default hip_ops.GRAD_IMAGES]"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -14,26 +16,6 @@ N, B = 4096, 2
 if len(sys.argv) > 1:
     ops.GRAD_IMAGES = int(sys.argv[1])
 print("GRAD_IMAGES", ops.GRAD_IMAGES)
-mode = sys.argv[2] if len(sys.argv) > 2 else ""
-if mode == "zeros":
-    def alloc(n_flat, device, extra_words=0):
-        stride = (n_flat + 63) // 64 * 64
-        arena = torch.zeros(ops.GRAD_IMAGES * stride + extra_words, dtype=torch.float32, device=device)
-        return arena, arena[:n_flat], (ops.GRAD_IMAGES, stride), arena[ops.GRAD_IMAGES * stride:]
-    ops.grad_images_alloc = alloc
-    print("arena from torch.zeros")
-if mode.startswith("sync_after:") or mode.startswith("sync_before:"):
-    when, name = mode.split(":")
-    f = getattr(ops, name)
-    def wrapped(*a, _f=f, **k):
-        if when == "sync_before":
-            torch.cuda.synchronize()
-        r = _f(*a, **k)
-        if when == "sync_after":
-            torch.cuda.synchronize()
-        return r
-    setattr(ops, name, wrapped)
-    print(mode)
 args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
 model = PointNet2(args)
 model.load_state_dict(network.init_state_dict(5))

@@ -1618,10 +1618,8 @@ __global__ __launch_bounds__(1024) void bn_sums_from_consumer_kernel(
     int C, int cout, int cin, int col0, const float* __restrict__ W, const float* __restrict__ dW,
     const float* __restrict__ db, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok, int rep_k, int rep_stride) {
-    // ONE workgroup: thread = (channel o of the BatchNorm, one of 16 slices of the (consumer row j, gradient image r)
-    // pairs); consecutive lanes read consecutive words of dW.  (One workgroup per channel was tried: its plain
-    // read-modify-writes of dgamma / dbeta then come from up to eight XCDs into cache lines that also hold words other
-    // kernels update with float atomics, and one run in three the next kernels saw gradients that were off by 2 %.)
+    // one workgroup: thread = (channel o of the BatchNorm, one of 16 slices of the (consumer row j, gradient image r)
+    // pairs); consecutive lanes read consecutive words of dW; fp64 partials added in slice order
     __shared__ int s_ok;
     __shared__ double s_red[2][16][64];
     const int o = threadIdx.x & 63, part = threadIdx.x >> 6;

@@ -544,19 +544,15 @@ def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dpro
 
 
 GRAD_IMAGES = 32       # images of the flat parameter gradient the backward kernels spread their atomics over
-FLAT_ALIGN = 32        # floats: every parameter starts on its own 128-byte line of the flat parameter / gradient vectors
 
 
 def flat_layout(params):
-    """Offsets of the parameters inside the flat parameter / gradient vectors, and the vectors' length.  Every parameter
-    starts on a 128-byte boundary: the gradients of one parameter are all produced the same way (float atomics, or the
-    plain read-modify-write of the BatchNorm shortcut kernels), and a cache line that mixes the two -- BatchNorm slots
-    next to a bias that later kernels add to atomically -- was seen to hand stale words to later readers (2 % errors in
-    one run out of three; scripts/debug_grad_images.py).  The padding words stay zero."""
+    """Offsets of the parameters inside the flat parameter / gradient vectors (back to back, in model.parameters() order)
+    and the vectors' length."""
     offs, o = [], 0
     for p in params:
         offs.append(o)
-        o += (p.numel() + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+        o += p.numel()
     return offs, o
 
 
@@ -564,11 +560,7 @@ def grad_images_alloc(n_flat: int, device, extra_words: int = 0):
     """One zero-filled arena: GRAD_IMAGES images of the flat gradient (image stride = n_flat rounded up to 64 floats)
     followed by `extra_words` floats.  Returns (arena, image 0 view (n_flat), (replicas, stride), extra view)."""
     stride = (n_flat + 63) // 64 * 64
-    # zero-filled by a fill KERNEL, not torch.zeros: for a tensor this size torch.zeros is a hipMemsetAsync, and float
-    # atomics (executed at the memory side, past the L2) issued right behind that memset lost part of their sums on this
-    # part -- alternating runs of the same step disagreed by ~1 % in every dW (scripts/debug_grad_images.py)
-    arena = torch.empty(GRAD_IMAGES * stride + extra_words, dtype=F32, device=device)
-    arena.fill_(0.0)
+    arena = torch.zeros(GRAD_IMAGES * stride + extra_words, dtype=F32, device=device)
     return arena, arena[:n_flat], (GRAD_IMAGES, stride), arena[GRAD_IMAGES * stride:]
 
 

@@ -28,7 +28,7 @@ def allreduce_flat_grad(flat_grad: torch.Tensor, world_size: int, group=None) ->
 
 def flatten_parameters(model) -> torch.Tensor:
     params = list(model.parameters())
-    offs, n = ops.flat_layout(params)             # every parameter on its own 128-byte line; the padding stays zero
+    offs, n = ops.flat_layout(params)
     flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
     for p, o in zip(params, offs):
         flat[o:o + p.numel()].copy_(p.detach().reshape(-1))

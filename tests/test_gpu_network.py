@@ -178,7 +178,7 @@ def test_flat_adam_matches_torch_adam():
         g = (torch.randn(flat.numel(), generator=gen) * 10 ** torch.randint(-6, 1, (flat.numel(),), generator=gen).float()).cuda()
         m1._last_flat_grad = g.clone()
         o1.step()
-        offs, _ = ops.flat_layout(list(m2.parameters()))            # every parameter on its own 128-byte line
+        offs, _ = ops.flat_layout(list(m2.parameters()))
         for p, o in zip(m2.parameters(), offs):
             p.grad = g[o:o + p.numel()].view(p.shape).clone()
         o2.step()
@@ -336,3 +336,22 @@ def test_per_point_layer_source_side_form():
     for k in grads:
         ref = sd_r[k].grad.numpy()
         np.testing.assert_allclose(grads[k], ref, atol=1e-6 + 2e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("B,N", [(2, 4096), (3, 24001)])
+def test_training_forward_is_bit_reproducible(B, N):
+    """The training-mode forward pass (batch statistics included) gives the same bits on every run, for the small-layer
+    kernels and for the per-point layer's source-side form.  It has to: statistics that move by 1e-7 (waves adding their
+    sums in arrival order) now and then change the sign of a pre-activation next to zero, and one flipped ReLU mask moved
+    weight gradients of the same step by 1-2 % (scripts/debug_grad_images.py)."""
+    args = make_args(subsample_size=N, ratio1=min(0.125, 1024 / N), r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=40)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    m = _model(args, network.init_state_dict(5)).train()
+    ref = None
+    for _ in range(6):
+        cov, proba = m(d)
+        got = (cov.detach().clone(), proba.detach().clone())
+        if ref is None:
+            ref = got
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
