@@ -67,9 +67,10 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
         "sn2_sa_backward:cf=16": 84 * e2 + 64 * e2 + 2 * 128 * m2 * B,
         # FP1: 24 B knn + 32 B skip + 3 x 144 B gathered rows (L2) read, 144 B written per point
         "sn2_fp_forward:34+8->34": (24 + 32 + 144) * N * B,
-        # FP1 backward: h + dy rows once (288 B; the BN sums come from the head's gradients), knn 24 B, skip 32 B, du written
-        # and read back 2 x 136 B, inverted-index entries 24 B, 3 gathered source rows (L2) counted once as 136 B
-        "sn2_fp_backward:34+8->34": (288 + 24 + 32 + 136 + 136 + 24 + 136) * N * B,
+        # FP1 backward (source-side form): h + dy rows once (288 B; the BN sums come from the head's gradients), skip 32 B,
+        # d pre-activation written once and gathered back through the inverted index (2 x 144 B; the index entries 24 B);
+        # the per-source work (G, dsrc, dW_A over B*m1 rows) is < 1 % of that
+        "sn2_fp_backward:34+8->34": (288 + 32 + 144 + 144 + 24) * N * B,
         "sn2_head_forward": (144 + 32) * N * B,
         "sn2_head_backward": (144 + 32 + 144) * N * B,
         "sn2_plot_project_forward": (8 + 8 + 16 + 4) * N * B + 24 * D * D * B,
@@ -82,24 +83,34 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
 DOMINANT_KERNEL = {
     "sn2_fps:N=32768": "fps_bucket_kernel<32, 16>", "sn2_ball_query:N=32768": "ball_query_grid_kernel",
     "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2>",
-    "sn2_fp_forward:34+8->34": "fp_fwd_kernel<34, 8, 34, true>",
-    "sn2_fp_backward:34+8->34": "fp_bwd_main_kernel<34, 8, 34, true, 8>",
+    "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34>",
+    "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512>",
     "sn2_head_forward": "head_fwd_kernel", "sn2_head_backward": "head_bwd_kernel",
     "sn2_three_nn:T=32768": "three_nn_grid_kernel", "sn2_pack_rows": "pack_rows_kernel",
 }
 
 
+# entry point -> all device kernels it launches (for the PMC traffic of the whole entry point, where it has several)
+ENTRY_KERNELS = {
+    "sn2_fp_backward:34+8->34": ["fp_bwd_rows_kernel<34, 8, 34, 512>", "fp_bwd_src_kernel<34, 8, 34>",
+                                 "fp_bwd_src_dw_kernel<34, 8, 34>", "fp_bwd_bn_kernel<34>"],
+    "sn2_fp_forward:34+8->34": ["fp_src_table_kernel<34, 8, 34>", "fp_fwd_rows_kernel<34, 8, 34>"],
+}
+
+
 def pmc_traffic(entry):
-    """HBM bytes per launch of the entry point's dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    """HBM bytes per launch of the entry point (the sum over its kernels) from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs; FETCH doubled per the gfx950 correction).  bench.py cannot collect
     counters itself; None when no profile is present."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    k = DOMINANT_KERNEL.get(entry)
-    if not files or k is None:
+    ks = ENTRY_KERNELS.get(entry) or ([DOMINANT_KERNEL[entry]] if entry in DOMINANT_KERNEL else [])
+    if not files or not ks:
         return None, None
     d = json.load(open(files[-1]))
-    return (d[k]["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])) if k in d else (None, None)
+    if DOMINANT_KERNEL.get(entry) not in d:
+        return None, None
+    return sum(d[k]["hbm_bytes_per_launch_corrected"] for k in ks if k in d), os.path.basename(files[-1])
 
 
 def rocprof_kernel_avg_ms(entry):

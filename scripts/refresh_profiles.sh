@@ -1,0 +1,25 @@
+#!/bin/bash
+# The measurement set behind profiles/rNN_* and DESIGN.md section 5, in one call on the GPU box:
+#   bash scripts/refresh_profiles.sh r01        (outputs under gpurun_out/refresh/, copy what is to be kept into profiles/)
+# rocprofv3: the program directly after "--"; counters in their own passes, without any trace option.
+set -o pipefail
+R=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/refresh
+rm -rf $OUT && mkdir -p $OUT
+cd $ROOT
+line() { grep '^{' "$1" | tail -1; }
+timeout -k 10 300 python bench.py > $OUT/bench.log 2>&1 && line $OUT/bench.log > $OUT/${R}_bench.json && echo "bench done" &&
+timeout -k 10 200 python bench.py --split-exchange --no-cpu-baseline > $OUT/split.log 2>&1 && line $OUT/split.log > $OUT/${R}_bench_split_exchange.json && echo "split done" &&
+timeout -k 10 200 python bench.py --host-inputs --no-cpu-baseline > $OUT/host.log 2>&1 && line $OUT/host.log > $OUT/${R}_bench_host_inputs.json && echo "host done" &&
+timeout -k 10 200 python bench.py --arch 3sa --no-cpu-baseline > $OUT/3sa.log 2>&1 && line $OUT/3sa.log > $OUT/${R}_bench_3sa.json && echo "3sa done" &&
+timeout -k 10 300 python bench.py --points 131072 --plots 8 --no-cpu-baseline > $OUT/c5.log 2>&1 && line $OUT/c5.log > $OUT/${R}_bench_131072pts.json && echo "c5 done" &&
+timeout -k 10 300 python scripts/bench_inference.py > $OUT/inf.log 2>&1 && line $OUT/inf.log > $OUT/${R}_bench_inference.json && echo "inference done" &&
+cd /tmp && export TMPDIR=/tmp &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/prof.log 2>&1 &&
+line $OUT/prof.log > $OUT/${R}_bench_under_rocprof.json && cp $(find $OUT/prof -name "*kernel_stats.csv" | tail -1) $OUT/${R}_kernel_stats.csv && echo "kernel stats done" &&
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --serial --eager --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 && echo "fetch pass done" &&
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --serial --eager --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 && echo "write pass done" &&
+cd $ROOT && python scripts/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | tail -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | tail -1) $OUT/${R}_pmc_traffic.json && echo "pmc summary done"
+rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write
+ls -la $OUT
