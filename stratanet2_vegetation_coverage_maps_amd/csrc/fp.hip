@@ -1614,45 +1614,44 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
 // |gamma| > 1e-4 on every channel (else the caller's ordinary pass runs: see `ok`); accumulated in fp64.
 // ok (device int): set to 1 when every |gamma| is large enough for the division and the sums were added, to 0 otherwise --
 // sn2_fp_backward then runs its ordinary pass over the rows (its BN kernels return at once when *ok == 1).
-__global__ __launch_bounds__(1024) void bn_sums_from_consumer_kernel(
+__global__ __launch_bounds__(256) void bn_sums_from_consumer_kernel(
     int C, int cout, int cin, int col0, const float* __restrict__ W, const float* __restrict__ dW,
     const float* __restrict__ db, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok, int rep_k, int rep_stride) {
-    // one workgroup: thread = (channel o of the BatchNorm, one of 16 slices of the (consumer row j, gradient image r)
-    // pairs); consecutive lanes read consecutive words of dW; fp64 partials added in slice order
+    // one workgroup per channel o of the BatchNorm; its threads share the (consumer row j, gradient image r) pairs
     __shared__ int s_ok;
-    __shared__ double s_red[2][16][64];
-    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
+    __shared__ double s_red[2][4];
+    const int o = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_ok = 1;
     __syncthreads();
-    if (threadIdx.x < C && !(fabsf(gamma[threadIdx.x]) > 1e-4f)) s_ok = 0;      // also catches NaN
+    for (int c = threadIdx.x; c < C; c += 256)
+        if (!(fabsf(gamma[c]) > 1e-4f)) s_ok = 0;               // also catches NaN
     __syncthreads();
-    if (threadIdx.x == 0) *ok = s_ok;
+    if (o == 0 && threadIdx.x == 0) *ok = s_ok;
     if (!s_ok) return;
     const int images = rep_k > 1 ? rep_k : 1;                   // the consumer's (dW, db) images are summed on the fly
+    const double g = (double)gamma[o], b = (double)beta[o];
     double sb = 0.0, sg = 0.0;
-    if (o < C) {
-        const double b = (double)beta[o];
-        for (int idx = part; idx < cout * images; idx += 16) {
-            const int r = idx / cout, j = idx - r * cout;
-            const double w = (double)W[j * cin + col0 + o];
-            const double dbj = (double)db[(size_t)r * rep_stride + j];
-            const double dwj = (double)dW[(size_t)r * rep_stride + j * cin + col0 + o];
-            sb += w * dbj;
-            sg += w * (dwj - b * dbj);
-        }
+    for (int idx = threadIdx.x; idx < cout * images; idx += 256) {
+        const int r = idx / cout, j = idx - r * cout;
+        const double w = (double)W[j * cin + col0 + o];
+        const double dbj = (double)db[(size_t)r * rep_stride + j];
+        const double dwj = (double)dW[(size_t)r * rep_stride + j * cin + col0 + o];
+        sb += w * dbj;
+        sg += w * (dwj - b * dbj);
     }
-    s_red[0][part][o] = sb;
-    s_red[1][part][o] = sg;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        sb += __shfl_xor(sb, m);
+        sg += __shfl_xor(sg, m);
+    }
+    if (lane == 0) s_red[0][wave] = sb, s_red[1][wave] = sg;
     __syncthreads();
-    if (threadIdx.x < C) {
-        sb = sg = 0.0;
-        for (int k = 0; k < 16; ++k) {
-            sb += s_red[0][k][o];
-            sg += s_red[1][k][o];
-        }
+    if (threadIdx.x == 0) {
+        sb = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+        sg = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
         dbeta[o] += (float)sb;
-        dgamma[o] += (float)(sg / (double)gamma[o]);
+        dgamma[o] += (float)(sg / g);
     }
 }
 
@@ -1676,7 +1675,7 @@ extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const flo
                                 int* ok, void* stream) {
     SN2_TRY(check_head(p));
     if (!p->dW1 || !p->db1 || !gamma || !beta || !dgamma || !dbeta || !ok) return SN2_EINVAL;
-    hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p->cin, 16, p->cin, 0, p->W1,
+    hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(p->cin), dim3(256), 0, (hipStream_t)stream, p->cin, 16, p->cin, 0, p->W1,
                        (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta, ok, p->grad_replicas,
                        p->grad_replica_stride);
     SN2_RETURN_LAUNCH();
@@ -1686,7 +1685,7 @@ extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* 
                               int* ok, void* stream) {
     SN2_TRY(check_fp(p));
     if (!p->knn_idx || !p->blk.dW || !p->blk.db || !gamma || !beta || !dgamma || !dbeta || !ok || p->ca > 64) return SN2_EINVAL;
-    hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p->ca, p->blk.cout, p->blk.cin, 0,
+    hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(p->ca), dim3(256), 0, (hipStream_t)stream, p->ca, p->blk.cout, p->blk.cin, 0,
                        (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta, ok,
                        p->blk.grad_replicas, p->blk.grad_replica_stride);
     SN2_RETURN_LAUNCH();
