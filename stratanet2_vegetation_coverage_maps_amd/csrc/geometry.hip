@@ -891,6 +891,13 @@ __global__ __launch_bounds__(256) void nn_grid_build_kernel(const float* __restr
     }
 }
 
+#ifdef SN2_NN_STAMPS
+// diagnostic build only (never shipped): per wave {cycles, candidates tested, final ring, query box cells}
+__device__ unsigned long long g_nn_dbg[4 * 16384];
+extern "C" int sn2_debug_nn_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_dbg), sizeof(unsigned long long) * n);
+}
+#endif
 __global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __restrict__ tbl, const int* __restrict__ hdr, int S,
                                                             int T, int k, const int* __restrict__ dst_order,
                                                             const float4* __restrict__ dst_sorted,
@@ -919,10 +926,19 @@ __global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __rest
               bx1 = __builtin_amdgcn_readfirstlane(cell1(wave_max(qx), x0, ix));
     const int by0 = __builtin_amdgcn_readfirstlane(cell1(wave_min(qy), y0, iy)),
               by1 = __builtin_amdgcn_readfirstlane(cell1(wave_max(qy), y0, iy));
-    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
-    int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF;
+    constexpr unsigned long long KINF = (0x7F800000ull << 32) | 0x7FFFFFFFull;     // (+inf, no index)
+    unsigned long long k0 = KINF, k1 = KINF, k2 = KINF;
     const int kk = k < S ? k : S;          // slots that will be filled
+#ifdef SN2_NN_STAMPS
+    unsigned long long t_begin;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin)::"memory");
+    unsigned n_cand = 0;
+    int rho_last = 0;
+#endif
     for (int rho = 0;; ++rho) {
+#ifdef SN2_NN_STAMPS
+        rho_last = rho;
+#endif
         const int xl = bx0 - rho, xh = bx1 + rho, yl = by0 - rho, yh = by1 + rho;
         const int cxl = xl < 0 ? 0 : xl, cxh = xh > G - 1 ? G - 1 : xh;
         for (int cy = (yl < 0 ? 0 : yl); cy <= (yh > G - 1 ? G - 1 : yh); ++cy) {
@@ -943,35 +959,63 @@ __global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __rest
                 // case (the candidate beats nobody's third best) is 8 VALU ops, one compare and one branch.  (Written
                 // inline, not as a lambda: called through a closure the best-three state ended up in scratch memory.)
                 const int p_lo = __builtin_amdgcn_readfirstlane(s_cell[c_lo]), p_hi = __builtin_amdgcn_readfirstlane(s_cell[c_hi + 1]);
-                float4 cn = s_tbl[p_lo];                                  // one candidate ahead: its LDS latency hides
-                for (int s = p_lo; s < p_hi; ++s) {                      // behind the previous candidate's arithmetic
-                    const float4 c = cn;
-                    cn = s_tbl[s + 1];                                   // (the table is followed by the cell starts: in bounds)
-                    const float dd = sn2_d2(c.x, c.y, c.z, qx, qy, qz);
-                    if (dd <= d2) {
-                        const int ii = __float_as_int(c.w);
-                        if (dd < d2 || ii < i2) {
-                            if (dd < d1 || (dd == d1 && ii < i1)) {
-                                d2 = d1; i2 = i1;
-                                if (dd < d0 || (dd == d0 && ii < i0)) {
-                                    d1 = d0; i1 = i0; d0 = dd; i0 = ii;
-                                } else {
-                                    d1 = dd; i1 = ii;
-                                }
-                            } else {
-                                d2 = dd; i2 = ii;
-                            }
-                        }
+#ifdef SN2_NN_STAMPS
+                n_cand += p_hi - p_lo;
+#endif
+// the running best three as 64-bit keys (d2 bits << 32 | source index): d2 >= 0, so the unsigned order of the keys IS the
+// lexicographic (d2, index) order, and an insertion is three branch-free min/max steps.  (With 64 lanes per query box
+// nearly every candidate is a hit for SOME lane, so the nested-if insertion ran, divergent, for most candidates.)
+#define NN_INSERT(DD, CW)                                                                                  \
+    {                                                                                                      \
+        const unsigned long long kn_ = ((unsigned long long)__float_as_uint(DD) << 32) | (unsigned)__float_as_int(CW); \
+        k2 = kn_ < k2 ? kn_ : k2;                                                                          \
+        const unsigned long long a_ = k1 < k2 ? k1 : k2, b_ = k1 < k2 ? k2 : k1;                           \
+        k1 = a_; k2 = b_;                                                                                  \
+        const unsigned long long c_ = k0 < k1 ? k0 : k1, e_ = k0 < k1 ? k1 : k0;                           \
+        k0 = c_; k1 = e_;                                                                                  \
+    }
+                int sp = p_lo;
+                for (; sp + 4 <= p_hi; sp += 4) {
+                    const float4 c0 = s_tbl[sp], c1 = s_tbl[sp + 1], c2 = s_tbl[sp + 2], c3 = s_tbl[sp + 3];
+                    const float e0 = sn2_d2(c0.x, c0.y, c0.z, qx, qy, qz), e1 = sn2_d2(c1.x, c1.y, c1.z, qx, qy, qz);
+                    const float e2 = sn2_d2(c2.x, c2.y, c2.z, qx, qy, qz), e3 = sn2_d2(c3.x, c3.y, c3.z, qx, qy, qz);
+                    if (fminf(fminf(e0, e1), fminf(e2, e3)) <= __uint_as_float((unsigned)(k2 >> 32))) {
+                        NN_INSERT(e0, c0.w)
+                        NN_INSERT(e1, c1.w)
+                        NN_INSERT(e2, c2.w)
+                        NN_INSERT(e3, c3.w)
                     }
                 }
+                for (; sp < p_hi; ++sp) {
+                    const float4 c = s_tbl[sp];
+                    const float dd = sn2_d2(c.x, c.y, c.z, qx, qy, qz);
+                    NN_INSERT(dd, c.w)
+                }
+#undef NN_INSERT
             }
         }
         if (xl <= 0 && yl <= 0 && xh >= G - 1 && yh >= G - 1) break;     // the whole grid has been visited
         const float reach = (float)rho * cw * 0.999f - 1e-4f;           // nothing unvisited is closer than this
-        const float dk = kk >= 3 ? d2 : (kk == 2 ? d1 : d0);
+        const float dk = __uint_as_float((unsigned)((kk >= 3 ? k2 : (kk == 2 ? k1 : k0)) >> 32));
         const float worst = wave_max(valid ? dk : 0.f);
         if (reach > 0.f && worst < reach * reach) break;
     }
+    const float d0 = __uint_as_float((unsigned)(k0 >> 32)), d1 = __uint_as_float((unsigned)(k1 >> 32)),
+                d2 = __uint_as_float((unsigned)(k2 >> 32));
+    const int i0 = (int)(unsigned)k0, i1 = (int)(unsigned)k1, i2 = (int)(unsigned)k2;
+#ifdef SN2_NN_STAMPS
+    {
+        unsigned long long t_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
+        const int wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+        if (lane == 0 && wid < 16384) {
+            g_nn_dbg[4 * wid + 0] = t_end - t_begin;
+            g_nn_dbg[4 * wid + 1] = n_cand;
+            g_nn_dbg[4 * wid + 2] = rho_last;
+            g_nn_dbg[4 * wid + 3] = (unsigned long long)((bx1 - bx0 + 1) * (by1 - by0 + 1));
+        }
+    }
+#endif
     if (!valid) return;
     const int t = dst_order[(size_t)b * T + p];
     const size_t o = ((size_t)b * T + t) * 3;
