@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int R, int f_stride, cons
     }
 }
 
-constexpr int HEAD_BWD_THREADS = 1024;
+constexpr int HEAD_BWD_THREADS = 256;
 constexpr int HEAD_BWD_LDS_FLOATS = OuterAcc<16, 35, 32>::LDS_FLOATS;   // >= OuterAcc<16, 17, 32>::LDS_FLOATS
 __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f_stride, const float* __restrict__ f,
                                                        const float* __restrict__ fa, const float* __restrict__ fc,
@@ -1511,8 +1511,9 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
                                                        float* __restrict__ db2, int rep_k, int rep_stride) {
     using Acc2 = OuterAcc<16, 17, 32>;  // rows 0..4 = d scores, rest zero;  Q = [z1 | 1]
     using Acc1 = OuterAcc<16, 35, 32>;  // d pre-activation of lin1;          Q = [y | 1]
-    // 16 waves per workgroup (4 per SIMD: the row loads are 144-byte strided, only occupancy hides them); the two
-    // accumulators take turns in one 8 KB staging region per wave
+    // 4 waves per workgroup, 4 workgroups per CU (4 waves per SIMD: the row loads are 144-byte strided, only occupancy
+    // hides them; 1024-thread workgroups took 82 us, 256-thread ones 74: the hardware balances workgroups); the two
+    // accumulators take turns in one 10 KB staging region per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lds2 = smem + (threadIdx.x >> 6) * HEAD_BWD_LDS_FLOATS;
     float* lds1 = lds2;
@@ -1699,7 +1700,7 @@ extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
     int grid = pick_grid(p->R, HEAD_BWD_THREADS, 1);
-    if (grid > 256) grid = 256;
+    if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
                        p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
                        p->db2, p->grad_replicas, p->grad_replica_stride);
