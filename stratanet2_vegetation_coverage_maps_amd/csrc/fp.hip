@@ -288,15 +288,28 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
             }
         });
     }
-    // workgroup-level reduction of the [dW | db] image, then one global atomic per element and workgroup
+    // workgroup-level reduction of the [dW | db] image (every wave's slab in its own staging region, added in wave order;
+    // LDS float atomics where a slab does not fit the region), then one global atomic per element and workgroup
+    constexpr bool SLAB = CO * (CI + 1) <= Acc::LDS_FLOATS;
     float* red = smem;
-    __syncthreads();
-    for (int i = threadIdx.x; i < CO * (CI + 1); i += WAVES * 64) red[i] = 0.f;
-    __syncthreads();
-    acc.flush_lds(red);
-    __syncthreads();
+    if constexpr (SLAB) {
+        acc.store_slab(lds);
+        __syncthreads();
+    } else {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CO * (CI + 1); i += WAVES * 64) red[i] = 0.f;
+        __syncthreads();
+        acc.flush_lds(red);
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < CO * (CI + 1); i += WAVES * 64) {
-        const float v = red[i];
+        float v = 0.f;
+        if constexpr (SLAB) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) v += smem[w * Acc::LDS_FLOATS + i];
+        } else {
+            v = red[i];
+        }
         if (v == 0.f) continue;
         const int o = i / (CI + 1), k = i - o * (CI + 1), img = sn2_grad_image(rep_k, rep_stride);
         if (k < CI) SN2_FLUSH_ADD(&dW[img + o * CI + k], v);
@@ -893,14 +906,11 @@ __global__ __launch_bounds__(256) void fp_bwd_src_dw_kernel(int n_src, int src_s
         for (int k = 0; k < CA; ++k) x[k] = fmaf(sa[k], x[k], sc[k]);
     }
     acc.add(lds, p, x);
-    float* red = smem;
-    __syncthreads();
-    for (int i = threadIdx.x; i < CO * CA; i += 256) red[i] = 0.f;
-    __syncthreads();
-    acc.flush_lds(red);
+    static_assert(CO * CA <= Acc::LDS_FLOATS, "a wave's image fits its staging region");
+    acc.store_slab(lds);
     __syncthreads();
     for (int i = threadIdx.x; i < CO * CA; i += 256) {
-        const float v = red[i];
+        const float v = (smem[i] + smem[Acc::LDS_FLOATS + i]) + (smem[2 * Acc::LDS_FLOATS + i] + smem[3 * Acc::LDS_FLOATS + i]);
         if (v != 0.f) SN2_FLUSH_ADD(&dW[sn2_grad_image(rep_k, rep_stride) + (i / CA) * CI + (i % CA)], v);
     }
 }
@@ -1585,13 +1595,14 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
     float* red = smem;
     constexpr int N2 = 16 * 17, N1 = 16 * 35;
     __syncthreads();
-    for (int i = threadIdx.x; i < N2 + N1; i += HEAD_BWD_THREADS) red[i] = 0.f;
-    __syncthreads();
-    acc2.flush_lds(red);
-    acc1.flush_lds(red + N2);
+    static_assert(N2 + N1 <= HEAD_BWD_LDS_FLOATS, "a wave's two images fit its staging region");
+    acc2.store_slab(lds2);
+    acc1.store_slab(lds2 + N2);
     __syncthreads();
     for (int i = threadIdx.x; i < N2 + N1; i += HEAD_BWD_THREADS) {
-        const float v = red[i];
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < HEAD_BWD_THREADS / 64; ++w) v += red[w * HEAD_BWD_LDS_FLOATS + i];
         if (v == 0.f) continue;
         const int img = sn2_grad_image(rep_k, rep_stride);
         if (i < N2) {

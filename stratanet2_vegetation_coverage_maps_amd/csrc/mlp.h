@@ -117,6 +117,23 @@ struct OuterAcc {
         }
     }
 
+    // this wave's tile sums as an image slab[CO][CK] (plain stores, every element written once): the workgroup then adds
+    // its waves' slabs in wave order.  The wave's own staging region is free for it once its last add() has returned.
+    // (flush_lds below does the same with LDS float atomics: ~0.4 lane-adds per clock -- 5-10 us at the end of a kernel.)
+    __device__ __forceinline__ void store_slab(float* slab) {
+        const int lane = threadIdx.x & 63;
+        const int r4 = lane >> 4, c = lane & 15;
+#pragma unroll
+        for (int a = 0; a < TO; ++a)
+#pragma unroll
+            for (int b = 0; b < TK; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = a * 16 + r4 * 4 + r, k = b * 16 + c;
+                    if (o < CO && k < CK) slab[o * CK + k] = acc[a][b][r];
+                }
+    }
+
     // add this wave's tile sums into a block-shared LDS image red[CO][CK] (LDS float atomics; the image must be zeroed
     // and the workgroup synchronised before, and synchronised again before it is read)
     __device__ __forceinline__ void flush_lds(float* red) {
