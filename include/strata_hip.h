@@ -90,6 +90,13 @@ int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, in
 #define SN2_THREE_NN_WS_WORDS(B, S) ((size_t)(B) * (4 * (size_t)(S) + 1032))
 int sn2_three_nn(const float *src_soa, int B, int S, const float *dst_soa, int T, int k, int *idx, float *w,
                  void *ws, const int *dst_fps_ws, void *stream);
+/* The same search with the targets sorted by the source grid's x,y cells inside the call (a counting sort, one workgroup
+ * per plot): every wave then holds 64 targets of one or two adjacent cells, whatever order the targets come in.
+ * 128 <= S <= 8192; ws = 16-byte aligned workspace of SN2_THREE_NN_XY_WS_WORDS(B,S,T) 32-bit words.  Same results as
+ * sn2_three_nn, bit for bit. */
+#define SN2_THREE_NN_XY_WS_WORDS(B, S, T) ((size_t)(B) * (4 * (size_t)(S) + 5 * (size_t)(T) + 1032))
+int sn2_three_nn_xy(const float *src_soa, int B, int S, const float *dst_soa, int T, int k, int *idx, float *w,
+                    void *ws, void *stream);
 
 /* Input pipeline of a batch: load_cloud of the reference DataLoader, data_loader/loader.py:73-87 --
  * centre, append the fake ground points, keep xyz, [train: rotate about z, flip, add noise], rescale, gather the subsample --

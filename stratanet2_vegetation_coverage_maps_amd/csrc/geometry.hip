@@ -1028,6 +1028,82 @@ __global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __rest
     w[o + 2] = u2 ? 1.0f / fmaxf(d2, 1e-16f) : 0.f;
 }
 
+// The targets of a plot in the order of the SOURCE grid's cells (rows of cells walked in a snake, so that consecutive cells
+// are always neighbours): counting sort in LDS, one workgroup per plot.  A wave of three_nn_grid_kernel then holds 64
+// targets of one or two adjacent cells -- a 1-2 cell query box for every wave.  (In the order sn2_fps leaves, a 3-D
+// Morton order of a 16^3 grid, the boxes averaged 7 cells and reached 72: 162 candidates per wave on average, 726 in
+// the slowest, and the slowest wave is the kernel.)  The order inside a cell is whatever the cursor atomics give: the
+// search is exact, so its results do not depend on it.
+__global__ __launch_bounds__(1024) void nn_target_sort_kernel(const float* __restrict__ dst, int T, const int* __restrict__ hdr,
+                                                              int* __restrict__ order, float4* __restrict__ sorted) {
+    __shared__ int s_hist[NN_GMAX * NN_GMAX + 1];
+    __shared__ int s_wsum[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* hb = hdr + (size_t)b * NN_HDR;
+    const int G = hb[NN_GMAX * NN_GMAX + 1 + 5];
+    const float* hf = reinterpret_cast<const float*>(hb + NN_GMAX * NN_GMAX + 1);
+    const float x0 = hf[0], y0 = hf[1], ix = hf[2], iy = hf[3];
+    const float* dx = dst + (size_t)b * 3 * T;
+    const float* dy = dx + T;
+    const float* dz = dy + T;
+    auto key_of = [&](int i) {
+        const float vx = dx[i] - x0, vy = dy[i] - y0;
+        int cx = (int)(vx * ix), cy = (int)(vy * iy);
+        cx = (vx < 0.f || cx < 0) ? 0 : (cx > G - 1 ? G - 1 : cx);
+        cy = (vy < 0.f || cy < 0) ? 0 : (cy > G - 1 ? G - 1 : cy);
+        return cy * G + ((cy & 1) ? G - 1 - cx : cx);
+    };
+    for (int i = tid; i <= G * G; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < T; i += 1024) atomicAdd(&s_hist[key_of(i)], 1);
+    __syncthreads();
+    {   // exclusive scan over the <= 1024 cells: one cell per thread, wave scan, 16 wave totals
+        const int v = tid < G * G ? s_hist[tid] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - v;
+        for (int k = 0; k < wave; ++k) run += s_wsum[k];
+        __syncthreads();
+        if (tid < G * G) s_hist[tid] = run;
+    }
+    __syncthreads();
+    int* ob = order + (size_t)b * T;
+    float4* sb = sorted + (size_t)b * T;
+    for (int i = tid; i < T; i += 1024) {
+        const int p = atomicAdd(&s_hist[key_of(i)], 1);
+        ob[p] = i;
+        sb[p] = make_float4(dx[i], dy[i], dz[i], 0.f);
+    }
+}
+
+extern "C" int sn2_three_nn_xy(const float* src_soa, int B, int S, const float* dst_soa, int T, int k, int* idx, float* w,
+                               void* ws, void* stream) {
+    if (!src_soa || !dst_soa || !idx || !w || !ws || B <= 0 || S <= 0 || T <= 0 || k < 1 || k > 3) return SN2_EINVAL;
+    if (S < 128 || S > 8192 || (((size_t)ws) % 16) != 0) return SN2_ELIMIT;
+    hipStream_t st = (hipStream_t)stream;
+    int G = (int)sqrtf((float)S / 4.f);   // about 4 sources per cell
+    G = G < 2 ? 2 : (G > NN_GMAX ? NN_GMAX : G);
+    float4* tbl = reinterpret_cast<float4*>(ws);
+    float4* sorted = tbl + (size_t)B * S;
+    int* hdr = reinterpret_cast<int*>(sorted + (size_t)B * T);
+    int* order = hdr + (size_t)B * NN_HDR;
+    hipLaunchKernelGGL(nn_grid_build_kernel, dim3(B), dim3(256), 0, st, src_soa, S, G, tbl, hdr);
+    hipLaunchKernelGGL(nn_target_sort_kernel, dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
+    const size_t lds = (size_t)S * 16 + (size_t)(G * G + 1) * 4;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&three_nn_grid_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(three_nn_grid_kernel, dim3(sn2_cdiv(T, 256), B), dim3(256), lds, st, (const float4*)tbl,
+                       (const int*)hdr, S, T, k, (const int*)order, (const float4*)sorted, idx, w);
+    SN2_RETURN_LAUNCH();
+}
+
 extern "C" int sn2_three_nn(const float* src_soa, int B, int S, const float* dst_soa, int T, int k, int* idx, float* w,
                             void* ws, const int* dst_fps_ws, void* stream) {
     if (!src_soa || !dst_soa || !idx || !w || B <= 0 || S <= 0 || T <= 0 || k < 1 || k > 3) return SN2_EINVAL;

@@ -193,18 +193,25 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
     return nbr, cnt, total
 
 
-def three_nn_ws_words(B: int, S: int) -> int:
-    """SN2_THREE_NN_WS_WORDS of include/strata_hip.h."""
-    return B * (4 * S + 1032)
+def three_nn_ws_words(B: int, S: int, T: int = 0) -> int:
+    """SN2_THREE_NN_XY_WS_WORDS (T > 0) / SN2_THREE_NN_WS_WORDS (T = 0) of include/strata_hip.h."""
+    return B * (4 * S + 5 * T + 1032)
+
+
+def three_nn_uses_grid(S: int, T: int) -> bool:
+    """The grid search of sn2_three_nn_xy applies (otherwise the full scan runs)."""
+    return 128 <= S <= 8192 and T > 2048
 
 
 def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int, out=None, grid: bool = True, ws=None,
              dst_fps_ws: Optional[torch.Tensor] = None):
     """-> idx (B*T,3) int32 local source indices, w (B*T,3) = 1/max(d2,1e-16) (0 on unused slots).
     out = (idx, w): caller-owned result buffers.
-    dst_fps_ws: the workspace `fps(..., return_ws=True)` filled for the TARGET points: enables the grid search (waves of
-    spatially adjacent targets; same result); ws: caller-owned workspace of three_nn_ws_words(B, S) int32 for it
-    (allocated here when None); grid=False forces the full scan (cross-checks)."""
+    grid=True: for T > 2048 targets and 128..8192 sources the search walks a per-plot x,y grid of the sources, a wave taking
+    64 targets of adjacent grid cells (sn2_three_nn_xy sorts the targets by cell itself; same result as the full scan, bit
+    for bit); ws: caller-owned workspace of three_nn_ws_words(B, S, T) int32 for it (allocated here when None).
+    dst_fps_ws (with grid=True): use the order `fps(..., return_ws=True)` left for the TARGET points instead of the
+    cell sort (the first form of the grid search, kept for cross-checks); grid=False forces the full scan."""
     B, _, S = src_soa.shape
     T = dst_soa.shape[2]
     _chk(src_soa, F32, (B, 3, S), "src_soa")
@@ -217,11 +224,19 @@ def three_nn(src_soa: torch.Tensor, dst_soa: torch.Tensor, k: int, out=None, gri
     else:
         idx = torch.empty(B * T, 3, dtype=I32, device=dev)
         w = torch.empty(B * T, 3, dtype=F32, device=dev)
-    if grid and dst_fps_ws is not None and 128 <= S <= 8192 and T > 2048:
+    if grid and three_nn_uses_grid(S, T) and dst_fps_ws is None:
+        n = three_nn_ws_words(B, S, T)
+        if ws is None:
+            ws = torch.empty(n, dtype=I32, device=dev)
+        else:
+            _chk(ws, I32, (n,), "ws")
+        _call("sn2_three_nn_xy", _ptr(src_soa), B, S, _ptr(dst_soa), T, k, _ptr(idx), _ptr(w), _ptr(ws), _stream(), tag=f"T={T}")
+        return idx, w
+    if grid and dst_fps_ws is not None and three_nn_uses_grid(S, T):
         if ws is None:
             ws = torch.empty(three_nn_ws_words(B, S), dtype=I32, device=dev)
-        else:
-            _chk(ws, I32, (three_nn_ws_words(B, S),), "ws")
+        elif ws.numel() < three_nn_ws_words(B, S):
+            raise ValueError("three_nn: workspace too small")
         _chk(dst_fps_ws, I32, (fps_ws_words(B, T),), "dst_fps_ws")
     else:
         ws = dst_fps_ws = None

@@ -207,7 +207,8 @@ class PointNet2(nn.Module):
         g.tot1, g.tot2 = g.totals[0:1], g.totals[1:2]
         g.ord1, g.ord2 = e(ops.sa_order_len(B, M1), dt=I32), e(ops.sa_order_len(B, M2), dt=I32)
         g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1)))
-        g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S), dt=I32) if 128 <= S <= 8192 else None for S in (M2, M1))
+        g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S, T), dt=I32) if ops.three_nn_uses_grid(S, T) else None
+                        for S, T in ((M2, M1), (M1, N)))
         g.ready = None
         return g
 
@@ -233,8 +234,8 @@ class PointNet2(nn.Module):
             ops.sa_order(g.cnt1, B, M1, out=g.ord1)
             ops.sa_order(g.cnt2, B, M2, out=g.ord2)
             ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
-            ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[0], dst_fps_ws=g.ws2)
-            ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1], dst_fps_ws=g.ws1)
+            ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[0])
+            ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1])
             ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
             ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
             ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
@@ -250,8 +251,8 @@ class PointNet2(nn.Module):
         g.ord1, g.ord2 = ops.sa_order(g.cnt1, B, M1), ops.sa_order(g.cnt2, B, M2)
         pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)      # GlobalSAModule: pos = zeros (point_net2.py:40)
         g.knn3 = ops.three_nn(pos3, g.pos2_soa, 1)
-        g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3, dst_fps_ws=ws2)
-        g.knn1 = ops.three_nn(g.pos1_soa, xyz, 3, dst_fps_ws=ws1)
+        g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3)
+        g.knn1 = ops.three_nn(g.pos1_soa, xyz, 3)
         # the inverted 3-NN tables the backward pass gathers through: positions only, so they belong here
         g.inv3 = ops.interp_index(g.knn3, B, M2, 1)
         g.inv2 = ops.interp_index(g.knn2, B, M1, M2)

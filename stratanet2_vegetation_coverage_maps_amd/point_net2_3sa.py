@@ -84,7 +84,8 @@ class PointNet2ThreeSA(PointNet2):
         g.knn4, g.knn3 = (e(B * M3, 3, dt=I32), e(B * M3, 3)), (e(B * M2, 3, dt=I32), e(B * M2, 3))
         g.knn2, g.knn1 = (e(B * M1, 3, dt=I32), e(B * M1, 3)), (e(B * N, 3, dt=I32), e(B * N, 3))
         g.inv4, g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M3, 1), (M2, M3), (M1, M2), (N, M1)))
-        g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S), dt=I32) if 128 <= S <= 8192 else None for S in (M3, M2, M1))
+        g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S, T), dt=I32) if ops.three_nn_uses_grid(S, T) else None
+                        for S, T in ((M3, M2), (M2, M1), (M1, N)))
         g.ready = None
         return g
 
@@ -107,9 +108,9 @@ class PointNet2ThreeSA(PointNet2):
             ops.sa_order(getattr(g, f"cnt{lvl}"), B, M, out=getattr(g, f"ord{lvl}"))
             src = cs
         ops.three_nn(g.posg, g.pos3_soa, 1, out=g.knn4)
-        ops.three_nn(g.pos3_soa, g.pos2_soa, 3, out=g.knn3, ws=g.nn_ws[0], dst_fps_ws=g.ws3)
-        ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[1], dst_fps_ws=g.ws2)
-        ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[2], dst_fps_ws=g.ws1)
+        ops.three_nn(g.pos3_soa, g.pos2_soa, 3, out=g.knn3, ws=g.nn_ws[0])
+        ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[1])
+        ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[2])
         ops.interp_index(g.knn4, B, M3, 1, out=g.inv4)
         ops.interp_index(g.knn3, B, M2, M3, out=g.inv3)
         ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)

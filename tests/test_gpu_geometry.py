@@ -145,8 +145,10 @@ def test_grid_three_nn_equals_full_scan(B, S, T, k):
     _, _, _, fws = ops.fps(dst.to(DEV), 64, None, return_ws=True)      # the targets' Morton order
     a_i, a_w = ops.three_nn(src.to(DEV), dst.to(DEV), k, dst_fps_ws=fws)
     b_i, b_w = ops.three_nn(src.to(DEV), dst.to(DEV), k, grid=False)
+    c_i, c_w = ops.three_nn(src.to(DEV), dst.to(DEV), k)          # targets sorted by the source grid's cells in the call
     torch.cuda.synchronize()
     assert torch.equal(a_i, b_i) and torch.equal(a_w, b_w)
+    assert torch.equal(c_i, b_i) and torch.equal(c_w, b_w)
 
 
 @pytest.mark.parametrize("B,N,M,r,cap", [(2, 32768, 1024, 1.0, 2000), (2, 4096, 512, 2 ** 0.5, 2000), (1, 8192, 64, 4.0, 300),
