@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="headline = the unpipelined step (geometry and features of a batch back to back on one stream)")
     ap.add_argument("--depth", type=int, default=3, help="geometry passes kept in flight ahead of the feature pass")
+    ap.add_argument("--no-pair", action="store_true", help="one geometry pass per batch (default: one pass covers two "
+                    "consecutive batches -- FPS is one workgroup per plot, so 32 plots take as long as 16)")
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per plot (default = the metric's 32768; other "
                     "values are extra measurements, e.g. 131072 with --plots 8 for BASELINE config 5's plot size)")
     ap.add_argument("--plots", type=int, default=PLOTS_PER_GPU, help="plots per GPU (default = the metric's 16)")
@@ -221,7 +223,7 @@ def main():
     flatten_parameters(model)
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
     # depth+1 resident batches (the pipeline's slots); batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
-    n_slots = 1 if a.serial else a.depth + 1
+    n_slots = 1 if a.serial else (a.depth + 1 if a.no_pair else 2 * a.depth + 2)
     slots = []
     for j in range(n_slots):
         host = make_batch(B, N_POINTS, first_plot=j * world * B + shard_of_rank(rank, B)[0])
@@ -324,7 +326,8 @@ def main():
         pipe.prime()
         for _ in range(a.warmup):
             pipe.step()
-        mode = f"pipelined depth {a.depth}/{launch}" + (" + H2D of every batch from pinned host memory" if a.host_inputs else "")
+        mode = (f"pipelined depth {a.depth}" + (", one geometry pass per two batches" if pipe.pair else "") + f"/{launch}" +
+                (" + H2D of every batch from pinned host memory" if a.host_inputs else ""))
     log(f"mode: {mode}")
 
     barrier()
@@ -423,8 +426,10 @@ def main():
                                       ("1024/256 + global, r 1/2 m, " if a.arch == "ref" else "1024/256/64 + global, r 1/2/4 m, ") +
                                       "train step fwd+P2+loss+bwd+Adam, inputs resident in HBM",
                           "mode": mode + ("" if a.serial else
-                                          ": every step runs one geometry pass (FPS, ball query, 3-NN of a later batch, side "
-                                          "streams) and one feature pass (this batch); distinct batches in the slots"),
+                                          ": every step runs one feature pass (this batch); the position-only kernels (FPS, "
+                                          "ball query, 3-NN) of every batch run exactly once, for later batches on side "
+                                          "streams" + (", two consecutive batches per launch" if (pipe is not None and pipe.pair) else "") +
+                                          "; distinct batches in the slots"),
                           "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
                "loss": round(loss_value, 6), "roofline": roof, "kernels": kernels}

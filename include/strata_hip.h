@@ -80,6 +80,10 @@ int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *id
 int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, int M, float r2, int cap,
                    int *nbr, int *cnt, unsigned long long *total, const int *fps_ws, void *stream);
 
+/* total = sum of cnt[0..n): the number of messages of a set of neighbour lists (what sn2_ball_query leaves in `total` for
+ * the lists of one call; needed again when the lists of one call are handed on in parts). */
+int sn2_count_sum(const int *cnt, int n, unsigned long long *total, void *stream);
+
 /* k nearest sources (k = 1..3) + inverse squared distance weights -- the no_grad part of
  * torch_geometric.nn.knn_interpolate, model/point_net2.py:63.
  * idx (B*T,3), w (B*T,3): w = 1/max(d2,1e-16); unused slots (k<3 or S<k) get w = 0 and idx = idx[0].

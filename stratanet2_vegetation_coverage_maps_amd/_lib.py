@@ -53,6 +53,7 @@ SIGNATURES = {
     "sn2_ball_query": [c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_void_p],
     "sn2_three_nn": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sn2_count_sum": [c_void_p, c_int, c_void_p, c_void_p],
     "sn2_three_nn_xy": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_prepare_plots": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p],

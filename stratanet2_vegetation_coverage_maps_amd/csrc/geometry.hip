@@ -1028,6 +1028,12 @@ __global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __rest
     w[o + 2] = u2 ? 1.0f / fmaxf(d2, 1e-16f) : 0.f;
 }
 
+extern "C" int sn2_count_sum(const int* cnt, int n, unsigned long long* total, void* stream) {
+    if (!cnt || !total || n <= 0) return SN2_EINVAL;
+    hipLaunchKernelGGL(count_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cnt, n, total);
+    SN2_RETURN_LAUNCH();
+}
+
 // The targets of a plot in the order of the SOURCE grid's cells (rows of cells walked in a snake, so that consecutive cells
 // are always neighbours): counting sort in LDS, one workgroup per plot.  A wave of three_nn_grid_kernel then holds 64
 // targets of one or two adjacent cells -- a 1-2 cell query box for every wave.  (In the order sn2_fps leaves, a 3-D

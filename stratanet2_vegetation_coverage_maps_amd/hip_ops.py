@@ -193,6 +193,13 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
     return nbr, cnt, total
 
 
+def count_sum(cnt: torch.Tensor, total: torch.Tensor):
+    """include/strata_hip.h: sn2_count_sum -- total (1,) int64 = sum of the neighbour counts cnt (n,) int32."""
+    _chk(cnt, I32, None, "cnt")
+    _chk(total, I64, (1,), "total")
+    _call("sn2_count_sum", _ptr(cnt), cnt.numel(), _ptr(total), _stream())
+
+
 def three_nn_ws_words(B: int, S: int, T: int = 0) -> int:
     """SN2_THREE_NN_XY_WS_WORDS (T > 0) / SN2_THREE_NN_WS_WORDS (T = 0) of include/strata_hip.h."""
     return B * (4 * S + 5 * T + 1032)

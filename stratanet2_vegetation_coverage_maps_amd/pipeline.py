@@ -24,20 +24,41 @@ from .optim import allreduce_flat_grad
 
 class TrainPipeline:
     def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True, n_streams=None,
-                 split_exchange=None):
+                 split_exchange=None, pair=None):
         """model: PointNet2 (train mode); opt: FlatAdam; slot_inputs: list of depth+1 dicts with device tensors "cloud"
         (B,10,N), "xyz" (B,3,N), "fps_start" (2,B) int32 + whatever `feature_step` needs;
         feature_step(inputs, geometry) -> loss: zero_grad, forward (with cloud_data["geometry"] = geometry),
         projection, loss, backward -- everything of the step except the gradient exchange and the optimiser."""
-        if len(slot_inputs) < depth + 1:
-            raise ValueError("need at least depth+1 input slots")
+        # pair mode: one geometry pass covers TWO consecutive batches (FPS is one workgroup per plot and M sequential
+        # rounds: 32 plots take as long as 16), so a side stream delivers two batches per pass.  The step is bound by
+        # (latency of a geometry pass under load) / (batches it covers x passes in flight), and the passes in flight are
+        # limited by the hardware queues (three side streams + the main one).  Needs 2*depth+2 slots.
+        if pair is None:
+            pair = len(slot_inputs) >= 2 * depth + 2 and len(slot_inputs) % 2 == 0 and hasattr(model, "alloc_geometry_pair")
+        self.pair = bool(pair)
+        if len(slot_inputs) < (2 * depth + 2 if self.pair else depth + 1):
+            raise ValueError("need at least depth+1 input slots (2*depth+2 in pair mode)")
+        if self.pair and len(slot_inputs) % 2:
+            raise ValueError("pair mode needs an even number of slots")
         self.model, self.opt, self.feature_step = model, opt, feature_step
         self.inputs = slot_inputs
         self.depth, self.slots = depth, len(slot_inputs)
         dev = slot_inputs[0]["xyz"].device
         self.dev = dev
         B, _, N = slot_inputs[0]["xyz"].shape
-        self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
+        if self.pair:
+            self.geo, self.geo_pairs, self.xyz2, self.fs2 = [None] * self.slots, [], [], []
+            for pb in range(self.slots // 2):
+                gp, (g0, g1) = model.alloc_geometry_pair(B, N, dev)
+                self.geo_pairs.append(gp)
+                self.geo[2 * pb], self.geo[2 * pb + 1] = g0, g1
+                self.xyz2.append(torch.empty(2 * B, 3, N, dtype=slot_inputs[0]["xyz"].dtype, device=dev))
+                self.fs2.append(torch.zeros(2, 2 * B, dtype=torch.int32, device=dev))
+        else:
+            self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
+        self.B = B
+        # batches the geometry may run ahead of the feature passes (never into a slot whose feature pass is not launched yet)
+        self.ahead = min(2 * depth, self.slots - 2) if self.pair else depth
         self.n_streams = n_streams or depth
         self.side = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
         self.geo_ready = [torch.cuda.Event() for _ in range(self.slots)]
@@ -57,6 +78,8 @@ class TrainPipeline:
     # ---- geometry of batch number i (its inputs must already be in slot i % slots)
     def issue_geometry(self, i=None):
         i = self.issued if i is None else i
+        if self.pair:
+            return self._issue_pair(i)
         k = i % self.slots
         st = self.side[i % self.n_streams]
         if self.slot_done[k] is not None:
@@ -74,6 +97,32 @@ class TrainPipeline:
             self.geo_ready[k].record(st)
         self.issued = max(self.issued, i + 1)
 
+    def _issue_pair(self, i):
+        """Geometry of batches i and i+1 (i even) in one pass on one side stream."""
+        i -= i % 2
+        B = self.B
+        k0, k1 = i % self.slots, (i + 1) % self.slots
+        pb = k0 // 2
+        st = self.side[(i // 2) % self.n_streams]
+        for k in (k0, k1):
+            if self.slot_done[k] is not None:
+                st.wait_event(self.slot_done[k])
+            else:
+                st.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(st):
+            for j, k in ((i, k0), (i + 1, k1)):
+                d = self.inputs[k]
+                if self.feeder is not None:
+                    for name, t in self.feeder(j).items():
+                        d[name].copy_(t, non_blocking=True)
+                h = k - k0
+                self.xyz2[pb][h * B:(h + 1) * B].copy_(d["xyz"], non_blocking=True)
+                self.fs2[pb][:, h * B:(h + 1) * B].copy_(d["fps_start"], non_blocking=True)
+            self.model._geometry_pair(self.xyz2[pb], self.fs2[pb], self.geo_pairs[pb], (self.geo[k0], self.geo[k1]))
+            self.geo_ready[k0].record(st)
+            self.geo_ready[k1].record(st)
+        self.issued = max(self.issued, i + 2)
+
     def _exchange_and_update(self, k):
         g = self.flat_grad[k]
         self.model._last_flat_grad = g
@@ -83,7 +132,7 @@ class TrainPipeline:
         """Warm every slot eagerly (allocator, lazy loads), then capture each slot's feature pass.  Geometry of all
         slots must be valid while warming: computed here, and left valid for steps 0..slots-1."""
         main = torch.cuda.current_stream(self.dev)
-        for i in range(self.slots):
+        for i in range(0, self.slots, 2 if self.pair else 1):
             self.issue_geometry(i)
         self.issued = 0
         for st in self.side:
@@ -118,9 +167,13 @@ class TrainPipeline:
         torch.cuda.synchronize(self.dev)
 
     def prime(self):
-        """Launch the geometry of the first `depth` batches (before the first step)."""
-        while self.issued < self.done + self.depth:
-            self.issue_geometry()
+        """Launch the geometry of the first `depth` batches (pairs of batches in pair mode) before the first step."""
+        self._run_ahead()
+
+    def _run_ahead(self):
+        step = 2 if self.pair else 1
+        while self.issued + step <= self.done + self.ahead:
+            self.issue_geometry(self.issued)
 
     def step(self):
         """One training step on batch number `done` (slot done % slots); keeps `depth` geometry passes in flight."""
@@ -145,8 +198,7 @@ class TrainPipeline:
         self.slot_done[k] = ev
         self.done = i + 1
         # geometry of batch i+depth goes into the slot whose tables batch i+depth-slots (= i-1 when slots = depth+1) read
-        while self.issued < self.done + self.depth:
-            self.issue_geometry(self.issued)
+        self._run_ahead()
         return loss
 
     def set_feeder(self, feeder):

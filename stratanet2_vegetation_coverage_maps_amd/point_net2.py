@@ -259,6 +259,62 @@ class PointNet2(nn.Module):
         g.inv1 = ops.interp_index(g.knn1, B, N, M1, src_pos=g.pos1_aos)
         return g
 
+    def alloc_geometry_pair(self, B, N, device=None):
+        """Buffers for `_geometry_pair`: the position-only kernels of TWO batches of B plots launched together (FPS is one
+        workgroup per plot and M sequential rounds: two batches take as long as one), plus the two per-batch views the
+        feature passes read.  -> (combined buffers, (geometry of the first batch, geometry of the second))."""
+        dev = torch.device(device if device is not None else self.lin1.weight.device)
+        M1, M2 = self._sizes(N)
+        gp = self.alloc_geometry(2 * B, N, dev)
+        e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
+        halves = []
+        for h in range(2):
+            g = _Saved()
+            g.B, g.N, g.M1, g.M2 = B, N, M1, M2
+            pl, r1, r2, rn = slice(h * B, (h + 1) * B), slice(h * B * M1, (h + 1) * B * M1), \
+                slice(h * B * M2, (h + 1) * B * M2), slice(h * B * N, (h + 1) * B * N)
+            g.idx1, g.pos1_soa, g.pos1_aos, g.nbr1, g.cnt1 = gp.idx1[pl], gp.pos1_soa[pl], gp.pos1_aos[r1], gp.nbr1[r1], gp.cnt1[r1]
+            g.idx2, g.pos2_soa, g.pos2_aos, g.nbr2, g.cnt2 = gp.idx2[pl], gp.pos2_soa[pl], gp.pos2_aos[r2], gp.nbr2[r2], gp.cnt2[r2]
+            g.knn3 = (gp.knn3[0][r2], gp.knn3[1][r2])
+            g.knn2 = (gp.knn2[0][r1], gp.knn2[1][r1])
+            g.knn1 = (gp.knn1[0][rn], gp.knn1[1][rn])
+            g.totals = torch.zeros(2, dtype=I64, device=dev)
+            g.tot1, g.tot2 = g.totals[0:1], g.totals[1:2]
+            g.ord1, g.ord2 = e(ops.sa_order_len(B, M1), dt=I32), e(ops.sa_order_len(B, M2), dt=I32)
+            g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1)))
+            g.ws1 = g.ws2 = g.nn_ws = None
+            g.ready = None
+            halves.append(g)
+        return gp, tuple(halves)
+
+    def _geometry_pair(self, xyz2, fps_start2, gp, halves):
+        """`_geometry` for two batches at once: xyz2 (2B,3,N), fps_start2 (2,2B); FPS, ball queries and 3-NN tables run on
+        the 2B plots in one launch each (into `gp`), the per-batch products (message totals, SA work items, inverted 3-NN
+        indices) per half.  Same tables as two `_geometry` calls."""
+        B2, _, N = xyz2.shape
+        B = B2 // 2
+        M1, M2 = self._sizes(N)
+        if (gp.B, gp.N) != (B2, N):
+            raise ValueError("geometry buffers do not match this batch pair")
+        ops.fps(xyz2, M1, fps_start2[0], out=(gp.idx1, gp.pos1_soa, gp.pos1_aos, gp.ws1))
+        ops.ball_query(xyz2, gp.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, gp.tot1, fps_ws=gp.ws1, out=(gp.nbr1, gp.cnt1))
+        ops.fps(gp.pos1_soa, M2, fps_start2[1], out=(gp.idx2, gp.pos2_soa, gp.pos2_aos, gp.ws2))
+        ops.ball_query(gp.pos1_soa, gp.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, gp.tot2, fps_ws=gp.ws2,
+                       out=(gp.nbr2, gp.cnt2))
+        ops.three_nn(gp.pos3, gp.pos2_soa, 1, out=gp.knn3)
+        ops.three_nn(gp.pos2_soa, gp.pos1_soa, 3, out=gp.knn2, ws=gp.nn_ws[0])
+        ops.three_nn(gp.pos1_soa, xyz2, 3, out=gp.knn1, ws=gp.nn_ws[1])
+        for h, g in enumerate(halves):
+            g.xyz = xyz2[h * B:(h + 1) * B]
+            ops.count_sum(g.cnt1, g.tot1)
+            ops.count_sum(g.cnt2, g.tot2)
+            ops.sa_order(g.cnt1, B, M1, out=g.ord1)
+            ops.sa_order(g.cnt2, B, M2, out=g.ord2)
+            ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
+            ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
+            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+        return halves
+
     def prefetch_geometry(self, cloud_data, lane: int = 0):
         """Run the position-only kernels of a batch on a side stream, ahead of time (typically for batch k+1 while
         batch k is in its backward pass: the FPS rounds are sequential and occupy one CU per plot, the feature kernels

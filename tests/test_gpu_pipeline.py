@@ -12,7 +12,7 @@ from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_ba
 pytestmark = pytest.mark.gpu
 
 
-def _setup(N, B, depth):
+def _setup(N, B, depth, n_slots=None):
     args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
     model = PointNet2(args)
     model.load_state_dict(network.init_state_dict(5))
@@ -24,7 +24,7 @@ def _setup(N, B, depth):
     # are about launch order and data movement, which a damped optimiser shows just as well.
     opt = FlatAdam(model, lr=1e-3, eps=1e-3, weight_decay=1e-3)
     slots = []
-    for j in range(depth + 1):
+    for j in range(n_slots or depth + 1):
         h = make_batch(B, N, first_plot=40 + j * B)
         slots.append({"cloud": h["cloud"].cuda(), "xyz": h["xyz"].cuda(),
                       "fps_start": torch.full((2, B), j, dtype=torch.int32, device="cuda"),
@@ -54,20 +54,24 @@ def _assert_same_losses(got, ref):
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("use_graph,split", [(False, False), (True, False), (True, True)])
-def test_pipeline_matches_plain_loop(use_graph, split):
-    N, B, depth, steps = 4096, 2, 2, 7
-    model, opt, slots, fstep = _setup(N, B, depth)
+@pytest.mark.parametrize("use_graph,split,pair", [(False, False, False), (True, False, False), (True, True, False),
+                                                  (False, False, True), (True, True, True)])
+def test_pipeline_matches_plain_loop(use_graph, split, pair):
+    """pair: one geometry pass per TWO batches (2*depth+2 slots), the mode bench.py runs."""
+    N, B, depth, steps = 4096, 2, 2, 9 if pair else 7
+    n_slots = 2 * depth + 2 if pair else depth + 1
+    model, opt, slots, fstep = _setup(N, B, depth, n_slots)
     ref_losses = []
     for i in range(steps):
-        l = fstep(slots[i % (depth + 1)])
+        l = fstep(slots[i % n_slots])
         opt.step()
         ref_losses.append(float(l.detach()))
     ref_params = model._flat_params.clone()
     ref_rm = model.fp1_module.nn[0][2].running_mean.clone()
 
-    model2, opt2, slots2, fstep2 = _setup(N, B, depth)
+    model2, opt2, slots2, fstep2 = _setup(N, B, depth, n_slots)
     pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=use_graph, split_exchange=split)
+    assert pipe.pair == pair
     pipe.capture()
     # capture() warms each slot with feature passes that update the BN running statistics but not the weights; reset
     # the model/optimiser state so both loops start equal
