@@ -34,7 +34,7 @@ class TrainPipeline:
         # (latency of a geometry pass under load) / (batches it covers x passes in flight), and the passes in flight are
         # limited by the hardware queues (three side streams + the main one).  Needs 2*depth+2 slots.
         if pair is None:
-            pair = len(slot_inputs) >= 2 * depth + 2 and len(slot_inputs) % 2 == 0 and hasattr(model, "alloc_geometry_pair")
+            pair = len(slot_inputs) >= 2 * depth + 2 and len(slot_inputs) % 2 == 0 and getattr(model, "alloc_geometry_pair", None) is not None
         self.pair = bool(pair)
         if len(slot_inputs) < (2 * depth + 2 if self.pair else depth + 1):
             raise ValueError("need at least depth+1 input slots (2*depth+2 in pair mode)")

@@ -63,6 +63,9 @@ class PointNet2ThreeSA(PointNet2):
         return self._sizes3(N)[:2]
 
     # ------------------------------------------------------------------------------------------ geometry
+    alloc_geometry_pair = None      # the two-batches-per-pass geometry of pipeline.TrainPipeline is built for the reference
+    _geometry_pair = None           # architecture only
+
     def alloc_geometry(self, B, N, device=None):
         dev = torch.device(device if device is not None else self.lin1.weight.device)
         M1, M2, M3 = self._sizes3(N)
