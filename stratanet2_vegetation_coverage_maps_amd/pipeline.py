@@ -6,6 +6,11 @@ POSITIONS only -- no weights, no features -- so for batch i+1, i+2 they can run 
 forward/backward.  That matters on MI355X because FPS is M strictly sequential rounds in ONE workgroup per plot: with
 16 plots per GPU it keeps 16 of 256 CUs busy for ~2 ms while the feature kernels (which fill the chip) need ~2 ms too.
 
+The step is bound by (latency of a geometry pass under load) / (batches a pass covers x passes in flight), and the passes
+in flight by the hardware queues (three side streams + the main one; more streams share queues and serialise).  FPS is
+one workgroup per plot, so a pass over TWO batches (32 plots) has the latency of a pass over one: in pair mode
+(2*depth+2 slots, the default of bench.py) every side-stream pass delivers the tables of two consecutive batches.
+
 Layout: `slots` = depth+1 sets of persistent buffers (inputs + `PointNet2.alloc_geometry`), `depth` side streams.
 
     side[j]  : wait slot_done[slot of batch i-1] ; geometry(batch i+depth) -> that slot     launched eagerly (10 kernels)
