@@ -18,6 +18,16 @@ Parity status
   `tests/golden/` were produced by `oracle/make_golden.py`, which imports that code from
   `/root/reference` in the build container and runs it; `oracle/network.py`, `oracle/projection.py` and
   `oracle/losses.py` are checked against those goldens by `tests/test_oracle_golden.py`.
+* Rows next to the hot path -- PINNED by `oracle/make_golden_aux.py`, which imports and RUNS the
+  reference's own numpy code in the build container and writes `tests/golden/f_*.npz`:
+    - `oracle/mosaic.py` (weights band, geotransform, the rasterio.merge callback in float32, hard medium-vegetation
+      band, finalisation) vs `inference/geotiff_raster.py:46-61,103-144,262-347`: bit for bit;
+    - `oracle/prepare.py::load_cloud` vs `data_loader/loader.py:73-255` under the same `numpy.random` seed: bit for bit
+      (also recorded in the fixture: the numpy-1.21-casting restatement and the loader under numpy 2.2 differ by 0.0);
+    - `oracle/prepare.py::normalize_z_with_minz_in_a_radius` vs `utils/load_data.py:237-249` on the real sklearn
+      kd-tree (points at exactly the radius, Lambert-sized coordinates): bit for bit.
+  `tests/test_oracle_golden_aux.py` holds the restatements to those fixtures; the `-m gpu` tests hold the HIP kernels to
+  the same fixtures.  Unpinned remainder: the rounding of a geotransform to integer pixel offsets (rasterio's job).
 * Third-party primitives (`oracle/primitives.py`): PARITY UNPINNED -- the reference holds no tests,
   fixtures or golden vectors and the wheels are absent and un-fetchable, so the
   primitives are restated from their published algorithms; every assumption is listed in the

@@ -1,11 +1,20 @@
 """CPU restatement of the parcel mosaic merge.  TEST INFRASTRUCTURE ONLY.
 
-Follows `/root/reference/inference/geotiff_raster.py`: `add_weights_band_to_rasters` (:103-118) and the pairwise
-`rasterio.merge` callback `_weighted_average_of_rasters` (:294-347), applied plot after plot on the parcel window
-(rasterio itself is absent; the placement rule of `get_geotransform` :46-61 is restated as integer pixel offsets).
-PARITY UNPINNED for the placement (rasterio's resampling is not available to check against); the merge arithmetic is
-restated operation for operation."""
+Follows `/root/reference/inference/geotiff_raster.py`: `add_weights_band_to_rasters` (:103-118), `get_geotransform`
+(:46-61), the pairwise `rasterio.merge` callback `_weighted_average_of_rasters` (:294-347) applied plot after plot on the
+parcel window, `insert_hard_med_veg_raster_band` (:119-144) and `finalize_merged_raster` (:262-285).
+
+PINNED: `tests/golden/f_mosaic.npz` holds the outputs of those reference functions themselves (run by
+`oracle/make_golden_aux.py` in the build container); `tests/test_oracle_golden_aux.py` holds this file to them bit for bit
+(merge in float32: the plot GeoTIFFs and hence rasterio.merge's canvas are Float32).  PARITY UNPINNED for one thing only:
+the rounding of a geotransform to integer pixel offsets, which rasterio (absent) does."""
 import numpy as np
+
+
+def get_geotransform(plot_center_xy, diam_meters, diam_pix):
+    """geotiff_raster.py:46-61: [x_min, pixel width, 0, y_max, 0, -pixel height] of a plot raster."""
+    return [plot_center_xy[0] - diam_meters // 2, diam_meters / diam_pix, 0,
+            plot_center_xy[1] + diam_meters // 2, 0, -diam_meters / diam_pix]
 
 
 def weights_band(diam_pix):
@@ -40,13 +49,15 @@ def merge_pair(old, new):
     return out
 
 
-def mosaic(rasters, offsets, H, W, diam_pix):
-    """rasters (B,3,D,D) with NaN, offsets (B,2) (row, col) -> (6,H,W) after merging the plots one by one."""
+def mosaic(rasters, offsets, H, W, diam_pix, dtype=np.float64):
+    """rasters (B,3,D,D) with NaN, offsets (B,2) (row, col) -> (6,H,W) after merging the plots one by one.
+    dtype=np.float32 is what the reference does (Float32 GeoTIFFs, geotiff_raster.py:79 => a float32 canvas in
+    rasterio.merge; numpy's promotions inside the callback follow from the same expressions); float64 is the yardstick."""
     w = weights_band(diam_pix)
-    acc = np.full((6, H, W), np.nan)
+    acc = np.full((6, H, W), np.nan, dtype=dtype)
     D = diam_pix
     for r, (oy, ox) in zip(rasters, offsets):
-        img = np.concatenate([r.astype(np.float64)] + [w[None]] * 3, 0)
+        img = np.concatenate([r] + [w[None]] * 3, 0).astype(dtype)
         win = acc[:, oy:oy + D, ox:ox + D]
         acc[:, oy:oy + D, ox:ox + D] = merge_pair(win, img)
     return acc

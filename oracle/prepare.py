@@ -1,5 +1,9 @@
 """CPU restatement of the offline preparation steps next to the hot path.  TEST INFRASTRUCTURE ONLY.
 
+PINNED: `tests/golden/f_load_cloud.npz` and `f_znorm.npz` hold what the reference's own `load_cloud` and
+`normalize_z_with_minz_in_a_radius` (on the real sklearn kd-tree) returned in the build container
+(`oracle/make_golden_aux.py`); `tests/test_oracle_golden_aux.py` holds this file to them bit for bit.
+
 `normalize_z_with_minz_in_a_radius` follows `/root/reference/utils/load_data.py:237-249`; sklearn's
 `NearestNeighbors(algorithm="kd_tree").radius_neighbors` is restated as what it computes: neighbours of point i are the
 points j whose float64 reduced distance (dx*dx + dy*dy) is <= radius*radius (inclusive)."""
@@ -30,8 +34,9 @@ def normalize_z_with_minz_in_a_radius(cloud, znorm_radius_in_meters):
 # ---------------------------------------------------------------------------------------------------------------------
 # load_cloud (`/root/reference/data_loader/loader.py:73-255`), restated with numpy 1.21's casting written out: under the
 # reference's pin a float32 array combined with a python / np.float64 SCALAR stays float32 (value-based casting), which
-# numpy >= 2 no longer does implicitly.  The random draws come from `rs` in the reference's order.  PARITY UNPINNED: the
-# reference's loader cannot run here (laspy / its dataset pickles are absent); each line cites the line it follows.
+# numpy >= 2 no longer does implicitly (python scalars stay weak under NEP 50, so the reference's own code gives the same
+# bits under numpy 2.2: recorded in the fixture).  The random draws come from `rs` in the reference's order.  Each line
+# cites the line it follows.
 # ---------------------------------------------------------------------------------------------------------------------
 def add_fake_empty_ground_points(diam_meters, n_input_feats, cloud):                      # :90-105
     x = np.arange(-diam_meters // 2, diam_meters // 2, 1) + 0.5                           # get_x_y_meshgrid :108-113

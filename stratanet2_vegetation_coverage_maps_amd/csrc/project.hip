@@ -273,6 +273,9 @@ namespace {
 __global__ void mosaic_merge_kernel(const float* __restrict__ rasters, const float* __restrict__ weights,
                                     const int* __restrict__ offsets, int B, int D, int H, int W,
                                     float* __restrict__ mean, float* __restrict__ wsum, int y0, int x0, int wh, int ww) {
+    // each product, sum and quotient rounded to fp32 on its own, as numpy does on the reference's float32 canvas (bit-exact
+    // against tests/golden/f_mosaic.npz): no fused multiply-add
+#pragma clang fp contract(off)
     const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int wy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int band = blockIdx.z;

@@ -97,7 +97,7 @@ class TrainPipeline:
                 # the next batch arrives from the host (pinned buffers): its copy into the slot rides on the side stream,
                 # in front of the geometry pass that reads it and behind the feature pass that last read the slot
                 for name, t in self.feeder(i).items():
-                    d[name].copy_(t, non_blocking=True)
+                    d[name].copy_(t, non_blocking=not getattr(self, 'feeder_blocking', False))
             self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k])
             self.geo_ready[k].record(st)
         self.issued = max(self.issued, i + 1)
@@ -119,7 +119,7 @@ class TrainPipeline:
                 d = self.inputs[k]
                 if self.feeder is not None:
                     for name, t in self.feeder(j).items():
-                        d[name].copy_(t, non_blocking=True)
+                        d[name].copy_(t, non_blocking=not getattr(self, 'feeder_blocking', False))
                 h = k - k0
                 self.xyz2[pb][h * B:(h + 1) * B].copy_(d["xyz"], non_blocking=True)
                 self.fs2[pb][:, h * B:(h + 1) * B].copy_(d["fps_start"], non_blocking=True)

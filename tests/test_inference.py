@@ -212,3 +212,76 @@ def test_fake_ground_points_rule():
     assert f.shape == (316, 2) and f.dtype == np.float32
     ref = prepare.add_fake_empty_ground_points(20, 10, np.zeros((10, 0), dtype=np.float32))
     assert ref.shape == (10, 316) and np.array_equal(ref[:2].T, f) and not ref[2:].any()
+
+
+# ---- the same kernels against fixtures produced by the reference's own numpy code (oracle/make_golden_aux.py)
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["merge_a", "merge_b"])
+def test_mosaic_merge_vs_reference_fixture(name):
+    """float32, bit for bit: the reference merges Float32 GeoTIFFs on a float32 canvas (geotiff_raster.py:79, 294-347)."""
+    from conftest import load_golden
+    from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
+    g = load_golden("f_mosaic")
+    H, W, D = (int(v) for v in g[f"{name}/HWD"])
+    r, off, want = g[f"{name}/rasters"], g[f"{name}/offsets"], g[f"{name}/canvas"]
+    dev = torch.device("cuda:0")
+    mean = torch.full((3, H, W), float("nan"), device=dev)
+    wsum = torch.full((3, H, W), float("nan"), device=dev)
+    wd = torch.from_numpy(inference.weights_band(D).astype(np.float32)).to(dev)
+    h = len(r) // 2
+    ops.mosaic_merge(torch.from_numpy(r[:h]).to(dev), wd, torch.from_numpy(off[:h]).to(dev), mean, wsum)
+    ops.mosaic_merge(torch.from_numpy(r[h:]).to(dev), wd, torch.from_numpy(off[h:]).to(dev), mean, wsum)
+    np.testing.assert_array_equal(mean.cpu().numpy(), want[:3])
+    np.testing.assert_array_equal(wsum.cpu().numpy(), want[3:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["finalize_a", "finalize_b"])
+def test_mosaic_finalize_vs_reference_fixture(name):
+    from conftest import load_golden
+    from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
+    g = load_golden("f_mosaic")
+    m, want = g[f"{name}/in"], g[f"{name}/out"]
+    dev = torch.device("cuda:0")
+    got, t = ops.mosaic_finalize(torch.from_numpy(m[:3].copy()).to(dev), torch.from_numpy(m[3].copy()).to(dev))
+    assert int(t[1]) == int(g[f"{name}/threshold_index"])
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_device_input_pipeline_vs_reference_loader_fixture(train):
+    """`sn2_prepare_plots` against what the reference's `load_cloud` returned under numpy.random.seed(7)."""
+    import types
+    from conftest import load_golden
+    from stratanet2_vegetation_coverage_maps_amd import input_pipeline
+    g = load_golden("f_load_cloud")
+    args = types.SimpleNamespace(diam_meters=20, z_max=24.24, subsample_size=int(g["subsample_size"]))
+    tag = "train" if train else "eval"
+    rs = np.random.RandomState(int(g["seed"]))
+    got = input_pipeline.prepare_batch([g[f"raw/{i}"] for i in range(3)], g["centers"], args, train, rs=rs, device="cuda:0")
+    for b in range(3):
+        gc, gx = got["cloud"][b].cpu().numpy(), got["xyz"][b].cpu().numpy()
+        wc, wx = g[f"{tag}/cloud/{b}"], g[f"{tag}/xyz/{b}"]
+        np.testing.assert_array_equal(gc[2:], wc[2:])
+        np.testing.assert_array_equal(gx[2], wx[2])
+        if train:       # the rotated x,y: a float64 product rounded to float32 (BLAS may fuse it): one float32 ulp
+            np.testing.assert_allclose(gx[:2], wx[:2], rtol=2e-7, atol=1e-6)
+            np.testing.assert_allclose(gc[:2], wc[:2], rtol=2e-7, atol=1e-7)
+        else:
+            np.testing.assert_array_equal(gx[:2], wx[:2])
+            np.testing.assert_array_equal(gc[:2], wc[:2])
+    assert rs.random() == float(g[f"{tag}/next_random"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["disc", "lambert", "lattice", "small_radius"])
+def test_znorm_vs_reference_on_sklearn_fixture(name):
+    from conftest import load_golden
+    from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
+    g = load_golden("f_znorm")
+    cloud, want = g[f"{name}/in"], g[f"{name}/out"]
+    xyz = torch.from_numpy(cloud[:3].copy()).cuda()
+    zmin, zout = ops.znorm(xyz, float(g[f"{name}/radius"]))
+    np.testing.assert_array_equal(zout.cpu().numpy(), want[2])
+    np.testing.assert_array_equal((cloud[2] - zmin.cpu().numpy()).astype(np.float32), want[2])
