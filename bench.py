@@ -2,6 +2,7 @@
 """bench.py -- plots/s of one full training step of the PointNet2 hot path on synthetic 32k-point plots.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            (no launcher: bench.py starts its N ranks itself, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -22,7 +23,53 @@ import os
 import sys
 import time
 
-import torch
+
+def _spawn_ranks_if_needed():
+    """`python bench.py --gpus N` typed as is (no launcher): start the N ranks as fresh child processes -- one per GPU,
+    the same environment torch.distributed.run would give them -- wait, and exit with their worst return code.  Runs
+    before torch or the HIP library are imported: this process never touches a GPU, so starting children is safe."""
+    if "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        if os.environ.get("SN2_BENCH_LAUNCH_CHECK"):       # tests/test_host_api.py: what environment did the rank get?
+            print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}),
+                  flush=True)
+            sys.exit(0 if os.environ["SN2_BENCH_LAUNCH_CHECK"] != "fail" or os.environ["RANK"] != "1" else 3)
+        return
+    p = argparse.ArgumentParser(add_help=False)
+    p.add_argument("--gpus", type=int, default=1)
+    n = p.parse_known_args()[0].gpus
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    while procs:
+        time.sleep(0.2)
+        for pr in list(procs):
+            code = pr.poll()
+            if code is None:
+                continue
+            procs.remove(pr)
+            if code != 0:
+                rc = rc or code
+                for other in procs:          # a rank died: the others would wait in a collective forever
+                    other.terminate()
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    _spawn_ranks_if_needed()
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -195,7 +242,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     # rehearsal knobs (never set by the driver): all ranks on one device / the gloo backend, to run the N > 1 code path on
     # a one-GPU box
     if os.environ.get("SN2_BENCH_ONE_DEVICE"):

@@ -214,6 +214,9 @@ typedef struct sn2_head {
     float *dy;                      /* backward out: d loss / d (fa*f+fc) (R,f_stride)                           */
     float *dW1, *db1, *dW2, *db2;   /* ACCUMULATED                                                               */
     int grad_replicas, grad_replica_stride; /* images of the four gradients, as in sn2_block                            */
+    const int *drop_mask;           /* F.dropout between lin1 and lin2 (model/point_net2.py:142) in training: (R) words,
+                                       bit j set = hidden channel j of the row is KEPT; NULL = no dropout (eval, p = 0) */
+    float drop_scale;               /* 1/(1-p) applied to the kept channels (0 when p = 1)                         */
 } sn2_head;
 int sn2_head_forward(const sn2_head *p, void *stream);
 int sn2_head_backward(const sn2_head *p, void *stream);

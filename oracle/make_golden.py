@@ -34,6 +34,11 @@ CASES = {
     # two plots, C2-style radii (1 m / 2 m), non-zero FPS starts
     "b2_c2_style": dict(B=2, N=2048, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0,
                         first_plot=100, starts=([17, 1203], [5, 0])),
+    # the WELL-CONDITIONED gradient case: reference defaults at config-1's plot size, four plots, so that every BatchNorm
+    # sees >= 1000 rows (B*M2 = 1024).  `well_conditioned`: generation FAILS unless the reference's own fp32 gradients agree
+    # with its fp64 gradients to 1e-3 of each tensor's magnitude -- the tests then hold the HIP gradients to a flat 1e-3.
+    "b4_well_conditioned": dict(B=4, N=2048, ratio1=0.5, r1=1.0, ratio2=0.25, r2=2.0,
+                                first_plot=510, starts=([11, 222, 1333, 2000], [1, 20, 300, 1000]), well_conditioned=True),
 }
 
 
@@ -67,13 +72,18 @@ def main():
     from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
 
     os.makedirs(OUT, exist_ok=True)
+    only = [a for a in argv[1:] if a in CASES]
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
+        if os.environ.get("SN2_GOLDEN_FIRST_PLOT"):            # search aid for a well-conditioned case
+            c = dict(c, first_plot=int(os.environ["SN2_GOLDEN_FIRST_PLOT"]))
         args = make_args(subsample_size=c["N"], ratio1=c["ratio1"], r1=c["r1"], ratio2=c["ratio2"], r2=c["r2"])
         data = make_batch(c["B"], c["N"], first_plot=c["first_plot"])
         starts = c["starts"]
         provider = lambda b, n, call: starts[call][b]          # noqa: E731
 
-        torch.manual_seed(0)
+        torch.manual_seed(int(os.environ.get("SN2_GOLDEN_SEED", c.get("weight_seed", 0))))
         model = PointNet2(args)
         # perturb BN affine/running stats so eval-mode parity is not trivially the identity
         g = torch.Generator().manual_seed(1234)
@@ -132,7 +142,10 @@ def main():
         model64 = model64.double().train()
         P.set_fps_start_provider(provider)
         cov64, proba64 = model64({"cloud": data["cloud"].double(), "xyz": data["xyz"]})
-        pred64 = project_to_plotwise_coverages(cov64, data["cloud"].double(), args)
+        # pixel ids from the fp32 cloud, as in the fp32 run: an fp64 cloud here moves border points into other pixels,
+        # i.e. a different arg-max routing -- a different function, not a more precise evaluation of the same one (that
+        # was the 1e-2..1e-1 "ill-conditioning" of round 1's N = 4096 goldens)
+        pred64 = project_to_plotwise_coverages(cov64, data["cloud"], args)
         l_abs = LF.get_absolute_loss(pred64, data["coverages"])
         l_log, _ = LF.get_NLL_loss(proba64, data["cloud"].double(), args)
         l_e = LF.get_entropy_loss(proba64)
@@ -141,6 +154,11 @@ def main():
             out[f"grad64/{k}"] = p.grad.numpy()
         out["train64/coverages_pointwise"] = cov64.detach().numpy()
         P.set_fps_start_provider(None)
+        worst = max((float(np.abs(out[f"grad/{k}"] - out[f"grad64/{k}"]).max() / np.abs(out[f"grad64/{k}"]).max()), k)
+                    for k, _ in model.named_parameters())
+        print(f"{name}: worst fp32-vs-fp64 gradient discrepancy of the reference itself: {worst[0]:.2e} ({worst[1]})")
+        if c.get("well_conditioned"):
+            assert worst[0] <= 1e-3, f"{name} is not well conditioned: pick other plots / start points"
 
         path = os.path.join(OUT, f"{name}.npz")
         np.savez_compressed(path, **out)

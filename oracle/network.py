@@ -82,9 +82,11 @@ def _fps_regular(pos_long, B, n, ratio, start):
 
 
 def forward(sd: Dict[str, torch.Tensor], cloud: torch.Tensor, xyz: torch.Tensor, args, training: bool,
-            fps_start: Optional[Sequence[torch.Tensor]] = None, use_kdtree: bool = False, details: bool = False):
+            fps_start: Optional[Sequence[torch.Tensor]] = None, use_kdtree: bool = False, details: bool = False,
+            dropout_mask: Optional[torch.Tensor] = None):
     """cloud (B,10,N), xyz (B,3,N) fp32 CPU tensors (the DataLoader collate of `loader.py:73-87`).
     fps_start = (start1 (B,), start2 (B,)) LOCAL start indices of the two FPS calls (None -> 0).
+    dropout_mask (B*N,16), non-zero = keep: the mask F.dropout (point_net2.py:142) would have drawn (None: torch draws).
     Returns (coverages_pointwise (B*N,4), proba_pointwise (B*N,4), extras) where extras holds the new BN
     running statistics (training) and, with details=True, the intermediate tensors."""
     B, _, N = cloud.shape
@@ -133,7 +135,12 @@ def forward(sd: Dict[str, torch.Tensor], cloud: torch.Tensor, xyz: torch.Tensor,
 
     # ---- head (:141-151)
     h = F.relu(F.linear(f1, sd["lin1.weight"], sd["lin1.bias"]))
-    h = F.dropout(h, p=args.drop, training=training)
+    if dropout_mask is not None and training and args.drop > 0:
+        # F.dropout with the Bernoulli(1-p) keep-mask handed in (so that the checker and the kernels see the same mask):
+        # kept elements are scaled by 1/(1-p), the others are zero (torch.nn.functional.dropout; p = 1 gives zeros)
+        h = h * (dropout_mask != 0).to(h.dtype) * (1.0 / (1.0 - args.drop) if args.drop < 1 else 0.0)
+    else:
+        h = F.dropout(h, p=args.drop, training=training)
     scores = F.linear(h, sd["lin2.weight"], sd["lin2.bias"])
     proba = torch.softmax(scores[:, :4], dim=1)
     density = torch.sigmoid(scores[:, 4:5])

@@ -42,7 +42,7 @@ class Head(Structure):  # sn2_head
                 ("fc", c_void_p), ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
                 ("coverages", c_void_p), ("proba", c_void_p), ("dcoverages", c_void_p), ("dproba", c_void_p),
                 ("dy", c_void_p), ("dW1", c_void_p), ("db1", c_void_p), ("dW2", c_void_p), ("db2", c_void_p),
-                ("grad_replicas", c_int), ("grad_replica_stride", c_int)]
+                ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("drop_mask", c_void_p), ("drop_scale", c_float)]
 
 
 # name -> argtypes; every entry point returns int (0 ok, >0 hipError_t, <0 argument error)

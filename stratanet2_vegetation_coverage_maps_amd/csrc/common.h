@@ -37,6 +37,25 @@ __device__ __forceinline__ int sn2_grad_image(int replicas, int stride) {
 
 static inline int sn2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- clearing a buffer.  Always a KERNEL, never hipMemsetAsync: every entry point may be captured into a hipGraph, and on
+// this runtime (ROCm 7.2) a captured memset NODE is only right on the FIRST replay -- from the second replay on it fills
+// the buffer with whatever its recycled argument block holds (scripts/debug_graph_d2h.py::memset_node: buf := 0; buf += 1
+// reads 1 once, then 97736275787777 = a pointer-looking word + 1).  That was round 1's NaN loss under `bench.py
+// --host-inputs`: the key table of the plot-wise projection came back "cleared" to garbage, empty pixels decoded to NaN;
+// it stayed hidden in the resident mode only because the stale block still held zeros until a device-to-host copy
+// reused it.  A kernel node carries its arguments with it and is ordered like any other node.
+#ifdef __HIPCC__
+static __global__ __launch_bounds__(256) void sn2_fill_words_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+static inline void sn2_fill_words(void* p, uint32_t v, size_t nwords, hipStream_t st) {
+    if (nwords == 0) return;
+    int grid = sn2_cdiv((long)nwords, 256 * 4);
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    hipLaunchKernelGGL(sn2_fill_words_kernel, dim3(grid), dim3(256), 0, st, (uint32_t*)p, v, nwords);
+}
+#endif
+
 // compute units of the current device (256 on MI355X), for the grids of the persistent kernels
 static inline int sn2_cu_count() {
     static int n = 0;

@@ -1455,8 +1455,11 @@ struct HeadOut {
     float dens;
 };
 
+// drop_mask / drop_scale: F.dropout(relu(lin1), p) of model/point_net2.py:142 -- bit j of the row's word set = channel j kept
+// and scaled by 1/(1-p); drop_mask == nullptr: no dropout.  z1 holds the values lin2 reads (after the dropout).
 __device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, cfp fa, cfp fc, cfp W1, cfp b1, cfp W2,
-                                         cfp b2, size_t r, HeadOut& o) {
+                                         cfp b2, size_t r, HeadOut& o, const int* __restrict__ drop_mask = nullptr,
+                                         float drop_scale = 1.f) {
     const float4* fr = reinterpret_cast<const float4*>(f + r * f_stride);
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
@@ -1473,6 +1476,11 @@ __device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stri
 #pragma unroll
         for (int k = 0; k < 34; ++k) acc = fmaf(W1[j * 34 + k], o.y[k], acc);
         o.z1[j] = fmaxf(acc, 0.f);
+    }
+    if (drop_mask) {
+        const int keep = drop_mask[r];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o.z1[j] = ((keep >> j) & 1) ? o.z1[j] * drop_scale : 0.f;
     }
     o.z1[16] = 1.f;
     float s[5];
@@ -1499,11 +1507,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int R, int f_stride, cons
                                                        const float* __restrict__ fa, const float* __restrict__ fc,
                                                        const float* __restrict__ W1, const float* __restrict__ b1,
                                                        const float* __restrict__ W2, const float* __restrict__ b2,
-                                                       float* __restrict__ cov, float* __restrict__ proba) {
+                                                       float* __restrict__ cov, float* __restrict__ proba,
+                                                       const int* __restrict__ drop_mask, float drop_scale) {
     for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
         HeadOut o;
         head_row(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), opaque(as_const(W1)), opaque(as_const(b1)),
-                 opaque(as_const(W2)), opaque(as_const(b2)), (size_t)r, o);
+                 opaque(as_const(W2)), opaque(as_const(b2)), (size_t)r, o, drop_mask, drop_scale);
         reinterpret_cast<float4*>(proba)[r] = make_float4(o.p[0], o.p[1], o.p[2], o.p[3]);
         reinterpret_cast<float4*>(cov)[r] = make_float4(o.p[0] * o.dens, o.p[1] * o.dens, o.p[2] * o.dens, o.p[3] * o.dens);
     }
@@ -1518,7 +1527,8 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
                                                        const float* __restrict__ dcov, const float* __restrict__ dproba,
                                                        float* __restrict__ dy, float* __restrict__ dW1,
                                                        float* __restrict__ db1, float* __restrict__ dW2,
-                                                       float* __restrict__ db2, int rep_k, int rep_stride) {
+                                                       float* __restrict__ db2, int rep_k, int rep_stride,
+                                                       const int* __restrict__ drop_mask, float drop_scale) {
     using Acc2 = OuterAcc<16, 17, 32>;  // rows 0..4 = d scores, rest zero;  Q = [z1 | 1]
     using Acc1 = OuterAcc<16, 35, 32>;  // d pre-activation of lin1;          Q = [y | 1]
     // 4 waves per workgroup, 4 workgroups per CU (4 waves per SIMD: the row loads are 144-byte strided, only occupancy
@@ -1540,7 +1550,7 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
         const cfp W1 = opaque(as_const(W1g)), W2 = opaque(as_const(W2g));
         HeadOut o;
         head_row(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), W1, opaque(as_const(b1)), W2,
-                 opaque(as_const(b2)), rr, o);
+                 opaque(as_const(b2)), rr, o, drop_mask, drop_scale);
         float gc[4] = {0.f, 0.f, 0.f, 0.f}, gp[4] = {0.f, 0.f, 0.f, 0.f};
         if (dcov) {
             const float4 v = reinterpret_cast<const float4*>(dcov)[rr];
@@ -1570,7 +1580,8 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
             float a = 0.f;
 #pragma unroll
             for (int i = 0; i < 5; ++i) a = fmaf(W2[i * 16 + j], ds[i], a);
-            dpre[j] = o.z1[j] > 0.f ? a : 0.f;
+            // through the dropout (kept: x scale) and the ReLU: z1 > 0 exactly where the channel is kept AND active
+            dpre[j] = o.z1[j] > 0.f ? a * drop_scale : 0.f;
         }
         acc1.add(lds1, dpre, o.y);
         if (valid) {
@@ -1679,7 +1690,8 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     SN2_TRY(check_head(p));
     if (!p->coverages || !p->proba) return SN2_EINVAL;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f_stride,
-                       p->f, p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba);
+                       p->f, p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba, p->drop_mask,
+                       p->drop_mask ? p->drop_scale : 1.f);
     SN2_RETURN_LAUNCH();
 }
 
@@ -1714,6 +1726,6 @@ extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
                        p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
-                       p->db2, p->grad_replicas, p->grad_replica_stride);
+                       p->db2, p->grad_replicas, p->grad_replica_stride, p->drop_mask, p->drop_mask ? p->drop_scale : 1.f);
     SN2_RETURN_LAUNCH();
 }

@@ -1236,7 +1236,7 @@ extern "C" int sn2_znorm(const float* x, const float* y, const float* z, int n, 
     int* start = hist + ncell;                       // ncell + 1
     int* cursor = start + ncell + 1;                 // ncell
     float4* sorted = reinterpret_cast<float4*>(ws + (((size_t)n + 3 * (size_t)ncell + 1 + 3) & ~(size_t)3));   // 16-byte aligned
-    if (hipMemsetAsync(hist, 0, (size_t)ncell * sizeof(int), st) != hipSuccess) return SN2_EINVAL;
+    sn2_fill_words(hist, 0u, (size_t)ncell, st);
     const int blocks = sn2_cdiv(n, 256);
     hipLaunchKernelGGL(znorm_cell_kernel, dim3(blocks), dim3(256), 0, st, x, y, n, x_min, y_min, inv, GX, GY, cell, hist);
     hipLaunchKernelGGL(znorm_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)hist, ncell, start, cursor);

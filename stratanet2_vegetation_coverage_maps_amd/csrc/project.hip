@@ -32,10 +32,14 @@ __device__ __forceinline__ int p1_pix(float v, float sf, float off, int D) {
     return i < 0 ? 0 : (i > D - 1 ? D - 1 : i);
 }
 
+// also clears the plot's (pixel, channel) key table for the scatter kernel that follows (see sn2_fill_words in common.h
+// for why this is not a hipMemsetAsync)
 __global__ __launch_bounds__(1024) void plot_minmax_kernel(const float* __restrict__ xy, long plot_stride, int N,
-                                                           float* __restrict__ mm) {
+                                                           float* __restrict__ mm, unsigned long long* __restrict__ keys,
+                                                           int ncell3) {
     __shared__ float s[4][16];
     const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < ncell3; i += 1024) keys[(size_t)b * ncell3 + i] = 0ull;
     const float* x = xy + (size_t)b * plot_stride;
     const float* y = x + N;
     float xmn = INFINITY, xmx = -INFINITY, ymn = INFINITY, ymx = -INFINITY;
@@ -230,9 +234,7 @@ extern "C" int sn2_plot_project_forward(const float* pred_pointwise, const float
     hipStream_t st = (hipStream_t)stream;
     // the first 4*B floats of `pred` double as the per-plot (xmin,xmax,ymin,ymax) scratch until the finalisation
     float* mm = pred;
-    hipError_t e = hipMemsetAsync(keys, 0, (size_t)B * D * D * 3 * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(plot_minmax_kernel, dim3(B), dim3(1024), 0, st, cloud_xy, plot_stride, N, mm);
+    hipLaunchKernelGGL(plot_minmax_kernel, dim3(B), dim3(1024), 0, st, cloud_xy, plot_stride, N, mm, keys, D * D * 3);
     hipLaunchKernelGGL((scatter_max_kernel<0>), dim3(grid_slices(N), B), dim3(1024), (size_t)D * D * 3 * 8, st,
                        pred_pointwise, cloud_xy, plot_stride, N, D, (const float*)mm, 0.f, 0.f, keys, pix);
     hipLaunchKernelGGL(p2_finalize_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long*)keys, D, arg, nocc, pred);
@@ -255,8 +257,7 @@ extern "C" int sn2_raster_project(const float* coverages, const float* cloud_xy,
     hipStream_t st = (hipStream_t)stream;
     const float sf = (float)(10.0 * ((double)D / (double)diam_meters));  // python: 10 * (diam_pix / diam_meters)
     const float off = (float)(diam_meters / 2);                           // diam_meters // 2
-    hipError_t e = hipMemsetAsync(keys, 0, (size_t)B * D * D * 3 * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return (int)e;
+    sn2_fill_words(keys, 0u, (size_t)B * D * D * 3 * 2, st);
     hipLaunchKernelGGL((scatter_max_kernel<1>), dim3(grid_slices(N), B), dim3(1024), (size_t)D * D * 3 * 8, st, coverages,
                        cloud_xy, plot_stride, N, D, (const float*)nullptr, sf, off, keys, pix);
     hipLaunchKernelGGL(p1_finalize_kernel, dim3(sn2_cdiv((long)B * D * D * 3, 256)), dim3(256), 0, st,
@@ -448,8 +449,8 @@ extern "C" int sn2_mosaic_finalize(const float* mean, const float* wsum, int H, 
     if (!mean || !wsum || !hist_ws || !sum_ws || !thr_out || !out || H <= 0 || W <= 0) return SN2_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const long P = (long)H * W;
-    if (hipMemsetAsync(hist_ws, 0, (size_t)SN2_MOSAIC_HIST_WORDS * sizeof(int), st) != hipSuccess) return SN2_EINVAL;
-    if (hipMemsetAsync(sum_ws, 0, sizeof(double), st) != hipSuccess) return SN2_EINVAL;
+    sn2_fill_words(hist_ws, 0u, (size_t)SN2_MOSAIC_HIST_WORDS, st);
+    sn2_fill_words(sum_ws, 0u, 2, st);
     int grid = sn2_cdiv(P, 256);
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(hard_hist_kernel, dim3(grid), dim3(256), 0, st, mean + P, P, hist_ws, sum_ws);

@@ -157,7 +157,7 @@ extern "C" int sn2_sa_order(const int* cnt, int B, int M, int* order, void* stre
     if (!cnt || !order || B <= 0 || M <= 0) return SN2_EINVAL;
     if (M > 16384) return SN2_ELIMIT;                     // the plot's counts must fit LDS
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(order, 0xFF, SN2_SA_ORDER_WORDS(B, M) * sizeof(int), st) != hipSuccess) return SN2_EINVAL;   // all -1
+    sn2_fill_words(order, 0xFFFFFFFFu, (size_t)SN2_SA_ORDER_WORDS(B, M), st);                                      // all -1
     hipLaunchKernelGGL(sa_order_kernel, dim3(sn2_cdiv(M, 256), B), dim3(256), (size_t)M * 4, st, cnt, B, M, order);
     SN2_RETURN_LAUNCH();
 }

@@ -533,8 +533,16 @@ def plot_max_backward(dout, arg, B, R_per_plot, C, dy):
     _call("sn2_plot_max_backward", _ptr(dout), _ptr(arg), B, R_per_plot, C, _ptr(dy), _stream())
 
 
+def dropout_mask_words(keep: torch.Tensor) -> torch.Tensor:
+    """keep (R,16) bool / 0-1 values (True = the hidden channel survives F.dropout) -> (R) int32 words, bit j = channel j."""
+    if keep.dim() != 2 or keep.shape[1] != 16:
+        raise ValueError("dropout mask must be (rows, 16)")
+    pow2 = (2 ** torch.arange(16, device=keep.device, dtype=torch.int32))
+    return ((keep != 0).to(torch.int32) * pow2).sum(1, dtype=torch.int32).contiguous()
+
+
 def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dproba=None, dy=None, grads=None,
-              grad_images=(1, 0)) -> Head:
+              grad_images=(1, 0), drop_mask=None, drop_p: float = 0.0) -> Head:
     R = f.shape[0]
     _chk(f, F32, (R, 36), "f")
     _chk(fa, F32, (34,), "fa")
@@ -562,6 +570,11 @@ def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dpro
     else:
         d.dW1 = d.db1 = d.dW2 = d.db2 = None
         d.grad_replicas, d.grad_replica_stride = 1, 0
+    if drop_mask is not None:
+        _chk(drop_mask, I32, (R,), "drop_mask")
+        d.drop_mask, d.drop_scale = _ptr(drop_mask), (1.0 / (1.0 - drop_p) if drop_p < 1.0 else 0.0)
+    else:
+        d.drop_mask, d.drop_scale = None, 1.0
     return d
 
 

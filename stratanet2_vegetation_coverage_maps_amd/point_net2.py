@@ -28,7 +28,7 @@ from torch.nn import Sequential as Seq
 from . import hip_ops as ops
 from ._lib import MAX_NEIGHBORS as _MAXN, STAT_SLOTS, StrataHipError
 
-MAX_NEIGHBORS = int(os.environ.get('SN2_DEBUG_CAP', _MAXN))  # debug knob only; the reference value is 2000
+MAX_NEIGHBORS = _MAXN      # radius(..., max_num_neighbors=2000), model/point_net2.py:24 (tests lower it by monkeypatching)
 
 F32, I32, I64, F64 = torch.float32, torch.int32, torch.int64, torch.float64
 
@@ -91,11 +91,12 @@ class _PointNet2Fn(torch.autograd.Function):
     gradients, the kernels read them through the modules (same storage)."""
 
     @staticmethod
-    def forward(ctx, model, xyz, cloud, fps_start, geo, *params):
+    def forward(ctx, model, xyz, cloud, fps_start, geo, drop_keep, *params):
         training = model.training
-        need_grad = any(ctx.needs_input_grad[5:])   # grad mode is off inside Function.forward; this is the reliable test
-        cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training, geo)
+        need_grad = any(ctx.needs_input_grad[6:])   # grad mode is off inside Function.forward; this is the reliable test
+        cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training, geo, drop_keep)
         ctx.model = model
+        saved.training = training
         ctx.saved = saved if need_grad else None
         ctx.n_params = len(params)
         return cov, proba
@@ -104,9 +105,14 @@ class _PointNet2Fn(torch.autograd.Function):
     def backward(ctx, dcov, dproba):
         if ctx.saved is None:
             raise RuntimeError("PointNet2: backward through a forward that recorded no graph")
+        if not ctx.saved.training:
+            # the backward kernels implement the BATCH-statistics BatchNorm gradient; after an eval-mode forward the right
+            # gradient is the running-statistics one (a*dy), which they do not compute: refuse instead of being wrong
+            raise RuntimeError("PointNet2: backward through an eval-mode forward is not supported by the HIP kernels "
+                               "(call model.train() for the forward pass whose gradients you need)")
         grads = ctx.model._backward_impl(ctx.saved, dcov, dproba)
         ctx.saved = None
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class PointNet2(nn.Module):
@@ -156,8 +162,6 @@ class PointNet2(nn.Module):
         if cloud.dim() != 3 or cloud.shape[1] != self.n_input_feats + 2 or xyz.shape != (cloud.shape[0], 3, cloud.shape[2]):
             raise ValueError(f"expected cloud (B,{self.n_input_feats + 2},N) and xyz (B,3,N), got "
                              f"{tuple(cloud.shape)} and {tuple(xyz.shape)}")
-        if self.training and self.drop > 0:
-            raise NotImplementedError("dropout p > 0 (reference default 0.0, config.py:76) is not in the HIP head yet")
         with torch.cuda.device(dev):
             cloud_d = cloud.to(device=dev, dtype=F32, non_blocking=True).contiguous()
             geo = cloud_data.get("geometry", None) if isinstance(cloud_data, dict) else None
@@ -176,8 +180,26 @@ class PointNet2(nn.Module):
                 xyz_d, fs = self._stage_positions(cloud_data, dev)
             self._last_cloud_dev = (cloud, cloud_d)  # lets project_to_plotwise_coverages skip a second H2D copy
             params = [p for p in self.parameters()]
-            cov, proba = _PointNet2Fn.apply(self, xyz_d, cloud_d, fs, geo, *params)
+            cov, proba = _PointNet2Fn.apply(self, xyz_d, cloud_d, fs, geo, self._dropout_keep(cloud_data, cloud_d), *params)
         return cov, proba
+
+    def _dropout_keep(self, cloud_data, cloud_d):
+        """F.dropout(x, p=self.drop, training=self.training) between lin1 and lin2 (model/point_net2.py:142): the (B*N) words
+        of kept hidden channels for the head kernels, or None (eval mode, p = 0).  The mask is drawn on the device from
+        torch's generator (Bernoulli(1-p) per element, as F.dropout draws it; torch's own CUDA dropout stream is not
+        reproducible across devices either); additive extension for parity tests: `cloud_data["dropout_mask"]`, a
+        (B*N,16) tensor, non-zero = keep."""
+        if not (self.training and self.drop > 0):
+            return None
+        R = cloud_d.shape[0] * cloud_d.shape[2]
+        keep = cloud_data.get("dropout_mask", None) if isinstance(cloud_data, dict) else None
+        if keep is None:
+            keep = torch.empty(R, 16, dtype=F32, device=cloud_d.device).bernoulli_(max(0.0, 1.0 - float(self.drop)))
+        else:
+            keep = torch.as_tensor(keep).to(device=cloud_d.device)
+            if tuple(keep.shape) != (R, 16):
+                raise ValueError(f"dropout_mask must have shape ({R},16)")
+        return ops.dropout_mask_words(keep)
 
     def _sizes(self, N):
         M1 = ops.fps_num_samples(N, self.sa1_module.ratio)
@@ -358,7 +380,7 @@ class PointNet2(nn.Module):
             raise ValueError(f"fps_start must have shape (2,{B})")
         return xyz_d, fs
 
-    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None):
+    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None, drop_keep=None):
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
@@ -411,7 +433,9 @@ class PointNet2(nn.Module):
         # ---- head                                                                  (:141-151)
         cov = torch.empty(B * N, 4, dtype=F32, device=dev)
         proba = torch.empty(B * N, 4, dtype=F32, device=dev)
-        ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba))
+        s.drop_keep = drop_keep
+        ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, drop_mask=drop_keep,
+                                       drop_p=self.drop))
         if training:
             torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)], 1)
         return cov, proba, s
@@ -461,7 +485,7 @@ class PointNet2(nn.Module):
         dy1 = torch.empty(B * N, 36, dtype=F32, device=dev)
         hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
         hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg,
-                           grad_images=images)
+                           grad_images=images, drop_mask=getattr(s, "drop_keep", None), drop_p=self.drop)
         ops.head_backward(hd)
         # FP1's BatchNorm gradients fall out of lin1's (hip_ops.head_bn_sums): no extra pass over the B*N rows
         bn1 = self.fp1_module.nn[0][2]

@@ -133,7 +133,7 @@ class PointNet2ThreeSA(PointNet2):
         return xyz_d, fs
 
     # ------------------------------------------------------------------------------------------ forward
-    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None):
+    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None, drop_keep=None):
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2, M3 = self._sizes3(N)
@@ -179,7 +179,9 @@ class PointNet2ThreeSA(PointNet2):
         s.h1 = e(B * N, 36)
         ops.fp_forward(self._fp1_desc(s), training)
         cov, proba = e(B * N, 4), e(B * N, 4)
-        ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba))
+        s.drop_keep = drop_keep
+        ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, drop_mask=drop_keep,
+                                       drop_p=self.drop))
         if training:
             torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)], 1)
         return cov, proba, s
@@ -215,7 +217,7 @@ class PointNet2ThreeSA(PointNet2):
         dy1 = e(B * N, 36)
         hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
         hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg,
-                           grad_images=images)
+                           grad_images=images, drop_mask=getattr(s, "drop_keep", None), drop_p=self.drop)
         ops.head_backward(hd)
         bn_ok = torch.empty(4, dtype=I32, device=dev)
 

@@ -14,6 +14,15 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # On a GPU box: start a forkserver NOW, before anything in this process initialises the GPU (device_count() does not).
+    # tests/test_gpu_distributed.py forks its ranks from it, so every rank is a clean process -- never a fork or an exec of
+    # a process that already holds the GPU.
+    if torch.cuda.device_count() > 0:
+        import multiprocessing
+        from multiprocessing import forkserver
+        multiprocessing.get_context("forkserver")
+        forkserver.set_forkserver_preload([])
+        forkserver.ensure_running()
 
 
 def pytest_collection_modifyitems(config, items):
@@ -41,4 +50,4 @@ def golden_args(name):
     return make_args(subsample_size=c["N"], ratio1=c["ratio1"], r1=c["r1"], ratio2=c["ratio2"], r2=c["r2"])
 
 
-GOLDEN_CASES = ["c1_ref_defaults", "b2_ref_defaults", "b2_c2_style"]
+GOLDEN_CASES = ["c1_ref_defaults", "b2_ref_defaults", "b2_c2_style", "b4_well_conditioned"]

@@ -63,17 +63,26 @@ def test_train_step_vs_reference_golden(name):
     np.testing.assert_allclose(proba.detach().cpu().numpy(), g["train/proba_pointwise"], atol=TOL, rtol=0)
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g["train/pred_coverages"], atol=TOL, rtol=0)
     np.testing.assert_allclose([loss.item()] + [p.item() for p in parts], g["train/losses"], atol=TOL, rtol=0)
-    # gradients: against the reference run with fp64 features/weights (same fp32 geometry); accepted error per
-    # parameter = 1e-3 of its magnitude, or twice the reference's OWN fp32-vs-fp64 discrepancy where that is larger
-    # (single-plot BatchNorms over 256 rows and near-tied pixel maxima make some of these gradients ill-conditioned)
+    # gradients: against the reference run with fp64 features/weights (same fp32 geometry and pixel ids) = the yardstick.
+    # `self_err` = the reference's OWN fp32-vs-fp64 discrepancy per tensor.  Where the case is well conditioned
+    # (b4_well_conditioned is generated under the assertion self_err <= 1e-3 for every tensor; b2_c2_style has 1e-5) the
+    # bound is a flat 1e-3 of the tensor's magnitude.  The N = 4096 reference-default cases are NOT well conditioned at
+    # default-initialised weights: rarely active ReLU channels get BatchNorm outputs of ~100 sigma, and a relative
+    # perturbation of 1e-8 of the weights -- in fp64 -- already moves the gradients by 3e-3 (scripts/cond_probe.py), so no
+    # fp32 evaluation can be held to 1e-3 there; the bound is the reference's own discrepancy.  The measured error of every
+    # tensor is printed (pytest -s shows it; on failure it is part of the message).
+    report, worst = [], 0.0
     for k, p in m.named_parameters():
         ref32, ref64 = g[f"grad/{k}"], g[f"grad64/{k}"]
         assert p.grad is not None, k
         scale = np.abs(ref64).max()
         self_err = np.abs(ref32 - ref64).max() / scale
-        tol = max(1e-3, 2.0 * self_err)
+        tol = max(1e-3, 1.0 * self_err)
         err = np.abs(p.grad.cpu().numpy() - ref64).max() / scale
-        assert err <= tol, f"{k}: rel err {err:.3e} > tol {tol:.3e} (reference fp32-vs-fp64 {self_err:.3e})"
+        report.append(f"{k:42s} err {err:.2e}  tol {tol:.2e}  reference fp32-vs-fp64 {self_err:.2e}{'  <-- FAIL' if err > tol else ''}")
+        worst = max(worst, err / tol)
+    print(f"\n[{name}] parameter gradients vs the reference's fp64 run (relative to max |grad|):\n  " + "\n  ".join(report))
+    assert worst <= 1.0, "\n".join(report)
     sd = m.state_dict()
     for k in sd:
         if "running_" in k:
@@ -355,3 +364,62 @@ def test_training_forward_is_bit_reproducible(B, N):
         if ref is None:
             ref = got
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("p_drop", [0.3, 0.5])
+def test_dropout_in_the_head_vs_oracle_with_the_same_mask(p_drop):
+    """F.dropout between lin1 and lin2 (/root/reference/model/point_net2.py:142, args.drop, config.py:76): with the keep-mask
+    handed in (`cloud_data["dropout_mask"]`, additive extension) forward, loss and gradients equal the oracle's; eval mode
+    ignores it; without a mask the kernel draws Bernoulli(1-p) per element from torch's generator."""
+    B, N = 2, 3000
+    args = make_args(subsample_size=N, ratio1=0.1, r1=1.0, ratio2=0.25, r2=2.0, drop=p_drop)
+    d = make_batch(B, N, first_plot=200)
+    sd = network.init_state_dict(3)
+    fs = torch.zeros(2, B, dtype=torch.long)
+    keep = torch.rand(B * N, 16, generator=torch.Generator().manual_seed(9)) >= p_drop
+    d["fps_start"], d["dropout_mask"] = fs, keep
+    m = _model(args, sd).train()
+    cov, proba = m(d)
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+    loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
+    loss.backward()
+    sd_r = {k: v.clone() for k, v in sd.items()}
+    for k in network.param_keys(sd_r):
+        sd_r[k].requires_grad_(True)
+    cov_r, proba_r, _ = network.forward(sd_r, d["cloud"], d["xyz"], args, training=True, fps_start=(fs[0], fs[1]),
+                                        dropout_mask=keep)
+    pred_r = projection.project_to_plotwise_coverages(cov_r, d["cloud"], args)
+    loss_r, _ = losses.total_loss(pred_r, proba_r, d["coverages"], d["pdf_all"], args.m, args.e)
+    loss_r.backward()
+    np.testing.assert_allclose(cov.detach().cpu().numpy(), cov_r.detach().numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(proba.detach().cpu().numpy(), proba_r.detach().numpy(), atol=TOL, rtol=0)
+    assert abs(loss.item() - loss_r.item()) < TOL
+    for k, p in m.named_parameters():
+        ref = sd_r[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-6 + 1e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+    # the mask matters (the no-dropout outputs differ), eval mode ignores it, and the built-in draw keeps ~(1-p)
+    no_drop = _model(make_args(subsample_size=N, ratio1=0.1, r1=1.0, ratio2=0.25, r2=2.0, drop=0.0), sd).train()
+    cov0, _ = no_drop({k: v for k, v in d.items() if k != "dropout_mask"})
+    assert (cov0 - cov).abs().max() > 1e-3
+    m2 = _model(args, sd).eval()
+    with torch.no_grad():
+        c_eval, _ = m2(d)
+        c_eval0, _ = no_drop.eval()({k: v for k, v in d.items() if k != "dropout_mask"})
+    assert torch.equal(c_eval, c_eval0)
+    words = m.train()._dropout_keep({"cloud": d["cloud"]}, d["cloud"].cuda())
+    kept = sum(int(((words >> j) & 1).sum()) for j in range(16)) / (16 * B * N)
+    assert abs(kept - (1 - p_drop)) < 0.01
+    torch.manual_seed(1)
+    a, _ = m(dict(cloud=d["cloud"], xyz=d["xyz"], fps_start=fs))
+    torch.manual_seed(1)
+    b, _ = m(dict(cloud=d["cloud"], xyz=d["xyz"], fps_start=fs))
+    assert torch.equal(a, b) and torch.isfinite(a).all()          # reproducible under torch's seed
+
+
+def test_backward_through_an_eval_forward_is_refused():
+    args = make_args(subsample_size=1024, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(1, 1024)
+    m = _model(args, network.init_state_dict(0)).eval()
+    cov, _ = m(d)
+    with pytest.raises(RuntimeError, match="eval-mode forward"):
+        cov.sum().backward()

@@ -96,33 +96,58 @@ def test_pipeline_matches_plain_loop(use_graph, split, pair):
     np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(), ref_rm.cpu().numpy(), atol=5e-4)   # one update more or less: 1e-2
 
 
-def test_pipeline_with_host_feeder_matches_resident_inputs():
-    """Batches fed from (pinned) host memory on the side streams give the same losses as the same batches resident in the
-    slots; the slot tensors start out zeroed, so a copy that came too late or not at all would show."""
-    N, B, depth, steps = 4096, 2, 2, 6
-    model, opt, slots, fstep = _setup(N, B, depth)
-    pipe = TrainPipeline(model, opt, fstep, slots, depth=depth, use_graph=True)
-    pipe.capture()
-    model.load_state_dict(network.init_state_dict(5))
-    opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_dev.zero_()
-    pipe.prime()
-    ref = [float(pipe.step().detach()) for _ in range(steps)]
-    pipe.drain()
-    torch.cuda.synchronize()
+@pytest.mark.parametrize("pair", [False, True])
+def test_pipeline_with_host_feeder_matches_plain_loop(pair):
+    """Batches fed from pinned host memory on the side streams (the way a DataLoader user of
+    /root/reference/learning/train.py:33-44 would feed the pipeline) give the losses of the plain loop over the same
+    batches.  Built to hit what round 1's `bench.py --host-inputs` NaN needed: hipGraph replays, pair mode (2*depth+2 slots,
+    one geometry pass per two batches), host sources created AFTER the capture with `.cpu()` (a device-to-host copy between
+    capture and replay), more DISTINCT batches than slots (a slot gets new data on every reuse; the slots start zeroed), and
+    a spin kernel in front of every geometry pass so that the feature passes really wait on `geo_ready`."""
+    N, B, depth = 4096, 2, 2
+    n_slots = 2 * depth + 2 if pair else depth + 1
+    n_host, steps = n_slots + 3, 2 * n_slots + 3
+    batches = [make_batch(B, N, first_plot=40 + j * B) for j in range(n_host)]
 
-    model2, opt2, slots2, fstep2 = _setup(N, B, depth)
-    host = [{k: v.cpu().pin_memory() for k, v in sl.items() if k in ("cloud", "xyz", "gt", "pdf")} for sl in slots2]
-    pipe2 = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=True)
-    pipe2.capture()
+    model, opt, slots, fstep = _setup(N, B, depth, n_slots)
+    ref = []
+    for i in range(steps):
+        h = batches[i % n_host]
+        inp = {"cloud": h["cloud"].cuda(), "xyz": h["xyz"].cuda(), "gt": h["coverages"].cuda(), "pdf": h["pdf_all"].cuda(),
+               "fps_start": torch.full((2, B), i % n_slots, dtype=torch.int32, device="cuda")}
+        l = fstep(inp)
+        opt.step()
+        ref.append(float(l.detach()))
+
+    model2, opt2, slots2, fstep2 = _setup(N, B, depth, n_slots)
+    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=True)
+    assert pipe.pair == pair
+    pipe.capture()
+    # AFTER the capture: device-to-host copies + pinning (the order bench.py --host-inputs uses)
+    dev_batches = [{"cloud": h["cloud"].cuda(), "xyz": h["xyz"].cuda(), "gt": h["coverages"].cuda(), "pdf": h["pdf_all"].cuda()}
+                   for h in batches]
+    host = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in dev_batches]
     for sl in slots2:                                   # wipe the resident copies: the feeder must bring the data
         for k in ("cloud", "xyz", "gt", "pdf"):
             sl[k].zero_()
     model2.load_state_dict(network.init_state_dict(5))
     opt2.exp_avg.zero_(); opt2.exp_avg_sq.zero_(); opt2.step_dev.zero_()
-    pipe2.issued = pipe2.done = 0
-    pipe2.set_feeder(lambda i: host[i % len(host)])
-    pipe2.prime()
-    got = [float(pipe2.step().detach()) for _ in range(steps)]
-    pipe2.drain()
+    pipe.issued = pipe.done = 0
+    pipe.set_feeder(lambda i: host[i % n_host])
+    issue = pipe.issue_geometry
+
+    def delayed(i=None):
+        for st in pipe.side:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(2_000_000)            # ~1 ms in front of whatever that side stream does next
+        return issue(i)
+    pipe.issue_geometry = delayed
+    pipe.prime()
+    out = torch.zeros(steps, dtype=torch.float64, device="cuda")
+    for i in range(steps):                              # no host synchronisation inside the loop
+        out[i] = pipe.step().detach()
+    pipe.drain()
     torch.cuda.synchronize()
+    got = out.cpu().tolist()
+    assert all(np.isfinite(got)), got
     _assert_same_losses(got, ref)

@@ -69,3 +69,26 @@ def test_no_oracle_import_in_product():
         if fn.endswith(".py"):
             txt = open(os.path.join(root, fn)).read()
             assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher: N child processes, rank/world/rendezvous set as torch.distributed.run
+    would; a failing rank makes the launcher exit non-zero.  (SN2_BENCH_LAUNCH_CHECK: the ranks only report and exit.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SN2_BENCH_LAUNCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["RANK"])
+    assert [d["RANK"] for d in got] == ["0", "1", "2"] and all(d["WORLD_SIZE"] == "3" for d in got)
+    assert all(d["LOCAL_RANK"] == d["RANK"] and d["MASTER_ADDR"] == "127.0.0.1" for d in got)
+    assert len({d["MASTER_PORT"] for d in got}) == 1
+    env["SN2_BENCH_LAUNCH_CHECK"] = "fail"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 3
