@@ -12,7 +12,7 @@ lib = ctypes.CDLL(so)
 B, N, M = 16, 32768, 1024
 xyz = make_batch(B, N)["xyz"].cuda()
 idx = torch.empty(B, M, dtype=torch.int32, device="cuda"); cs = torch.empty(B, 3, M, device="cuda"); ca = torch.empty(B * M, 4, device="cuda")
-ws = torch.empty(5 * B * N, dtype=torch.int32, device="cuda")
+ws = torch.empty(5 * B * N + 4104 * B, dtype=torch.int32, device="cuda")
 lib.sn2_fps.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
 def run():
     rc = lib.sn2_fps(xyz.data_ptr(), B, N, M, None, idx.data_ptr(), cs.data_ptr(), ca.data_ptr(), ws.data_ptr(), None)
@@ -24,9 +24,23 @@ t = time.perf_counter(); run(); torch.cuda.synchronize(); el = time.perf_counter
 lib.sn2_debug_fps_stamps(out)
 d = [out[i] - base[i] for i in range(8)]
 rounds = d[6]
-names = ["(a) tests", "(b) dirty loop", "(c) wave reduce+publish", "barrier wait", "(d) select/next sample"]
-tot = sum(d[:5])
-print(f"wall {el*1e3:.3f} ms for {rounds} rounds (stamped build); wave0: dirty buckets/round {d[5]/rounds:.2f}, tie rounds {d[7]}")
-for n, v in zip(names, d[:5]):
-    print(f"  {n:28s} {v/rounds:8.1f} ticks/round  {100*v/tot:5.1f}%")
-print(f"  total {tot/rounds:.1f} ticks/round (s_memtime ticks: 100 MHz? see guide) ")
+if os.environ.get("SN2_FPS_SPECULATE", "1") != "0":
+    names = ["(A) tests", "(B) dirty buckets", "(D) select + accept (wave 0)", "barrier waits"]
+    tot = sum(d[:4])
+    print(f"wall {el*1e3:.3f} ms for {rounds} super-rounds, {d[4]} samples = {d[4]/rounds:.2f} per super-round (stamped build); "
+          f"wave 0: dirty buckets/super-round {d[5]/rounds:.2f}, tie searches {d[7]}")
+    for n, v in zip(names, d[:4]):
+        print(f"  {n:30s} {v/rounds:8.1f} ticks/super-round  {100*v/tot:5.1f}%")
+    print(f"  total {tot/rounds:.1f} ticks/super-round = {tot/d[4]:.1f} per sample (s_memtime ticks = shader clocks)")
+    o2 = (ctypes.c_ulonglong * 32)()
+    lib.sn2_debug_fps_stamps2(o2)
+    print("  accepted per super-round (both runs), histogram 0..16:", list(o2[:17]))
+    print("  why the prefix ended: tie/hidden %d, not above next max %d, own second max %d, an earlier bucket's second max %d, K reached %d, "
+          "touched by an earlier sample %d" % tuple(o2[17:23]))
+else:
+    names = ["(a) tests", "(b) dirty loop", "(c) wave reduce+publish", "barrier wait", "(d) select/next sample"]
+    tot = sum(d[:5])
+    print(f"wall {el*1e3:.3f} ms for {rounds} rounds (stamped build); wave0: dirty buckets/round {d[5]/rounds:.2f}, tie rounds {d[7]}")
+    for n, v in zip(names, d[:5]):
+        print(f"  {n:28s} {v/rounds:8.1f} ticks/round  {100*v/tot:5.1f}%")
+    print(f"  total {tot/rounds:.1f} ticks/round (s_memtime ticks: 100 MHz)")

@@ -2,6 +2,7 @@
 // All discrete decisions use the canonical fp32 squared distance sn2_d2 (common.h) so that the index structures
 // are bit-identical to the oracle's.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------------
 // pack_rows: (cloud (B,C,N), xyz (B,3,N)) -> rows0 (B*N,12) = [cloud rows 2..9 | x y z 0]
@@ -265,6 +266,10 @@ __device__ __forceinline__ void fps_st_dist(float4* t, int p, float v) { reinter
 #ifdef SN2_FPS_STAMPS
 // diagnostic build only (never shipped): per-phase cycle totals of wave 0 of workgroup 0
 __device__ unsigned long long g_fps_dbg[8];
+__device__ unsigned long long g_fps_dbg2[32];
+extern "C" int sn2_debug_fps_stamps2(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fps_dbg2), sizeof(g_fps_dbg2));
+}
 #define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
 extern "C" int sn2_debug_fps_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fps_dbg), sizeof(g_fps_dbg));
@@ -482,6 +487,389 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(const float* __rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Speculative bucketed FPS (exact; round 2).  fps_bucket_kernel above pays, for EVERY sample, a sequential chain of
+// test -> L2 load -> update -> wave reduction -> LDS exchange -> barrier -> arg-max (1.75 us per round at N = 32768, of
+// which the 16-wave barrier + exchange + selection are more than half).  But consecutive FPS samples are far apart:
+// sample t only lowers distances inside the ball of radius sqrt(D_t(max)) around it, and the next maxima sit in other
+// holes of the sampling.  So one SUPER-ROUND accepts up to K samples from one arg-max pass:
+//   let m_0 > m_1 > ... be the bucket maxima in strictly decreasing order, c_e the point attaining m_e.  c_0 is the next
+//   sample.  c_e (e >= 1) is the sample after c_0..c_{e-1}  iff  (1) m_e is strictly larger than every other bucket
+//   maximum left (m_e > m_{e+1}) and than the second-largest distance of its own bucket and of the buckets of
+//   c_0..c_{e-1} (their other points only ever get smaller), and (2) c_e itself is untouched by c_0..c_{e-1}:
+//   sn2_d2(c_e, c_j) >= m_e for all j < e (then fminf(D(c_e), d2) == D(c_e) bit for bit).  Under (1)+(2) c_e is the
+//   unique arg-max of the running distances after the first e samples were applied -- without applying them.
+//   The accepted prefix c_0..c_{j-1} is then applied to the dirty buckets in ONE pass (a bucket is loaded once and
+//   min-ed with the samples whose box test it fails), and the barriers, the exchange and the arg-max are paid once per
+//   super-round instead of once per sample.  Exact ties anywhere (equal maxima, duplicated points) end the prefix; a tie
+//   for m_0 takes the lowest-ORIGINAL-index search of the old kernel.  Indices are bit-identical to the brute-force
+//   kernel and to the oracle (tests/test_gpu_geometry.py), whatever K is.
+// Per super-round: all waves test + update their dirty buckets and refresh (max, second max, arg-max point) of those
+// buckets in LDS; barrier; wave 0 alone extracts the K+1 largest maxima (three sorted heads per lane, DPP wave max),
+// runs the acceptance tests (lane e = candidate e), emits the samples; barrier.
+// ------------------------------------------------------------------------------------------------------------
+// wave64 max with the DPP modifier fused into v_max_f32 (the update_dpp builtin above costs a v_mov, a v_mov_dpp, an
+// s_nop and the v_max per step: 24 instructions per reduction; this is 12).  All 64 lanes must be active.
+__device__ __forceinline__ float wave_max_fused(float v) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int SPW, int NW, int K>
+__global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restrict__ pos, int N, int M,
+                                                        const int* __restrict__ start, const int* __restrict__ order,
+                                                        float4* sorted, int* __restrict__ idx_out,
+                                                        float* __restrict__ cpos_soa, float* __restrict__ cpos_aos) {
+    constexpr int NBK = SPW * NW;
+    constexpr int SL = (SPW + 63) / 64;                // bucket slots per lane of the owning wave
+    constexpr int T = 4;                               // maxima every wave hands to the final selection
+    static_assert(SPW <= 128 && NW <= 16 && K >= 2 && K <= 16 && NW * T <= 64 && SPW >= T, "limits");
+    extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
+    float4* s_pt = reinterpret_cast<float4*>(fps_smem);            // [NBK] arg-max point of the bucket: x, y, z, sorted position
+    float4* s_acc = s_pt + NBK;                                    // [K] accepted samples of this super-round
+    float* s_box = reinterpret_cast<float*>(s_acc + K);            // [6][NBK] bucket boxes, [component][wave][slot]
+    float* s_val = s_box + 6 * NBK;                                // [NBK] largest running distance of the bucket (-1: empty)
+    float* s_max2 = s_val + NBK;                                   // [NBK] >= the second largest (== s_val: treated as a tie)
+    unsigned* s_q = reinterpret_cast<unsigned*>(s_max2 + NBK);     // [NBK] work queue of a super-round: bucket | samples << 11
+    float2* s_top = reinterpret_cast<float2*>(s_q + NBK);          // [NW*T] per-wave maxima: (value, bucket | place << 16)
+    int* s_ctl = reinterpret_cast<int*>(s_top + NW * T);           // [0] accepted (0: tie search), [1] done, [2] tie value, [3] queue length
+    unsigned* s_win = reinterpret_cast<unsigned*>(s_ctl + 4);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* px = pos + (size_t)b * 3 * N;
+    const float* py = px + N;
+    const float* pz = py + N;
+    const int* ord = order + (size_t)b * N;
+    float4* pts = sorted + (size_t)b * N;              // (x, y, z, running distance = +inf from spatial_order_kernel)
+    float* my_box = s_box + wave * SPW;                // + component * NBK + slot; bucket of (wave, slot) = slot * NW + wave
+    for (int k = 0; k < SPW; ++k) {
+        const int p = (k * NW + wave) * 64 + lane;     // position in the sorted order (bucket k*NW + wave)
+        const bool v = p < N;
+        const float4 q = v ? pts[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float lx = -wave_max_fused(v ? -q.x : -INFINITY), ly = -wave_max_fused(v ? -q.y : -INFINITY),
+                    lz = -wave_max_fused(v ? -q.z : -INFINITY);
+        const float hx = wave_max_fused(v ? q.x : -INFINITY), hy = wave_max_fused(v ? q.y : -INFINITY),
+                    hz = wave_max_fused(v ? q.z : -INFINITY);
+        if (lane == 0) {
+            my_box[0 * NBK + k] = lx; my_box[1 * NBK + k] = ly; my_box[2 * NBK + k] = lz;
+            my_box[3 * NBK + k] = hx; my_box[4 * NBK + k] = hy; my_box[5 * NBK + k] = hz;
+        }
+    }
+    for (int g = tid; g < NBK; g += NW * 64) {
+        s_val[g] = g * 64 < N ? INFINITY : -1.f;       // every real bucket is dirty for the first sample
+        s_max2[g] = -1.f;
+    }
+    int cur = start ? start[b] : 0;
+    cur = cur < 0 ? 0 : (cur >= N ? N - 1 : cur);
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    // the accepted samples of the current super-round live in lanes 0..j-1 of (ax, ay, az) in EVERY wave
+    float ax = px[cur], ay = py[cur], az = pz[cur];
+    int j = 1, cnt = 1;
+    int* out_idx = idx_out + (size_t)b * M;            // sorted positions are stored as -1 - position and translated at the end
+    if (tid == 0) {
+        out_idx[0] = cur;
+        cpos_soa[((size_t)b * 3 + 0) * M] = ax;
+        cpos_soa[((size_t)b * 3 + 1) * M] = ay;
+        cpos_soa[((size_t)b * 3 + 2) * M] = az;
+        reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M] = make_float4(ax, ay, az, 0.f);
+        s_ctl[3] = 0;
+    }
+    if (M <= 1) return;
+    __syncthreads();
+
+    while (true) {
+        STAMP(t0);
+        // (A) which of this wave's buckets can change, and through which of the j samples?  lane = bucket slot.  Dirty
+        // buckets go into ONE queue of the workgroup, so that (B) can deal them out evenly: with the buckets tied to their
+        // waves the slowest wave had twice the average load and the others waited for it.
+#pragma unroll
+        for (int h = 0; h < SL; ++h) {
+            const int sl = 64 * h + lane;
+            unsigned sm = 0u;
+            if (sl < SPW) {
+                const float b0 = my_box[0 * NBK + sl], b1 = my_box[1 * NBK + sl], b2 = my_box[2 * NBK + sl];
+                const float b3 = my_box[3 * NBK + sl], b4 = my_box[4 * NBK + sl], b5 = my_box[5 * NBK + sl];
+                const float mx = s_val[sl * NW + wave];
+                for (int k = 0; k < j; ++k) {
+                    const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), k));
+                    const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), k));
+                    const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), k));
+                    if (sn2_box_d2(b0, b1, b2, b3, b4, b5, sx, sy, sz) < mx) sm |= 1u << k;
+                }
+            }
+            const unsigned long long bal = __ballot(sm != 0u);
+            if (bal) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ctl[3], __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (sm != 0u) s_q[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =
+                    (unsigned)(sl * NW + wave) | (sm << 11);
+            }
+        }
+        STAMP(t1);
+        __syncthreads();
+        // (B) the queue, four entries per wave in flight: new distances; if the bucket's maximum (or its holder) moved, the
+        // new (max, second max, arg-max point) go to LDS
+        const int qn = s_ctl[3];
+        constexpr int QD = 4;                            // queue entries per wave in flight (8 measured no faster: the phase is VALU-bound)
+        for (int i0 = wave; i0 < qn; i0 += QD * NW) {
+            unsigned ent[QD];
+            int p[QD];
+            bool on[QD];
+            float4 q[QD];
+            float U[QD];
+#pragma unroll
+            for (int u = 0; u < QD; ++u) {
+                const int i = i0 + u * NW;
+                on[u] = i < qn;
+                ent[u] = s_q[on[u] ? i : 0];
+                const int g = (int)(ent[u] & 2047u);
+                p[u] = g * 64 + lane;
+                q[u] = pts[p[u] < N ? p[u] : 0];
+                U[u] = s_val[g];
+            }
+#pragma unroll
+            for (int u = 0; u < QD; ++u) {
+                if (!on[u]) continue;
+                const int g = (int)(ent[u] & 2047u);
+                unsigned sm = ent[u] >> 11;
+                const float d0 = q[u].w;
+                float nd = d0;
+                while (sm) {
+                    const int k = __ffs(sm) - 1;
+                    sm &= sm - 1;
+                    const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), k));
+                    const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), k));
+                    const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), k));
+                    nd = fminf(nd, sn2_d2(q[u].x, q[u].y, q[u].z, sx, sy, sz));
+                }
+                const bool real = p[u] < N;
+                const bool changed = real && nd < d0;
+                if (changed) fps_st_dist(pts, p[u], nd);
+                // nothing of the bucket's maximum moved (no changed point held it): its (max, point) stand, and its
+                // second-max entry stays an UPPER bound of the true one, which is all the acceptance tests need
+                if (__ballot(changed && d0 == U[u]) == 0ull && U[u] != INFINITY) continue;
+                if (!real) nd = -1.f;                               // padding lanes of the last bucket never win
+                const float m1 = wave_max_fused(nd);
+                const unsigned long long bal = __ballot(nd == m1);
+                const int first = __ffsll((long long)bal) - 1;
+                float m2 = m1;
+                if (__popcll(bal) == 1) m2 = wave_max_fused(nd == m1 ? -1.f : nd);
+                const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[u].x), first));
+                const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[u].y), first));
+                const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[u].z), first));
+                if (lane == 0) {
+                    s_val[g] = m1;
+                    s_max2[g] = m2;
+                    s_pt[g] = make_float4(fx, fy, fz, __int_as_float(g * 64 + first));
+                }
+            }
+        }
+        STAMP(t2);
+        __syncthreads();
+        STAMP(t3);
+        // (C) every wave: the T largest maxima of its own buckets, in order -> s_top
+        {
+            float v[SL];
+            int gid[SL];
+#pragma unroll
+            for (int h = 0; h < SL; ++h) {
+                const int sl = 64 * h + lane;
+                gid[h] = sl * NW + wave;
+                v[h] = sl < SPW ? s_val[gid[h]] : -2.f;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float lm = v[0];
+#pragma unroll
+                for (int h = 1; h < SL; ++h) lm = fmaxf(lm, v[h]);
+                const float m = wave_max_fused(lm);
+                const int owner = __ffsll((long long)__ballot(lm == m)) - 1;
+                int hh = SL - 1;
+#pragma unroll
+                for (int h = SL - 2; h >= 0; --h) hh = v[h] == m ? h : hh;
+                const int gsel = __builtin_amdgcn_readlane(gid[0] + hh * 64 * NW, owner);
+                if (lane == owner) {
+#pragma unroll
+                    for (int h = 0; h < SL; ++h) if (h == hh) v[h] = -3.f;
+                }
+                if (lane == 0) s_top[wave * T + t] = make_float2(m, __int_as_float(gsel | (t << 16)));
+            }
+        }
+        __syncthreads();
+        STAMP(t4);
+        // (D) wave 0: the K+1 largest of the NW*T values in order, acceptance tests, emission
+        if (wave == 0) {
+            const float2 tp = s_top[lane < NW * T ? lane : 0];
+            float val = lane < NW * T ? tp.x : -3.f;
+            const int tg = __float_as_int(tp.y);
+            // (measured: ranking the 64 entries by compare-and-count, 5 instructions per entry and lane, is slower than these
+            // K+1 reduction chains: 7800 against 6000 clocks per super-round at K = 8)
+            float cm = -4.f;                  // lane e: value of candidate e
+            int cg = 0;                       //         its bucket
+            bool cbad = true;                 //         tie with another bucket / its wave has no further known value
+#pragma unroll
+            for (int e = 0; e <= K; ++e) {
+                const float m = wave_max_fused(val);
+                const unsigned long long bal = __ballot(val == m);
+                const int owner = __ffsll((long long)bal) - 1;
+                const int g = __builtin_amdgcn_readlane(tg, owner);
+                if (lane == e) {
+                    cm = m;
+                    cg = g & 0xFFFF;
+                    cbad = (__popcll(bal) > 1) || ((g >> 16) >= T - 1);
+                }
+                if (lane == owner) val = -3.f;
+            }
+            const float mnext = __shfl_down(cm, 1);
+            const bool isc = lane < K;
+            const float4 pt = s_pt[isc ? cg : 0];
+            const float mx2 = s_max2[isc ? cg : 0];
+            bool ok = isc && !cbad && cm > mnext && mx2 < cm && cm > 0.f;
+#ifdef SN2_FPS_STAMPS
+            bool touched = false;
+#endif
+#pragma unroll
+            for (int e = 0; e < K - 1; ++e) {
+                const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.x), e));
+                const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.y), e));
+                const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.z), e));
+                const float jm2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx2), e));
+                if (e < lane && (sn2_d2(pt.x, pt.y, pt.z, jx, jy, jz) < cm || jm2 >= cm)) ok = false;
+#ifdef SN2_FPS_STAMPS
+                if (e < lane && sn2_d2(pt.x, pt.y, pt.z, jx, jy, jz) < cm) touched = true;
+#endif
+            }
+            const unsigned long long okm = __ballot(ok);
+            int nj = __ffsll((long long)~okm) - 1;             // length of the accepted prefix
+            nj = nj > K ? K : nj;
+#ifdef SN2_FPS_STAMPS
+            if (b == 0) {
+                // why did the prefix end at candidate nj?  1 tie/hidden, 2 not above the next maximum, 3 own second max,
+                // 4 touched by an earlier sample or an earlier bucket's second max, 5 K reached
+                int why = 5;
+                if (nj < K) {
+                    const bool c1 = cbad, c2 = !(cm > mnext), c3 = !(mx2 < cm);
+                    const int w = c1 ? 1 : (c2 ? 2 : (c3 ? 3 : (touched ? 6 : 4)));
+                    why = __builtin_amdgcn_readlane(w, nj);
+                }
+                if (lane == 0) { g_fps_dbg2[nj] += 1; g_fps_dbg2[16 + why] += 1; }
+            }
+#endif
+            const int rem = M - cnt;
+            nj = nj > rem ? rem : nj;
+            if (lane < nj) {
+                s_acc[lane] = make_float4(pt.x, pt.y, pt.z, 0.f);
+                out_idx[cnt + lane] = -1 - __float_as_int(pt.w);
+                cpos_soa[((size_t)b * 3 + 0) * M + cnt + lane] = pt.x;
+                cpos_soa[((size_t)b * 3 + 1) * M + cnt + lane] = pt.y;
+                cpos_soa[((size_t)b * 3 + 2) * M + cnt + lane] = pt.z;
+                reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M + cnt + lane] = make_float4(pt.x, pt.y, pt.z, 0.f);
+            }
+            if (lane == 0) {
+                s_ctl[0] = nj;
+                s_ctl[1] = (cnt + (nj > 0 ? nj : 1) >= M) ? 1 : 0;
+                s_ctl[2] = __builtin_amdgcn_readlane(__float_as_int(cm), 0);
+                s_ctl[3] = 0;
+                *s_win = 0xFFFFFFFFu;
+            }
+        }
+        STAMP(t5);
+        __syncthreads();
+        j = s_ctl[0];
+        const int done = s_ctl[1];
+#ifdef SN2_FPS_STAMPS
+        STAMP(t6);
+        if (b == 0 && tid == 0) {
+            g_fps_dbg[0] += t1 - t0;
+            g_fps_dbg[1] += t2 - t1;
+            g_fps_dbg[2] += t5 - t3;
+            g_fps_dbg[3] += (t3 - t2) + (t6 - t5);
+            g_fps_dbg[4] += (unsigned long long)(j > 0 ? j : 1);
+            g_fps_dbg[5] += (unsigned long long)qn;
+            g_fps_dbg[6] += 1;
+            g_fps_dbg[7] += j == 0 ? 1 : 0;
+        }
+#endif
+        if (j > 0) {
+            const float4 a = s_acc[lane < j ? lane : 0];
+            ax = a.x; ay = a.y; az = a.z;
+        } else {
+            // exact tie of the maximal distance (duplicated points, ...): lowest ORIGINAL index among all points attaining it
+            const float V = __int_as_float(s_ctl[2]);
+#pragma unroll
+            for (int h = 0; h < SL; ++h) {
+                const int sl = 64 * h + lane;
+                unsigned long long cand = __ballot(sl < SPW && s_val[sl * NW + wave] == V);
+                while (cand) {
+                    const int kk = 64 * h + __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const int pp = (kk * NW + wave) * 64 + lane;
+                    const float d = pp < N ? pts[pp].w : -1.f;
+                    unsigned oi = 0xFFFFFFFFu;
+                    if (d == V) oi = (unsigned)ord[pp];
+                    oi = wave_min_u32_dpp(oi);
+                    if (lane == 0) atomicMin(s_win, oi);
+                }
+            }
+            __syncthreads();
+            cur = __builtin_amdgcn_readfirstlane((int)*s_win);
+            ax = px[cur]; ay = py[cur]; az = pz[cur];
+            if (tid == 0) {
+                out_idx[cnt] = cur;
+                cpos_soa[((size_t)b * 3 + 0) * M + cnt] = ax;
+                cpos_soa[((size_t)b * 3 + 1) * M + cnt] = ay;
+                cpos_soa[((size_t)b * 3 + 2) * M + cnt] = az;
+                reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M + cnt] = make_float4(ax, ay, az, 0.f);
+            }
+            j = 1;
+        }
+        cnt += j;
+        if (done) break;
+    }
+    // sorted positions -> original indices (kept out of the loop: the load would sit on wave 0's critical path)
+    __syncthreads();
+    for (int i = tid; i < M; i += NW * 64) {
+        const int v = out_idx[i];
+        if (v < 0) out_idx[i] = ord[-1 - v];
+    }
+}
+
+template <int SPW, int NW, int K>
+static size_t fps_spec_lds_bytes() {
+    return (size_t)(SPW * NW) * 16 + (size_t)K * 16 + (size_t)(SPW * NW) * 4 * 9 + (size_t)NW * 4 * 8 + 32;
+}
+
+#ifndef SN2_FPS_K
+#define SN2_FPS_K 8       // samples a super-round may accept (measured at 16 x 32768 -> 1024: 4.9 accepted on average with 8, 5.5
+                          // with 12, 5.6 with 16 -- the prefix mostly ends at a candidate touched by an earlier one -- while
+                          // the selection's cost grows with K)
+#endif
+// SN2_FPS_SPECULATE=0 in the environment selects the one-sample-per-round kernel (cross-checks and timing comparisons
+// only; both produce the same indices).
+static bool fps_use_speculation() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SN2_FPS_SPECULATE");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <int SPW, int NW = 16>
 static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* start, int* ws, int* idx, float* cs,
                              float* ca, hipStream_t st) {
@@ -490,6 +878,15 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
     int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
     hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid);
+    if (fps_use_speculation()) {
+        constexpr int K = SN2_FPS_K;
+        const size_t lds = fps_spec_lds_bytes<SPW, NW, K>();
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_spec_kernel<SPW, NW, K>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((fps_spec_kernel<SPW, NW, K>), dim3(B), dim3(NW * 64), lds, st, pos, N, M, start, (const int*)order,
+                           sorted, idx, cs, ca);
+        SN2_RETURN_LAUNCH();
+    }
     hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), 0, st, pos, N, M, start, (const int*)order,
                        sorted, idx, cs, ca);
     SN2_RETURN_LAUNCH();

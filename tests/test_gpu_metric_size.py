@@ -3,9 +3,8 @@ forward, plot-wise projection, loss and every parameter gradient against the ora
 canonical fp32 tests), for the reference architecture and for the 3sa variant.  References to match:
 /root/reference/model/point_net2.py:106-153, learning/train.py:52-64.
 
-Gradient yardstick: the oracle run again with fp64 features and weights (same fp32 geometry and pixel ids).  The oracle's
-own fp32-vs-fp64 discrepancy per tensor is printed next to the HIP error; the bound is max(1e-3, that discrepancy) of the
-tensor's magnitude (why a flat 1e-3 cannot hold at default-initialised weights: tests/test_gpu_network.py, scripts/cond_probe.py)."""
+Yardstick: the oracle run with fp64 features and weights (same fp32 geometry and pixel ids): outputs 1e-4, gradients 1e-3
+of each tensor's magnitude, flat.  The fp32 oracle's own distance from that run is printed next to the HIP error."""
 import numpy as np
 import pytest
 import torch
@@ -32,7 +31,7 @@ def _oracle(arch, sd, d, args, fs, dtype):
     pred = projection.project_to_plotwise_coverages(cov, d["cloud"], args)          # pixel ids from the fp32 cloud
     loss, _ = olosses.total_loss(pred, proba, d["coverages"], d["pdf_all"], args.m, args.e)
     loss.backward()
-    return s, cov.detach(), proba.detach(), pred.detach(), float(loss)
+    return s, cov.detach(), proba.detach(), pred.detach(), float(loss.detach())
 
 
 @pytest.mark.parametrize("arch", ["ref", "3sa"])
@@ -54,20 +53,34 @@ def test_metric_size_forward_loss_backward_vs_oracle(arch):
     torch.cuda.synchronize()
 
     s32, cov_r, proba_r, pred_r, loss_r = _oracle(arch, sd, d, args, fs, torch.float32)
-    np.testing.assert_allclose(cov.detach().cpu().numpy(), cov_r.numpy(), atol=TOL, rtol=0)
-    np.testing.assert_allclose(proba.detach().cpu().numpy(), proba_r.numpy(), atol=TOL, rtol=0)
-    np.testing.assert_allclose(pred.detach().cpu().numpy(), pred_r.numpy(), atol=TOL, rtol=0)
-    assert abs(loss.item() - loss_r) < TOL
-    s64, *_ = _oracle(arch, sd, d, args, fs, torch.float64)
+    s64, cov_64, proba_64, pred_64, loss_64 = _oracle(arch, sd, d, args, fs, torch.float64)
+    # Forward 1e-4 (BASELINE.json north_star), gradients 1e-3 of each tensor's magnitude -- against the oracle evaluated
+    # in fp64.  The fp32 oracle is printed beside it: at this size it sits up to 1e-3 (outputs) and 1e-1 (gradients) away
+    # from the fp64 evaluation (oracle/check.py says why), so "within 1e-4 of the fp32 CPU path" is not a property any
+    # fp32 implementation -- the reference's included -- can have here; within 1e-4 of the exact network is.
+    lines, fails = [], []
+    for name, got, r32, r64 in (("coverages_pointwise", cov, cov_r, cov_64), ("proba_pointwise", proba, proba_r, proba_64),
+                                ("pred_coverages", pred, pred_r, pred_64)):
+        g = got.detach().cpu().double().numpy()
+        e_hip, e_ref = np.abs(g - r64.numpy()).max(), np.abs(r32.double().numpy() - r64.numpy()).max()
+        d_direct = np.abs(g - r32.double().numpy()).max()
+        lines.append(f"{name:22s} |HIP - fp64 oracle| {e_hip:.2e}   |fp32 oracle - fp64 oracle| {e_ref:.2e}   |HIP - fp32 oracle| {d_direct:.2e}")
+        if e_hip > TOL:
+            fails.append(lines[-1])
+    print(f"\n[{arch}-arch, {B} x {N}] forward:\n  " + "\n  ".join(lines))
+    if abs(loss.item() - loss_64) > TOL:
+        fails.append(f"loss {loss.item()} vs fp64 oracle {loss_64} (fp32 oracle {loss_r})")
     report, worst = [], 0.0
     for k, p in m.named_parameters():
         g64 = s64[k].grad.numpy()
         scale = np.abs(g64).max()
         self_err = np.abs(s32[k].grad.numpy() - g64).max() / scale
         err = np.abs(p.grad.cpu().numpy() - g64).max() / scale
-        tol = max(1e-3, self_err)
+        tol = 1e-3
         report.append(f"{k:42s} err {err:.2e}  tol {tol:.2e}  oracle fp32-vs-fp64 {self_err:.2e}{'  <-- FAIL' if err > tol else ''}")
         worst = max(worst, err / tol)
+        if err > tol:
+            fails.append(report[-1])
     print(f"\n[{arch}-arch, {B} x {N}] loss {loss.item():.6f} (oracle {loss_r:.6f}); parameter gradients vs the oracle's fp64 run:\n  "
           + "\n  ".join(report))
-    assert worst <= 1.0, "\n".join(report)
+    assert not fails, "\n".join(fails)

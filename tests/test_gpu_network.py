@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN_CASES, golden_args, golden_state_dict, load_golden
-from oracle import losses, network, projection
+from oracle import check, losses, network, projection
 from stratanet2_vegetation_coverage_maps_amd import (PointNet2, project_to_2d_rasters, project_to_plotwise_coverages)
 from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
 from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
@@ -63,21 +63,19 @@ def test_train_step_vs_reference_golden(name):
     np.testing.assert_allclose(proba.detach().cpu().numpy(), g["train/proba_pointwise"], atol=TOL, rtol=0)
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g["train/pred_coverages"], atol=TOL, rtol=0)
     np.testing.assert_allclose([loss.item()] + [p.item() for p in parts], g["train/losses"], atol=TOL, rtol=0)
-    # gradients: against the reference run with fp64 features/weights (same fp32 geometry and pixel ids) = the yardstick.
-    # `self_err` = the reference's OWN fp32-vs-fp64 discrepancy per tensor.  Where the case is well conditioned
-    # (b4_well_conditioned is generated under the assertion self_err <= 1e-3 for every tensor; b2_c2_style has 1e-5) the
-    # bound is a flat 1e-3 of the tensor's magnitude.  The N = 4096 reference-default cases are NOT well conditioned at
-    # default-initialised weights: rarely active ReLU channels get BatchNorm outputs of ~100 sigma, and a relative
-    # perturbation of 1e-8 of the weights -- in fp64 -- already moves the gradients by 3e-3 (scripts/cond_probe.py), so no
-    # fp32 evaluation can be held to 1e-3 there; the bound is the reference's own discrepancy.  The measured error of every
-    # tensor is printed (pytest -s shows it; on failure it is part of the message).
+    # gradients: against the reference run with fp64 features/weights (same fp32 geometry and pixel ids) = the yardstick:
+    # a flat 1e-3 of each tensor's magnitude.  (The reference's OWN fp32 run is further from it than that on the N = 4096
+    # cases -- `self_err`, printed: rarely active ReLU channels get BatchNorm outputs of ~100 sigma and torch's fp32 CPU
+    # batch statistics are good to ~1e-5 relative; the HIP statistics are finalised in fp64.)  Only the single-plot case
+    # c1_ref_defaults (256-row BatchNorms; a 1e-8 relative weight perturbation moves its fp64 gradients by 3e-3,
+    # scripts/cond_probe.py) gets max(1e-3, self_err).  Every measured error is printed.
     report, worst = [], 0.0
     for k, p in m.named_parameters():
         ref32, ref64 = g[f"grad/{k}"], g[f"grad64/{k}"]
         assert p.grad is not None, k
         scale = np.abs(ref64).max()
         self_err = np.abs(ref32 - ref64).max() / scale
-        tol = max(1e-3, 1.0 * self_err)
+        tol = max(1e-3, 1.0 * self_err) if name == "c1_ref_defaults" else 1e-3
         err = np.abs(p.grad.cpu().numpy() - ref64).max() / scale
         report.append(f"{k:42s} err {err:.2e}  tol {tol:.2e}  reference fp32-vs-fp64 {self_err:.2e}{'  <-- FAIL' if err > tol else ''}")
         worst = max(worst, err / tol)
@@ -139,20 +137,10 @@ def test_forward_backward_vs_oracle_other_sizes(B, N, ratio1, r1, r2):
     pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
     loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
     loss.backward()
-    sd_r = {k: v.clone() for k, v in sd.items()}
-    keys = network.param_keys(sd_r)
-    for k in keys:
-        sd_r[k].requires_grad_(True)
-    cov_r, proba_r, ex = network.forward(sd_r, d["cloud"], d["xyz"], args, training=True, fps_start=(fs[0], fs[1]))
-    pred_r = projection.project_to_plotwise_coverages(cov_r, d["cloud"], args)
-    loss_r, _ = losses.total_loss(pred_r, proba_r, d["coverages"], d["pdf_all"], args.m, args.e)
-    loss_r.backward()
-    np.testing.assert_allclose(cov.detach().cpu().numpy(), cov_r.detach().numpy(), atol=TOL, rtol=0)
-    np.testing.assert_allclose(proba.detach().cpu().numpy(), proba_r.detach().numpy(), atol=TOL, rtol=0)
-    assert abs(loss.item() - loss_r.item()) < TOL
-    for k, p in m.named_parameters():
-        ref = sd_r[k].grad.numpy()
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-6 + 1e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+    ref = check.train_step(sd, d, args, fps_start=fs)                  # the oracle in fp64: see oracle/check.py
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred)
+    print(f"\n[{B} x {N}] vs the fp64 oracle:\n  {report}")
+    assert not fails, "\n".join(fails)
 
 
 def test_eval_is_batch_independent_and_deterministic():
@@ -278,20 +266,10 @@ def test_dense_plot_128k_points_vs_oracle():
     from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
     loss, _ = dev_losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
     loss.backward()
-    sd_r = {k: v.clone() for k, v in sd.items()}
-    for k in network.param_keys(sd_r):
-        sd_r[k].requires_grad_(True)
-    cov_r, proba_r, _ = network.forward(sd_r, d["cloud"], d["xyz"], args, training=True, fps_start=(fs[0], fs[1]),
-                                        use_kdtree=True)
-    pred_r = projection.project_to_plotwise_coverages(cov_r, d["cloud"], args)
-    loss_r, _ = losses.total_loss(pred_r, proba_r, d["coverages"], d["pdf_all"], args.m, args.e)
-    loss_r.backward()
-    np.testing.assert_allclose(cov.detach().cpu().numpy(), cov_r.detach().numpy(), atol=TOL, rtol=0)
-    np.testing.assert_allclose(proba.detach().cpu().numpy(), proba_r.detach().numpy(), atol=TOL, rtol=0)
-    assert abs(loss.item() - loss_r.item()) < TOL
-    for k, p in m.named_parameters():
-        ref = sd_r[k].grad.numpy()
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-6 + 2e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+    ref = check.train_step(sd, d, args, fps_start=fs, use_kdtree=True)      # the oracle in fp64 (oracle/check.py)
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred)
+    print(f"\n[1 x {N}] vs the fp64 oracle:\n  {report}")
+    assert not fails, "\n".join(fails)
 
 
 def test_per_point_layer_source_side_form():
@@ -331,20 +309,13 @@ def test_per_point_layer_source_side_form():
     for k in running:
         np.testing.assert_allclose(running[k], running0[k], atol=1e-6, rtol=1e-5, err_msg=k)
 
-    sd_r = {k: v.clone() for k, v in sd.items()}
-    for k in network.param_keys(sd_r):
-        sd_r[k].requires_grad_(True)
-    cov_r, proba_r, _ = network.forward(sd_r, d["cloud"], d["xyz"], args, training=True, fps_start=(fs[0], fs[1]),
-                                        use_kdtree=True)
-    pred_r = projection.project_to_plotwise_coverages(cov_r, d["cloud"], args)
-    loss_r, _ = losses.total_loss(pred_r, proba_r, d["coverages"], d["pdf_all"], args.m, args.e)
-    loss_r.backward()
-    np.testing.assert_allclose(cov, cov_r.detach().numpy(), atol=TOL, rtol=0)
-    np.testing.assert_allclose(proba, proba_r.detach().numpy(), atol=TOL, rtol=0)
-    assert abs(loss - loss_r.item()) < TOL
+    ref = check.train_step(sd, d, args, fps_start=fs, use_kdtree=True)      # the oracle in fp64 (oracle/check.py)
+    assert np.abs(cov - ref["cov"].numpy()).max() <= TOL and np.abs(proba - ref["proba"].numpy()).max() <= TOL
+    assert abs(loss - ref["loss"]) <= TOL
     for k in grads:
-        ref = sd_r[k].grad.numpy()
-        np.testing.assert_allclose(grads[k], ref, atol=1e-6 + 2e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+        g = ref["grads"][k].numpy()
+        err = np.abs(grads[k] - g).max() / np.abs(g).max()
+        assert err <= 1e-3, f"{k}: {err:.2e}"
 
 
 @pytest.mark.parametrize("B,N", [(2, 4096), (3, 24001)])
@@ -383,28 +354,19 @@ def test_dropout_in_the_head_vs_oracle_with_the_same_mask(p_drop):
     pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
     loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
     loss.backward()
-    sd_r = {k: v.clone() for k, v in sd.items()}
-    for k in network.param_keys(sd_r):
-        sd_r[k].requires_grad_(True)
-    cov_r, proba_r, _ = network.forward(sd_r, d["cloud"], d["xyz"], args, training=True, fps_start=(fs[0], fs[1]),
-                                        dropout_mask=keep)
-    pred_r = projection.project_to_plotwise_coverages(cov_r, d["cloud"], args)
-    loss_r, _ = losses.total_loss(pred_r, proba_r, d["coverages"], d["pdf_all"], args.m, args.e)
-    loss_r.backward()
-    np.testing.assert_allclose(cov.detach().cpu().numpy(), cov_r.detach().numpy(), atol=TOL, rtol=0)
-    np.testing.assert_allclose(proba.detach().cpu().numpy(), proba_r.detach().numpy(), atol=TOL, rtol=0)
-    assert abs(loss.item() - loss_r.item()) < TOL
-    for k, p in m.named_parameters():
-        ref = sd_r[k].grad.numpy()
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-6 + 1e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+    ref = check.train_step(sd, d, args, fps_start=fs, dropout_mask=keep)   # the oracle in fp64 with the same mask
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred)
+    print(f"\n[dropout p = {p_drop}] vs the fp64 oracle:\n  {report}")
+    assert not fails, "\n".join(fails)
     # the mask matters (the no-dropout outputs differ), eval mode ignores it, and the built-in draw keeps ~(1-p)
     no_drop = _model(make_args(subsample_size=N, ratio1=0.1, r1=1.0, ratio2=0.25, r2=2.0, drop=0.0), sd).train()
     cov0, _ = no_drop({k: v for k, v in d.items() if k != "dropout_mask"})
     assert (cov0 - cov).abs().max() > 1e-3
     m2 = _model(args, sd).eval()
+    m3 = _model(make_args(subsample_size=N, ratio1=0.1, r1=1.0, ratio2=0.25, r2=2.0, drop=0.0), sd).eval()
     with torch.no_grad():
         c_eval, _ = m2(d)
-        c_eval0, _ = no_drop.eval()({k: v for k, v in d.items() if k != "dropout_mask"})
+        c_eval0, _ = m3({k: v for k, v in d.items() if k != "dropout_mask"})
     assert torch.equal(c_eval, c_eval0)
     words = m.train()._dropout_keep({"cloud": d["cloud"]}, d["cloud"].cuda())
     kept = sum(int(((words >> j) & 1).sum()) for j in range(16)) / (16 * B * N)
