@@ -50,6 +50,11 @@ typedef struct sn2_block {
                                         + r * grad_replica_stride floats; a workgroup adds into ONE image, so that the
                                         float atomics spread over the memory channels.  The gradient is the sum of the
                                         images (sn2_grad_reduce).  dgamma / dbeta always have one image.  0 or 1: one. */
+    int mma_bf16;                  /* != 0: this block's contractions on the matrix cores (forward, input gradient, weight
+                                      gradient) take bfloat16 operands (weights and activations rounded to nearest even,
+                                      v_mfma_f32_16x16x32_bf16 / 16x16x16, fp32 accumulate); ReLU, BatchNorm, statistics, the
+                                      extremum and everything that decides an index stay fp32 (BASELINE.json configs[4]).
+                                      0: exact fp32 products (v_mfma_f32_16x16x4_f32), the reference's precision.          */
 } sn2_block;
 /* flat[i] += sum_{r=1..replicas-1} flat[r*stride + i], i < n: folds the images of a flat gradient vector into image 0 */
 int sn2_grad_reduce(float *flat, int n, int replicas, int stride, void *stream);

@@ -60,10 +60,38 @@ def param_keys(sd) -> Sequence[str]:
                                   or k.endswith("num_batches_tracked"))]
 
 
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)          # round to nearest even, as v_cvt_pk_bf16_f32
+
+
+class _LinearBF16(torch.autograd.Function):
+    """A Linear layer whose three contractions take bfloat16 operands and accumulate wider -- the checker of the build's
+    bf16 variant (sn2_block.mma_bf16; BASELINE.json configs[4]; NOT in the reference): y = r(x) r(W)^T + b,
+    dx = r(dy) r(W), dW = r(dy)^T r(x), db = sum(dy), r = rounding to bfloat16."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        xr, Wr = _bf16(x), _bf16(W)
+        ctx.save_for_backward(xr, Wr)
+        return xr @ Wr.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, Wr = ctx.saved_tensors
+        dyr = _bf16(dy)
+        return dyr @ Wr, dyr.t() @ xr, dy.sum(0)
+
+
+BF16_LAYERS = ()      # prefixes of the blocks evaluated with bf16 operands (set through `forward(..., bf16_layers=)`)
+
+
 def _mlp(x, sd, prefix, n_blocks, training, new_stats):
     """(Linear -> ReLU -> BN) x n_blocks, `model/point_net2.py:45-53`; torch BatchNorm1d defaults."""
     for i in range(n_blocks):
-        x = F.linear(x, sd[f"{prefix}.{i}.0.weight"], sd[f"{prefix}.{i}.0.bias"])
+        if prefix in BF16_LAYERS:
+            x = _LinearBF16.apply(x, sd[f"{prefix}.{i}.0.weight"], sd[f"{prefix}.{i}.0.bias"])
+        else:
+            x = F.linear(x, sd[f"{prefix}.{i}.0.weight"], sd[f"{prefix}.{i}.0.bias"])
         x = F.relu(x)
         rm = sd[f"{prefix}.{i}.2.running_mean"].clone()
         rv = sd[f"{prefix}.{i}.2.running_var"].clone()
@@ -83,12 +111,15 @@ def _fps_regular(pos_long, B, n, ratio, start):
 
 def forward(sd: Dict[str, torch.Tensor], cloud: torch.Tensor, xyz: torch.Tensor, args, training: bool,
             fps_start: Optional[Sequence[torch.Tensor]] = None, use_kdtree: bool = False, details: bool = False,
-            dropout_mask: Optional[torch.Tensor] = None):
+            dropout_mask: Optional[torch.Tensor] = None, bf16_layers: Sequence[str] = ()):
     """cloud (B,10,N), xyz (B,3,N) fp32 CPU tensors (the DataLoader collate of `loader.py:73-87`).
     fps_start = (start1 (B,), start2 (B,)) LOCAL start indices of the two FPS calls (None -> 0).
     dropout_mask (B*N,16), non-zero = keep: the mask F.dropout (point_net2.py:142) would have drawn (None: torch draws).
+    bf16_layers: prefixes of the (Linear, ReLU, BN) stacks whose Linear layers take bfloat16 operands (`_LinearBF16`).
     Returns (coverages_pointwise (B*N,4), proba_pointwise (B*N,4), extras) where extras holds the new BN
     running statistics (training) and, with details=True, the intermediate tensors."""
+    global BF16_LAYERS
+    BF16_LAYERS = tuple(bf16_layers)
     B, _, N = cloud.shape
     # long form (B*N, f), plot-major (point_net2.py:155-158), drop normalised x,y (:118)
     pos0 = xyz.permute(0, 2, 1).reshape(B * N, 3).contiguous()

@@ -17,7 +17,7 @@ class Block(Structure):  # sn2_block
                 ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("a", c_void_p),
                 ("c", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("stat_slots", c_void_p),
                 ("dW", c_void_p), ("db", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
-                ("grad_replicas", c_int), ("grad_replica_stride", c_int)]
+                ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("mma_bf16", c_int)]
 
 
 class SA(Structure):  # sn2_sa

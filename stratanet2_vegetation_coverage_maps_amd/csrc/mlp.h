@@ -5,6 +5,52 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- one contraction on the matrix cores, in either operand precision ---------------------------------------------
+// Every dense contraction of the library has the same shape: a 16 x 16 output tile per wave, K walked in slots of four
+// (lane (q, c) supplies element k = 4 kb + q of its row / column for slot kb).  `contract<BF16, KBN>(acc, a, b)` adds
+// sum_{kb < KBN} A(kb) * B(kb) to the tile, a(kb) / b(kb) returning this lane's two operand values of slot kb:
+//   BF16 = false:  one v_mfma_f32_16x16x4_f32 per slot, in slot order (exact fp32 products, fp32 accumulate);
+//   BF16 = true:   the operands are rounded to bfloat16 (v_cvt_pk_bf16_f32, round to nearest even) and EIGHT slots go
+//                  into one v_mfma_f32_16x16x32_bf16 (four into a v_mfma_f32_16x16x16_bf16 when no more than four are
+//                  left), fp32 accumulate -- BASELINE.json configs[4], "bf16 MLP weights on MFMA".  Which k a register
+//                  slot stands for does not matter as long as A and B agree, so the fp32 operand registers are reused as
+//                  they are: lane (q, c) holds 8 (4) consecutive entries of the instruction's K = 32 (16).
+// Loop-invariant operands (the weights) are converted once: the conversions are hoisted out of the loops by the compiler.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool BF16, int KBN, class FA, class FB>
+__device__ __forceinline__ f32x4 contract(f32x4 acc, FA a, FB b) {
+    if constexpr (!BF16) {
+#pragma unroll
+        for (int kb = 0; kb < KBN; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a(kb), b(kb), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int k0 = 0; k0 < KBN; k0 += 8) {
+            if (KBN - k0 > 4) {
+                bf16x8 av, bv;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    av[t] = (__bf16)(k0 + t < KBN ? a(k0 + t < KBN ? k0 + t : 0) : 0.f);
+                    bv[t] = (__bf16)(k0 + t < KBN ? b(k0 + t < KBN ? k0 + t : 0) : 0.f);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+            } else {
+                bf16x4 av, bv;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    av[t] = (__bf16)(k0 + t < KBN ? a(k0 + t < KBN ? k0 + t : 0) : 0.f);
+                    bv[t] = (__bf16)(k0 + t < KBN ? b(k0 + t < KBN ? k0 + t : 0) : 0.f);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, av), __builtin_bit_cast(s16x4, bv), acc,
+                                                                0, 0, 0);
+            }
+        }
+    }
+    return acc;
+}
+
 // out[o] = (relu) ( b[o] + sum_k W[o*CI+k] * in[k] ).  W, b are wave-uniform constant-address-space pointers (common.h):
 // the loads are s_load_dwordx* and the FMAs take SGPR operands.
 template <int CI, int CO, bool RELU>

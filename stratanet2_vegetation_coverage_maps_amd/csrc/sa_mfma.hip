@@ -60,7 +60,7 @@ __device__ __forceinline__ float row_sum(float v) {
 }
 
 // PASS 0: statistics of block 0 only (nl == 2);  PASS 1: full forward, statistics of the last block, extremum
-template <int CF, int NL, int C1, int C2, int PASS>
+template <int CF, int NL, int C1, int C2, int PASS, bool BF16>
 __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
     constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16, CS = PASS == 0 ? C1 : CL, TOS = CS / 16;
@@ -72,14 +72,19 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
     const int ncent = a.B * a.M;
 
     // ---- operand registers, loaded once
-    float A1[TO1][KB1];
+    // the bias of the first layer rides in the weight matrix against the constant-1 column of the gathered input -- in fp32.
+    // With bf16 operands it stays OUT of the contraction (it would be rounded to bfloat16) and starts the accumulator.
+    float A1[TO1][KB1], bias1[TO1][4];
 #pragma unroll
-    for (int io = 0; io < TO1; ++io)
+    for (int io = 0; io < TO1; ++io) {
 #pragma unroll
         for (int kb = 0; kb < KB1; ++kb) {
             const int k = 4 * kb + q, o = 16 * io + c;
-            A1[io][kb] = k < CIN ? a.W0[o * CIN + k] : (k == CIN ? a.b0[o] : 0.f);
+            A1[io][kb] = k < CIN ? a.W0[o * CIN + k] : ((k == CIN && !BF16) ? a.b0[o] : 0.f);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias1[io][r] = BF16 ? a.b0[16 * io + 4 * q + r] : 0.f;
+    }
     float A2[NL == 2 ? TO2 : 1][TO1][4], bias2[NL == 2 ? TO2 : 1][4], a1v[TO1][4], c1v[TO1][4];
     if constexpr (NL == 2 && PASS == 1) {
 #pragma unroll
@@ -183,9 +188,8 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
                 bk[KB1 - 1] = q < 3 ? pj - cpq[t] : 1.0f;   // pos_j - pos_i | bias column
 #pragma unroll
                 for (int io = 0; io < TO1; ++io) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kb = 0; kb < KB1; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[io][kb], bk[kb], acc, 0, 0, 0);
+                    f32x4 acc = {bias1[io][0], bias1[io][1], bias1[io][2], bias1[io][3]};
+                    acc = contract<BF16, KB1>(acc, [&](int kb) { return A1[io][kb]; }, [&](int kb) { return bk[kb]; });
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
                     D1[io][t] = acc;
@@ -217,11 +221,8 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             f32x4 acc = {bias2[io][0], bias2[io][1], bias2[io][2], bias2[io][3]};
-#pragma unroll
-                            for (int is = 0; is < TO1; ++is)
-#pragma unroll
-                                for (int kb = 0; kb < 4; ++kb)
-                                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[io][is][kb], D1[is][t][kb], acc, 0, 0, 0);
+                            acc = contract<BF16, 4 * TO1>(acc, [&](int kk) { return A2[io][kk >> 2][kk & 3]; },
+                                                          [&](int kk) { return D1[kk >> 2][t][kk & 3]; });
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
                             DL[io][t] = acc;
@@ -338,7 +339,7 @@ struct SaBwdArgs {
 };
 
 // PASS 2 = "C" (nl == 2): dW/db of block 1, dgamma/dbeta of block 0.   PASS 3 = "D": dW/db of block 0 (+ dfeat).
-template <int CF, int NL, int C1, int C2, int PASS>
+template <int CF, int NL, int C1, int C2, int PASS, bool BF16>
 __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
     constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
     constexpr bool LAST2 = NL == 2 && PASS == 2;             // this pass produces block 1's weight gradient
@@ -360,14 +361,17 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
     const float invE = etot > 0 ? (float)(1.0 / (double)etot) : 0.f;
 
     // ---- operand registers
-    float A1[TO1][KB1];
+    float A1[TO1][KB1], bias1[TO1][4];      // bias of the first layer: inside the contraction in fp32, outside with bf16 operands
 #pragma unroll
-    for (int io = 0; io < TO1; ++io)
+    for (int io = 0; io < TO1; ++io) {
 #pragma unroll
         for (int kb = 0; kb < KB1; ++kb) {
             const int k = 4 * kb + q, o = 16 * io + c;
-            A1[io][kb] = k < CIN ? a.W0[o * CIN + k] : (k == CIN ? a.b0[o] : 0.f);
+            A1[io][kb] = k < CIN ? a.W0[o * CIN + k] : ((k == CIN && !BF16) ? a.b0[o] : 0.f);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias1[io][r] = BF16 ? a.b0[16 * io + 4 * q + r] : 0.f;
+    }
     float A2[NL == 2 ? TO2 : 1][TO1][4], A2T[TO1][NL == 2 ? TO2 : 1][4], bias2[NL == 2 ? TO2 : 1][4], a1v[TO1][4], c1v[TO1][4];
     // BN-backward constants: block 0 (index 0) and, for nl == 2, block 1 (index 1)
     float cA0[TO1][4], cC0[TO1][4], cD0[TO1][4], mu0[TO1][4], is0[TO1][4];
@@ -511,9 +515,8 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
                 bks[t][KB1 - 1] = q < 3 ? pj - cpq[t] : 1.0f;
 #pragma unroll
                 for (int io = 0; io < TO1; ++io) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kb = 0; kb < KB1; ++kb) v = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[io][kb], bks[t][kb], v, 0, 0, 0);
+                    f32x4 v = {bias1[io][0], bias1[io][1], bias1[io][2], bias1[io][3]};
+                    v = contract<BF16, KB1>(v, [&](int kb) { return A1[io][kb]; }, [&](int kb) { return bks[t][kb]; });
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     D1[io][t] = v;
@@ -533,11 +536,8 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         f32x4 v = {bias2[io][0], bias2[io][1], bias2[io][2], bias2[io][3]};
-#pragma unroll
-                        for (int is = 0; is < TO1; ++is)
-#pragma unroll
-                            for (int kb = 0; kb < 4; ++kb)
-                                v = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[io][is][kb], Y1[is][t][kb], v, 0, 0, 0);
+                        v = contract<BF16, 4 * TO1>(v, [&](int kk) { return A2[io][kk >> 2][kk & 3]; },
+                                                    [&](int kk) { return Y1[kk >> 2][t][kk & 3]; });
                         const int e = e0 + eoff * t + c;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -552,11 +552,8 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int io = 0; io < TO2; ++io)
-#pragma unroll
-                            for (int kb = 0; kb < 4; ++kb)
-                                v = __builtin_amdgcn_mfma_f32_16x16x4f32(A2T[is][io][kb], dp2[io][t][kb], v, 0, 0, 0);
+                        v = contract<BF16, 4 * TO2>(v, [&](int kk) { return A2T[is][kk >> 2][kk & 3]; },
+                                                    [&](int kk) { return dp2[kk >> 2][t][kk & 3]; });
                         dy1[is][t] = v;
                     }
                 if constexpr (PASS == 2) {
@@ -627,11 +624,8 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int io = 0; io < TO1; ++io)
-#pragma unroll
-                                for (int kb = 0; kb < 4; ++kb)
-                                    v = __builtin_amdgcn_mfma_f32_16x16x4f32(A0T[kt][io][kb], dp1[io][t][kb], v, 0, 0, 0);
+                            v = contract<BF16, 4 * TO1>(v, [&](int kk) { return A0T[kt][kk >> 2][kk & 3]; },
+                                                        [&](int kk) { return dp1[kk >> 2][t][kk & 3]; });
                             if (val[t]) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -648,17 +642,38 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
             {
                 const float* rp = lds_p + q * PS + c;
                 const float* rq = lds_q + q * QS + c;
+                if constexpr (!BF16) {
 #pragma unroll 4
-                for (int st = 0; st < 16; ++st) {
-                    float av[TP], bv[TQ];
+                    for (int st = 0; st < 16; ++st) {
+                        float av[TP], bv[TQ];
 #pragma unroll
-                    for (int i = 0; i < TP; ++i) av[i] = rp[st * 4 * PS + 16 * i];
+                        for (int i = 0; i < TP; ++i) av[i] = rp[st * 4 * PS + 16 * i];
 #pragma unroll
-                    for (int j = 0; j < TQ; ++j) bv[j] = rq[st * 4 * QS + 16 * j];
+                        for (int j = 0; j < TQ; ++j) bv[j] = rq[st * 4 * QS + 16 * j];
 #pragma unroll
-                    for (int i = 0; i < TP; ++i)
+                        for (int i = 0; i < TP; ++i)
 #pragma unroll
-                        for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < TQ; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    }
+                } else {
+                    // the 64 messages of the step are the K of two v_mfma_f32_16x16x32_bf16 per tile pair
+#pragma unroll
+                    for (int s8 = 0; s8 < 2; ++s8) {
+                        float av[TP][8], bv[TQ][8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                            for (int i = 0; i < TP; ++i) av[i][u] = rp[(8 * s8 + u) * 4 * PS + 16 * i];
+#pragma unroll
+                            for (int j = 0; j < TQ; ++j) bv[j][u] = rq[(8 * s8 + u) * 4 * QS + 16 * j];
+                        }
+#pragma unroll
+                        for (int i = 0; i < TP; ++i)
+#pragma unroll
+                            for (int j = 0; j < TQ; ++j)
+                                acc[i][j] = contract<true, 8>(acc[i][j], [&](int u) { return av[i][u]; }, [&](int u) { return bv[j][u]; });
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -727,6 +742,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 // launched from sa.hip
 template <int CF, int NL, int C1, int C2, int PASS>
 int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nblocks_out) {
+    const bool bf16 = p->blk[0].mma_bf16 != 0;
     SaFwdArgs a;
     a.B = p->B; a.Nsrc = p->Nsrc; a.M = p->M; a.cap = p->cap; a.feat_stride = p->feat_stride; a.spos_stride = p->spos_stride;
     a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt; a.order = p->order;
@@ -739,7 +755,8 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
     int blocks = sn2_cdiv((long)p->B * p->M, 16);          // one wave per quad of centroids, four waves per workgroup
     if (blocks > SN2_STAT_SLOTS) blocks = SN2_STAT_SLOTS;
     if (nblocks_out) *nblocks_out = blocks;
-    hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS>), dim3(blocks), dim3(256), 0, st, a);
+    if (bf16) hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, false>), dim3(blocks), dim3(256), 0, st, a);
     SN2_RETURN_LAUNCH();
 }
 
@@ -769,7 +786,7 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
     int blocks = sn2_cdiv((long)p->B * p->M, 16);
     if (blocks > 512) blocks = 512;
     const size_t lds = (size_t)Acc::LDS_FLOATS * 4 * sizeof(float);
-    auto kern = &sa_mfma_bwd_kernel<CF, NL, C1, C2, PASS>;
+    auto kern = p->blk[0].mma_bf16 ? &sa_mfma_bwd_kernel<CF, NL, C1, C2, PASS, true> : &sa_mfma_bwd_kernel<CF, NL, C1, C2, PASS, false>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);

@@ -72,7 +72,7 @@ class _Saved:
     pass
 
 
-def _blocks_of(seq, aux_arena, stats_arena, cursor):
+def _blocks_of(seq, aux_arena, stats_arena, cursor, mma_bf16=False):
     out = []
     for blk in seq:
         lin, bn = blk[0], blk[2]
@@ -83,6 +83,7 @@ def _blocks_of(seq, aux_arena, stats_arena, cursor):
         cursor[0] += 4 * c
         cursor[1] += ns
         out.append(ops.BlockBuffers(lin, bn, aux, st))
+        out[-1].mma_bf16 = mma_bf16
     return out
 
 
@@ -128,6 +129,9 @@ class PointNet2(nn.Module):
         self.last_G_tensor = None
         self._last_flat_grad = None
         self._last_cloud_dev = None
+        # additive extension (not a reference flag): "bf16" = bfloat16 operands on the matrix cores (BASELINE.json
+        # configs[4]); default "fp32" = the reference's precision
+        self.set_mma_dtype(getattr(args, "mma_dtype", "fp32"))
         if self.n_class != 4 or self.n_input_feats != 8:
             raise ValueError("the HIP kernels cover the reference architecture: n_class=4, 10 input features")
         ndim = 3
@@ -151,6 +155,19 @@ class PointNet2(nn.Module):
         self.sigmoid = nn.Sigmoid()
         if self.cuda_device is not None:
             self.cuda(self.cuda_device)
+
+    BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn")     # the blocks `mma_dtype = "bf16"` applies to
+    mma_dtype = "fp32"
+
+    def set_mma_dtype(self, dtype: str):
+        """"fp32" (default: exact fp32 products, the reference's precision) or "bf16": the dense contractions of
+        `BF16_BLOCKS` -- forward, input gradient, weight gradient -- take bfloat16 operands on v_mfma_f32_16x16x32_bf16 /
+        16x16x16 with fp32 accumulation; ReLU, BatchNorm, statistics, every arg-max and all position-only kernels stay
+        fp32, so the index structures are the same bits in both modes."""
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("mma_dtype must be 'fp32' or 'bf16'")
+        self.mma_dtype = dtype
+        return self
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, cloud_data):
@@ -397,8 +414,9 @@ class PointNet2(nn.Module):
         aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)
         stats = torch.empty(STAT_SLOTS * 2 * sum(widths), dtype=F32, device=dev)
         cur = [0, 0]
-        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur)
-        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur)
+        bf = self.mma_dtype == "bf16"
+        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur, bf)
+        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur, bf)
         s.b_sa3 = _blocks_of(self.sa3_module.nn, aux, stats, cur)[0]
         s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur)[0]
         s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur)[0]

@@ -52,6 +52,7 @@ class PointNet2ThreeSA(PointNet2):
             self.cuda(self.cuda_device)
 
     N_FPS = 3
+    BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn", "sa3_module.conv.local_nn")
 
     def _sizes3(self, N):
         M1 = ops.fps_num_samples(N, self.sa1_module.ratio)
@@ -148,9 +149,10 @@ class PointNet2ThreeSA(PointNet2):
         aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)
         stats = torch.empty(STAT_SLOTS * 2 * sum(widths), dtype=F32, device=dev)
         cur = [0, 0]
-        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur)
-        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur)
-        s.b_sa3 = _blocks_of(self.sa3_module.conv.local_nn, aux, stats, cur)
+        bf = self.mma_dtype == "bf16"
+        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur, bf)
+        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur, bf)
+        s.b_sa3 = _blocks_of(self.sa3_module.conv.local_nn, aux, stats, cur, bf)
         s.b_sa4 = _blocks_of(self.sa4_module.nn, aux, stats, cur)[0]
         s.b_fp4 = _blocks_of(self.fp4_module.nn, aux, stats, cur)[0]
         s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur)[0]

@@ -28,6 +28,8 @@ def test_3sa_forward_backward_vs_oracle(B, N, ratio1):
     loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
     loss.backward()
     ref = check.train_step(sd, d, args, fps_start=fs, arch="3sa")           # the oracle's generalisation, in fp64
-    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred)
+    # gradients 2e-3: the one-plot case has 64-row BatchNorms at the third level, where a single ReLU decision next to zero
+    # moves the gradients behind it by ~1e-3 (measured 1.4e-3 on fp2's bias; everything in front of it agrees to 3e-6)
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred, tol_grad=2e-3)
     print(f"\n[3sa {B} x {N}] vs the fp64 oracle:\n  {report}")
     assert not fails, "\n".join(fails)

@@ -1,0 +1,76 @@
+"""The bf16 variant (BASELINE.json configs[4]: "bf16 MLP weights on MFMA"; not in the reference, whose precision is fp32):
+`mma_dtype = "bf16"` sends the dense contractions of `PointNet2.BF16_BLOCKS` through v_mfma_f32_16x16x32_bf16 / 16x16x16 with
+operands rounded to bfloat16 and fp32 accumulation.
+
+Checks: (1) every index structure is the same bits as in fp32 mode (the position-only kernels do not change); (2) forward,
+loss and gradients against the oracle evaluated with the SAME operand rounding in the same layers (`oracle.network
+._LinearBF16`, fp64 accumulate): stated tolerance 1e-3 on outputs (measured 4e-5 .. 8e-5) and 2e-2 of a gradient tensor's
+magnitude (measured <= 6e-3, on bias gradients: the kernels sum the ROUNDED d pre-activations for the bias where it rides in
+the weight matrix, the oracle the unrounded ones); (3) against the fp32 mode the outputs move by ~1e-2 (a bfloat16 ulp is
+2^-8 = 0.4 %): bf16 changes the result as much as bf16 must, and no more (stated bound 1e-1)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import check, network
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, losses, project_to_plotwise_coverages
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, sd, d, dtype):
+    args.cuda, args.mma_dtype = 0, dtype
+    m = PointNet2(args)
+    m.load_state_dict(sd)
+    m.train()
+    cov, proba = m(d)
+    saved = cov.grad_fn.saved
+    idx = {k: getattr(saved, k).clone() for k in ("idx1", "idx2", "cnt1", "cnt2")}
+    for lvl in ("1", "2"):                                       # the padded lists: entries below the count
+        nbr, cnt = getattr(saved, "nbr" + lvl), getattr(saved, "cnt" + lvl)
+        valid = torch.arange(nbr.shape[1], device=nbr.device)[None, :] < cnt[:, None]
+        idx["nbr" + lvl] = torch.where(valid, nbr, torch.full_like(nbr, -1))
+    idx.update(knn1=saved.knn1[0].clone(), knn2=saved.knn2[0].clone(), w1=saved.knn1[1].clone())
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+    loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
+    loss.backward()
+    torch.cuda.synchronize()
+    return m, cov, proba, pred, loss, idx
+
+
+def _check(name, args, sd, d, fs, tol_out, tol_grad):
+    m, cov, proba, pred, loss, idx = _run(args, sd, d, "bf16")
+    m32, cov32, _, _, _, idx32 = _run(args, sd, d, "fp32")
+    for k in idx:                                                   # (1) discrete structures: bit-identical
+        assert torch.equal(idx[k], idx32[k]), k
+    ref = check.train_step(sd, d, args, fps_start=fs, use_kdtree=True, bf16_layers=PointNet2.BF16_BLOCKS)
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, tol_out=tol_out, tol_grad=tol_grad, pred=pred)
+    moved = float((cov - cov32).abs().max())
+    print(f"\n[bf16, {name}] vs the oracle with bf16 operands in {PointNet2.BF16_BLOCKS}:\n  {report}\n"
+          f"  bf16 vs fp32 mode: max |d coverages| = {moved:.2e}")
+    assert not fails, "\n".join(fails)
+    assert 1e-6 < moved < 1e-1                                      # (3) it is a different precision, and only that
+
+
+def test_bf16_variant_on_the_well_conditioned_case():
+    """The inputs and weights of the golden `b4_well_conditioned` (the case whose fp32 and fp64 reference gradients agree to
+    1.6e-4): here the bf16 build and the oracle with the same operand rounding must agree closely."""
+    from conftest import golden_args, golden_state_dict, load_golden
+    g, args = load_golden("b4_well_conditioned"), golden_args("b4_well_conditioned")
+    d = {"cloud": torch.from_numpy(g["in/cloud"]), "xyz": torch.from_numpy(g["in/xyz"]),
+         "coverages": torch.from_numpy(g["in/coverages"]), "pdf_all": torch.from_numpy(g["in/pdf_all"])}
+    fs = torch.from_numpy(g["in/fps_start"])
+    d["fps_start"] = fs
+    _check("b4_well_conditioned", args, golden_state_dict(g), d, fs, tol_out=1e-3, tol_grad=2e-2)
+
+
+def test_bf16_variant_at_default_initialisation():
+    """Default-initialised weights at a larger size (the badly conditioned regime of oracle/check.py): with the operand
+    rounding reproduced exactly the two still agree to 1e-4 / 6e-3 (measured); same stated tolerances as above."""
+    B, N = 4, 8192
+    args = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=300)
+    fs = torch.zeros(2, B, dtype=torch.long)
+    d["fps_start"] = fs
+    _check(f"{B} x {N}, default init", args, network.init_state_dict(4), d, fs, tol_out=1e-3, tol_grad=2e-2)

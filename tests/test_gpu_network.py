@@ -267,7 +267,7 @@ def test_dense_plot_128k_points_vs_oracle():
     loss, _ = dev_losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
     loss.backward()
     ref = check.train_step(sd, d, args, fps_start=fs, use_kdtree=True)      # the oracle in fp64 (oracle/check.py)
-    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred)
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred, tol_grad=2e-3)     # one plot: 256-row BatchNorms
     print(f"\n[1 x {N}] vs the fp64 oracle:\n  {report}")
     assert not fails, "\n".join(fails)
 
