@@ -21,7 +21,8 @@ def train_step(sd, d, args, fps_start=None, dtype=torch.float64, arch="ref", dro
         s[k].requires_grad_(True)
     cloud = d["cloud"].to(dtype)
     if arch == "3sa":
-        cov, proba, ex = network.forward_3sa(s, cloud, d["xyz"], args, training=True, fps_start=fps_start, use_kdtree=use_kdtree)
+        cov, proba, ex = network.forward_3sa(s, cloud, d["xyz"], args, training=True, fps_start=fps_start, use_kdtree=use_kdtree,
+                                             bf16_layers=bf16_layers)
     else:
         fs = None if fps_start is None else (fps_start[0], fps_start[1])
         cov, proba, ex = network.forward(s, cloud, d["xyz"], args, training=True, fps_start=fs, use_kdtree=use_kdtree,

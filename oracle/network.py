@@ -217,7 +217,9 @@ def init_state_dict_3sa(seed: int = 0):
     return sd
 
 
-def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False):
+def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False, bf16_layers=()):
+    global BF16_LAYERS
+    BF16_LAYERS = tuple(bf16_layers)
     B, _, N = cloud.shape
     pos0 = xyz.permute(0, 2, 1).reshape(B * N, 3).contiguous()
     x0 = cloud.permute(0, 2, 1).reshape(B * N, -1)[:, 2:].contiguous()

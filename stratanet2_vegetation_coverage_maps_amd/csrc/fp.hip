@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void fp_bwd_src_dw_kernel(int n_src, int src_s
 // lane: 4096 rows are only 64 waves on a 1024-SIMD chip and each wave would issue >6000 dependent FMAs (the first
 // version ran 0.3-0.7 ms per kernel at ~1 % of the chip).  Here one workgroup = 64 rows x 4 waves and wave g owns the
 // output channels [g*COG, (g+1)*COG): 4x the waves, 4x shorter streams, the same weights-in-SGPR inner loops.
-template <int CA, int CB, int CO, bool KNN>
+template <int CA, int CB, int CO, bool KNN, bool BF16>
 __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot, int S_per_plot, int src_stride,
                                                            int skip_stride, int h_stride, const float* __restrict__ src,
                                                            const float* __restrict__ src_a, const float* __restrict__ src_c,
@@ -1008,19 +1008,28 @@ __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int k = 4 * kb + qq;
-        Wb[kb] = (g < NG && o < CO) ? (k < CI ? W[o * CI + k] : (k == CI ? bias[o] : 0.f)) : 0.f;
+        // bf16 operands: the bias stays out of the contraction (it would be rounded) and starts the accumulator instead
+        Wb[kb] = (g < NG && o < CO) ? (k < CI ? W[o * CI + k] : ((k == CI && !BF16) ? bias[o] : 0.f)) : 0.f;
     }
+    const float bias_o = (BF16 && g < NG && o < CO) ? bias[o] : 0.f;
     __syncthreads();
     float ssum = 0.f, ssq = 0.f;
     if (g < NG) {
         f32x4 D[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) D[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) D[t] = f32x4{bias_o, bias_o, bias_o, bias_o};
+        if constexpr (!BF16) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
+            for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    D[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_q[(16 * t + cc) * QS + 4 * kb + qq], Wb[kb], D[t], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                D[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_q[(16 * t + cc) * QS + 4 * kb + qq], Wb[kb], D[t], 0, 0, 0);
+                D[t] = contract<true, KB>(D[t], [&](int kb) { return s_q[(16 * t + cc) * QS + 4 * kb + qq]; },
+                                          [&](int kb) { return Wb[kb]; });
         }
         // D[t][j]: row 16 t + 4 qq + j, channel o
 #pragma unroll
@@ -1058,7 +1067,7 @@ constexpr size_t fp_split_lds_bytes(int slabs) {
 template <int CI>
 constexpr bool fp_split_du_seq() { return fp_split_lds_bytes<CI>(4) > 150 * 1024; }   // one slab, the waves take turns
 
-template <int CA, int CB, int CO, bool KNN>
+template <int CA, int CB, int CO, bool KNN, bool BF16>
 __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     int R, int R_per_plot, int S_per_plot, int src_stride, int skip_stride, int h_stride, int dskip_stride, int du_stride,
     float invR, const float* __restrict__ src, const float* __restrict__ src_a, const float* __restrict__ src_c,
@@ -1113,11 +1122,25 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
         const int r4 = lane >> 4, c16 = lane & 15;
         const float* rp = s_p + (g * 64 + r4) * 16 + c16;
         const float* rq = s_q + r4 * QS + c16;
+        if constexpr (!BF16) {
 #pragma unroll 4
-        for (int st = 0; st < 16; ++st) {
-            const float av = rp[st * 4 * 16];
+            for (int st = 0; st < 16; ++st) {
+                const float av = rp[st * 4 * 16];
 #pragma unroll
-            for (int c = 0; c < TK; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, rq[st * 4 * QS + c * 16], acc[c], 0, 0, 0);
+                for (int c = 0; c < TK; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, rq[st * 4 * QS + c * 16], acc[c], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8) {          // the block's 64 rows = the K of two v_mfma_f32_16x16x32_bf16
+                float av[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) av[u] = rp[(8 * s8 + u) * 4 * 16];
+#pragma unroll
+                for (int c = 0; c < TK; ++c)
+                    acc[c] = contract<true, 8>(acc[c], [&](int u) { return av[u]; },
+                                               [&](int u) { return rq[(8 * s8 + u) * 4 * QS + c * 16]; });
+            }
         }
     }
     // partial input gradient of this channel group, dp_g (64 x 16) . W_g (16 x CI), on the matrix cores: A[row][o] read
@@ -1143,12 +1166,19 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
                     f32x4 D[TJ];
 #pragma unroll
                     for (int jt = 0; jt < TJ; ++jt) D[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!BF16) {
 #pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {
-                        const float av = s_p[(g * 64 + 16 * tile + cc) * 16 + 4 * kb + qq];
+                        for (int kb = 0; kb < 4; ++kb) {
+                            const float av = s_p[(g * 64 + 16 * tile + cc) * 16 + 4 * kb + qq];
+#pragma unroll
+                            for (int jt = 0; jt < TJ; ++jt)
+                                D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wb[kb][jt], D[jt], 0, 0, 0);
+                        }
+                    } else {
 #pragma unroll
                         for (int jt = 0; jt < TJ; ++jt)
-                            D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wb[kb][jt], D[jt], 0, 0, 0);
+                            D[jt] = contract<true, 4>(D[jt], [&](int kb) { return s_p[(g * 64 + 16 * tile + cc) * 16 + 4 * kb + qq]; },
+                                                      [&](int kb) { return Wb[kb][jt]; });
                     }
 #pragma unroll
                     for (int jt = 0; jt < TJ; ++jt)
@@ -1225,13 +1255,15 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
         const int grid = sn2_cdiv(R, 64);
         constexpr size_t lf = (size_t)(64 * OuterAcc<16, CA + CB + 1>::QS + 2 * 16 * ((CO + 15) / 16)) * sizeof(float);
         static_assert(lf <= 48 * 1024, "fp_fwd_split_kernel staging");
-        hipLaunchKernelGGL((fp_fwd_split_kernel<CA, CB, CO, KNN>), dim3(grid), dim3(256), lf, st, R, p->R_per_plot,
+        auto kf = p->blk.mma_bf16 ? &fp_fwd_split_kernel<CA, CB, CO, KNN, true> : &fp_fwd_split_kernel<CA, CB, CO, KNN, false>;
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(256), lf, st, R, p->R_per_plot,
                            p->S_per_plot, p->src_stride, p->skip_stride, p->h_stride, p->src, p->src_a, p->src_c, p->knn_idx,
                            p->knn_w, p->skip, p->blk.W, p->blk.b, p->h, training ? p->blk.stat_slots : (float*)nullptr);
         hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return (int)e0;
         return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
     }
+    if (p->blk.mma_bf16) return SN2_ELIMIT;   // bf16 operands exist on the matrix-core kernel of the small layers only
     if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) {
         if (fp_source_side_ok<CA, CO>(p)) {               // the per-point layer: source-side form
             const int n_src = p->B * p->S_per_plot;
@@ -1316,8 +1348,9 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     constexpr size_t lb = fp_split_lds_bytes<CI>(fp_split_du_seq<CI>() ? 1 : 4);
     static_assert(lb <= 150 * 1024, "fp_bwd_split_kernel staging must fit LDS");
     const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS;   // the 64-row x 4-channel-group kernel for small layers
+    if (!small && p->blk.mma_bf16) return SN2_ELIMIT;       // bf16 operands: that kernel only
     if (small) {
-        auto ks = &fp_bwd_split_kernel<CA, CB, CO, KNN>;
+        auto ks = p->blk.mma_bf16 ? &fp_bwd_split_kernel<CA, CB, CO, KNN, true> : &fp_bwd_split_kernel<CA, CB, CO, KNN, false>;
         if (lb > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         hipLaunchKernelGGL(ks, dim3(sn2_cdiv(R, 64)), dim3(256), lb, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,

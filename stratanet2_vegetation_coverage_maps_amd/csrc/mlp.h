@@ -11,8 +11,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // sum_{kb < KBN} A(kb) * B(kb) to the tile, a(kb) / b(kb) returning this lane's two operand values of slot kb:
 //   BF16 = false:  one v_mfma_f32_16x16x4_f32 per slot, in slot order (exact fp32 products, fp32 accumulate);
 //   BF16 = true:   the operands are rounded to bfloat16 (v_cvt_pk_bf16_f32, round to nearest even) and EIGHT slots go
-//                  into one v_mfma_f32_16x16x32_bf16 (four into a v_mfma_f32_16x16x16_bf16 when no more than four are
-//                  left), fp32 accumulate -- BASELINE.json configs[4], "bf16 MLP weights on MFMA".  Which k a register
+//                  into one v_mfma_f32_16x16x32_bf16 (a contraction of no more than four slots uses one
+//                  v_mfma_f32_16x16x16_bf16), fp32 accumulate -- BASELINE.json configs[4], "bf16 MLP weights on MFMA".  Which k a register
 //                  slot stands for does not matter as long as A and B agree, so the fp32 operand registers are reused as
 //                  they are: lane (q, c) holds 8 (4) consecutive entries of the instruction's K = 32 (16).
 // Loop-invariant operands (the weights) are converted once: the conversions are hoisted out of the loops by the compiler.
@@ -26,9 +26,13 @@ __device__ __forceinline__ f32x4 contract(f32x4 acc, FA a, FB b) {
 #pragma unroll
         for (int kb = 0; kb < KBN; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a(kb), b(kb), acc, 0, 0, 0);
     } else {
+        // One instruction shape per accumulation chain: a v_mfma_f32_16x16x16_bf16 that takes the result of a
+        // v_mfma_f32_16x16x32_bf16 as its accumulator three instructions later read two of its four registers too early
+        // on this toolchain (ROCm 7.2; rows 4q+0, 4q+1 of the tile wrong, scripts/debug_bf16_sa3.py) -- so more than four
+        // slots use the K = 32 form throughout (a short tail is padded with zeros), four or fewer the K = 16 form.
 #pragma unroll
         for (int k0 = 0; k0 < KBN; k0 += 8) {
-            if (KBN - k0 > 4) {
+            if (KBN > 4) {
                 bf16x8 av, bv;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {

@@ -156,7 +156,10 @@ class PointNet2(nn.Module):
         if self.cuda_device is not None:
             self.cuda(self.cuda_device)
 
-    BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn")     # the blocks `mma_dtype = "bf16"` applies to
+    # the blocks `mma_dtype = "bf16"` applies to: everything that runs on the matrix cores -- the set-abstraction levels and
+    # the dense layers over centroids (SA3, FP3, FP2).  The two per-point layers (FP1 in its source-side form, the head)
+    # are VALU streaming kernels bound by HBM, not by arithmetic: they stay fp32.
+    BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn", "sa3_module.nn", "fp3_module.nn", "fp2_module.nn")
     mma_dtype = "fp32"
 
     def set_mma_dtype(self, dtype: str):
@@ -414,12 +417,12 @@ class PointNet2(nn.Module):
         aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)
         stats = torch.empty(STAT_SLOTS * 2 * sum(widths), dtype=F32, device=dev)
         cur = [0, 0]
-        bf = self.mma_dtype == "bf16"
-        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur, bf)
-        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur, bf)
-        s.b_sa3 = _blocks_of(self.sa3_module.nn, aux, stats, cur)[0]
-        s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur)[0]
-        s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur)[0]
+        bf = lambda prefix: self.mma_dtype == "bf16" and prefix in self.BF16_BLOCKS      # noqa: E731
+        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur, bf("sa1_module.conv.local_nn"))
+        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur, bf("sa2_module.conv.local_nn"))
+        s.b_sa3 = _blocks_of(self.sa3_module.nn, aux, stats, cur, bf("sa3_module.nn"))[0]
+        s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur, bf("fp3_module.nn"))[0]
+        s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur, bf("fp2_module.nn"))[0]
         s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
         s.aux, s.stats = aux, stats
 

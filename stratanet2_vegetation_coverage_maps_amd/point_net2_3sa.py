@@ -52,7 +52,8 @@ class PointNet2ThreeSA(PointNet2):
             self.cuda(self.cuda_device)
 
     N_FPS = 3
-    BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn", "sa3_module.conv.local_nn")
+    BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn", "sa3_module.conv.local_nn", "sa4_module.nn",
+                   "fp4_module.nn", "fp3_module.nn", "fp2_module.nn")
 
     def _sizes3(self, N):
         M1 = ops.fps_num_samples(N, self.sa1_module.ratio)
@@ -153,10 +154,10 @@ class PointNet2ThreeSA(PointNet2):
         s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur, bf)
         s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur, bf)
         s.b_sa3 = _blocks_of(self.sa3_module.conv.local_nn, aux, stats, cur, bf)
-        s.b_sa4 = _blocks_of(self.sa4_module.nn, aux, stats, cur)[0]
-        s.b_fp4 = _blocks_of(self.fp4_module.nn, aux, stats, cur)[0]
-        s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur)[0]
-        s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur)[0]
+        s.b_sa4 = _blocks_of(self.sa4_module.nn, aux, stats, cur, bf)[0]
+        s.b_fp4 = _blocks_of(self.fp4_module.nn, aux, stats, cur, bf)[0]
+        s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur, bf)[0]
+        s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur, bf)[0]
         s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
         s.aux, s.stats = aux, stats
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731

@@ -74,3 +74,26 @@ def test_bf16_variant_at_default_initialisation():
     fs = torch.zeros(2, B, dtype=torch.long)
     d["fps_start"] = fs
     _check(f"{B} x {N}, default init", args, network.init_state_dict(4), d, fs, tol_out=1e-3, tol_grad=2e-2)
+
+
+def test_bf16_variant_of_the_3sa_architecture():
+    """The same for the 3sa-arch variant (third ball-query level CF = 32, global level on 64 + 3, FP4 on 64 + 64 inputs)."""
+    from stratanet2_vegetation_coverage_maps_amd.point_net2_3sa import PointNet2ThreeSA
+    B, N = 2, 4096
+    args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0, ratio3=0.25, r3=4.0, mma_dtype="bf16")
+    d = make_batch(B, N, first_plot=500)
+    fs = torch.zeros(3, B, dtype=torch.long)
+    d["fps_start"] = fs
+    sd = network.init_state_dict_3sa(2)
+    m = PointNet2ThreeSA(args)
+    m.set_mma_dtype("bf16")
+    m.load_state_dict(sd)
+    m.train()
+    cov, proba = m(d)
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+    loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
+    loss.backward()
+    ref = check.train_step(sd, d, args, fps_start=fs, arch="3sa", bf16_layers=PointNet2ThreeSA.BF16_BLOCKS)
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, tol_out=1e-3, tol_grad=2e-2, pred=pred)
+    print(f"\n[bf16, 3sa {B} x {N}] vs the oracle with the same operand rounding:\n  {report}")
+    assert not fails, "\n".join(fails)
