@@ -102,9 +102,18 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
         f"sn2_fps:N={m1}": 12 * m1 * B + 32 * m2 * B,
         f"sn2_ball_query:N={N}": 12 * (N + m1) * B + 4 * e1 + 4 * m1 * B,
         f"sn2_ball_query:N={m1}": 12 * (m1 + m2) * B + 4 * e2 + 4 * m2 * B,
+        # 3-NN of the N points among the m1 centroids (x,y-grid search): positions in, 3 x (index, weight) out
+        f"sn2_three_nn_xy:T={N}": 12 * (m1 + N) * B + 24 * N * B,
+        f"sn2_three_nn_xy:T={m1}": 12 * (m2 + m1) * B + 24 * m1 * B,
         f"sn2_three_nn:T={N}": 12 * (m1 + N) * B + 24 * N * B,
         f"sn2_three_nn:T={m1}": 12 * (m2 + m1) * B + 24 * m1 * B,
         f"sn2_three_nn:T={m2}": 12 * (1 + m2) * B + 24 * m2 * B,
+        # inverted 3-NN index (source -> (row, weight) list): the three tables (rows N, m1, m2) in, the same entries out in
+        # source order + offsets/counts and the sources' Morton order; ONE figure for the entry point (its three calls per
+        # step are summed by the timer)
+        "sn2_interp_index": 3 * (24 + 8) * (N + m1 + m2) * B + 24 * (m1 + m2 + 1) * B,
+        # work items of the SA passes: counts in, 4 ints per centroid out (both levels)
+        "sn2_sa_order": (4 + 16) * (m1 + m2) * B,
         "sn2_pack_rows": (44 + 48) * N * B,
         # SA1: per pass 4 B index + 48 B gathered row per message (the gather is L2 traffic once the 1.5 MB/plot
         # table is resident; counted here as the algorithmic upper bound), 2 forward passes / 2 backward passes
@@ -128,8 +137,8 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
 
 # entry point -> the kernel that dominates it (names as rocprofv3 prints them, see profiles/*_pmc_traffic.json)
 DOMINANT_KERNEL = {
-    "sn2_fps:N=32768": "fps_bucket_kernel<32, 16>", "sn2_ball_query:N=32768": "ball_query_grid_kernel",
-    "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2>",
+    "sn2_fps:N=32768": "fps_spec_kernel<32, 16, 8>", "sn2_ball_query:N=32768": "ball_query_grid_kernel",
+    "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>",
     "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34>",
     "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512>",
     "sn2_head_forward": "head_fwd_kernel", "sn2_head_backward": "head_bwd_kernel",
@@ -177,14 +186,14 @@ def rocprof_kernel_avg_ms(entry):
 
 def cpu_baseline():
     """The oracle (CPU restatement of the reference path, kd-tree neighbour search, all host cores) on a bounded
-    sample of the same workload: 4 plots of 32 768 points, 1 warm-up step, then timed steps until ~12 s of CPU work are
-    done (at most 20)."""
+    sample of the same workload: the metric's own batch (16 plots of 32 768 points, ~2.7 s per step on 16 threads), 1 warm-up
+    step, then timed steps until ~12 s of CPU work are done (at least 3, at most 20)."""
     from oracle import losses as olosses, network, projection
     # the GPU box gives one GPU's job a share of 16 cores whatever os.cpu_count() says: more OpenMP threads than that
     # only spin against each other
     ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
     torch.set_num_threads(ncores)
-    B = 4
+    B = PLOTS_PER_GPU
     args = workload_args(None)
     d = make_batch(B, N_POINTS)
     sd = network.init_state_dict(0)
@@ -202,7 +211,7 @@ def cpu_baseline():
         opt.step()
         times.append(time.perf_counter() - t0)
         log(f"cpu_baseline step {it}: {times[-1]:.2f} s")
-        if it >= 1 and (times[-1] > 60 or sum(times[1:]) > 12.0):
+        if it >= 3 and (times[-1] > 60 or sum(times[1:]) > 12.0):
             break
     t = sum(times[1:]) / len(times[1:])
     return {"value": round(B / t, 3), "unit": "plots/s", "cores": ncores, "kind": "port",
@@ -349,13 +358,10 @@ def main():
         for _ in range(max(0, a.warmup - 1)):
             step()
         if not a.eager and world == 1:
-            try:
-                graph, loss_static = capture_serial()
-                launch = "hipGraph"
-            except Exception as exc:                 # noqa: BLE001 - fall back loudly, never silently change the work
-                log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eager")
-                graph = None
-                torch.cuda.synchronize()
+            # a failed capture is an error, not a mode switch: an eager run under the same metric string would be a different
+            # measurement (--eager asks for it explicitly)
+            graph, loss_static = capture_serial()
+            launch = "hipGraph"
         mode = f"serial/{launch}"
     else:
         # ---- software pipeline (stratanet2_vegetation_coverage_maps_amd/pipeline.py): geometry of batches i+1..i+depth on
@@ -363,15 +369,8 @@ def main():
         from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
         pipe = TrainPipeline(model, opt, feature_step, slots, depth=a.depth, use_graph=not a.eager,
                              split_exchange=True if a.split_exchange else None)
-        try:
-            pipe.capture()
-            launch = "eager" if a.eager else "hipGraph"
-        except Exception as exc:                     # noqa: BLE001
-            log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); pipeline runs eager")
-            torch.cuda.synchronize()
-            pipe = TrainPipeline(model, opt, feature_step, slots, depth=a.depth, use_graph=False)
-            pipe.capture()
-            launch = "eager"
+        pipe.capture()                               # a failed hipGraph capture raises: no silent eager fallback
+        launch = "eager" if a.eager else "hipGraph"
         if a.host_inputs:
             pinned = [{k: v.cpu().pin_memory() for k, v in sl.items() if k in ("cloud", "xyz", "gt", "pdf")} for sl in slots]
             pipe.set_feeder(lambda i: pinned[i % len(pinned)])
@@ -447,11 +446,13 @@ def main():
             by = algorithmic_bytes(k, B, N_POINTS, m1, m2, e1, e2)
             kernels.append({"entry": k, "ms": round(tms, 4),
                             "alg_GBps": None if by is None else round(by / (tms * 1e-3) / 1e9, 1)})
+        CALLS_PER_STEP = {"sn2_interp_index": 3, "sn2_sa_order": 2}     # entry points whose byte model covers all their calls of a step
+
         def roofline_of(entry, note):
             if not entry or entry not in dom:
                 return None
             c, tms = dom[entry]
-            avg_ms = tms / c
+            avg_ms = tms / (c / CALLS_PER_STEP.get(entry, 1))
             by = algorithmic_bytes(entry, B, N_POINTS, m1, m2, e1, e2)
             ach = None if by is None else by / (avg_ms * 1e-3) / 1e9
             traffic, tsrc = pmc_traffic(entry)
@@ -462,6 +463,18 @@ def main():
                     "dominant_device_kernel_avg_ms_rocprof": rocprof_kernel_avg_ms(entry),
                     "timing": ("HIP events inside the timed region" if mode == "serial/eager" else
                                "HIP events over 5 unpipelined eager steps right after the timed region"), "note": note}
+        # ---- the whole step against both roofs: compulsory HBM bytes and dense-layer flops of ONE step
+        E1p, E2p = e1 / B, e2 / B                                                    # messages per plot
+        fwd_flops = 864 * E1p + 1216 * E2p + 4480 * m2 + 12288 * m2 + 5440 * m1 + 2856 * N_POINTS + 1248 * N_POINTS
+        step_flops = B * (3 * fwd_flops - 352 * E1p)
+        fwd_bytes = 368 * N_POINTS + 8 * (E1p + E2p) + 16 * (m1 + m2) + 8 * (16 * m1 + 32 * m2 + 64 + 64 * m2 + 34 * m1) + 48 * m1 + 16 * m2
+        step_bytes = B * 2.2 * fwd_bytes
+        MFMA_PEAK = {"f32": 157.3e12, "bf16": 2.5e15}[a.dtype]
+        whole_step = {"compulsory_bytes": int(step_bytes), "hbm_frac": round(step_bytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                      "dense_flops": int(step_flops), "mfma_frac": round(step_flops / (ms * 1e-3) / MFMA_PEAK, 4),
+                      "mfma_peak_TFLOPs": MFMA_PEAK / 1e12,
+                      "what": "SURVEY.md 8d: compulsory HBM bytes (2.2 x forward) and dense-layer flops (3 x forward - 352 E1) of "
+                              "one step at the measured message counts, over the timed ms_per_step"}
         roof = roofline_of(dominant, "longest entry point of the feature pass, the stream that bounds the pipelined step "
                                      "(the geometry passes run beside it on side streams)" if not a.serial else
                            "longest entry point of the step")
@@ -486,7 +499,16 @@ def main():
                           "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
                "loss": round(loss_value, 6), "roofline": roof, "kernels": kernels}
+        if roof is not None:
+            roof["whole_step"] = whole_step
         if roof_geo is not None:
+            if roof_geo["kernel"].startswith("sn2_fps"):
+                # farthest point sampling: M strictly sequential arg-max rounds per plot -- what describes it is the time per
+                # sample and how little of the chip it occupies, not a bandwidth
+                roof_geo["us_per_sample"] = round(roof_geo["avg_ms"] * 1e3 / max(1, m1 - 1), 4)
+                roof_geo["workgroups"] = B * (2 if (pipe is not None and pipe.pair) else 1)
+                roof_geo["compute_units"] = 256
+                roof_geo["bound"] = "latency"
             out["roofline_off_critical_path"] = roof_geo
         if serial_ms is not None:
             out["unpipelined"] = {"ms_per_step": round(serial_ms, 4), "plots_per_s": round(B / (serial_ms * 1e-3), 2),

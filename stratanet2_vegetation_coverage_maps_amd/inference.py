@@ -109,6 +109,7 @@ def predict_parcel(model, batches, mosaic: ParcelMosaic, args, prefetch: int = 3
             cd["geometry"] = geo
         cov, _ = model(cd)
         clouds_dev = model._last_cloud_dev[1]
+        model._last_cloud_dev = None
         rasters, _ = project_batch_to_2d_rasters(clouds_dev, cov, args)
         mosaic.add(rasters, cur["plot_center"])
         n += clouds_dev.shape[0]

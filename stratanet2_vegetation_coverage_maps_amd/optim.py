@@ -26,6 +26,29 @@ def allreduce_flat_grad(flat_grad: torch.Tensor, world_size: int, group=None) ->
     return 1.0 / world_size
 
 
+def broadcast_bn_buffers(model, world_size: int, src: int = 0, group=None) -> int:
+    """Optional second exchange of the data-parallel path (torch DDP's `broadcast_buffers`): every rank takes
+    rank `src`'s BatchNorm running statistics -- 520 floats + 7 counters, one small broadcast.  The training step does not
+    need it (batch statistics are per GPU, as DDP without SyncBN; the weights stay identical through the all-reduced
+    gradient), but without it the replicas' EVAL-mode outputs drift apart, because each rank's running statistics follow
+    its own shard.  Call it every K steps or before evaluating / checkpointing from a rank other than `src`.
+    Returns the number of floats exchanged."""
+    bufs = [b for n, b in model.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
+    cnts = [b for n, b in model.named_buffers() if n.endswith("num_batches_tracked")]
+    if world_size <= 1 or not bufs:
+        return 0
+    flat = torch.cat([b.reshape(-1).float() for b in bufs] + [c.reshape(-1).float() for c in cnts])
+    torch.distributed.broadcast(flat, src=src, group=group)
+    o = 0
+    for b in bufs:
+        b.copy_(flat[o:o + b.numel()].view_as(b))
+        o += b.numel()
+    for c in cnts:
+        c.copy_(flat[o:o + 1].view_as(c).to(c.dtype))
+        o += 1
+    return int(flat.numel())
+
+
 def flatten_parameters(model) -> torch.Tensor:
     params = list(model.parameters())
     offs, n = ops.flat_layout(params)

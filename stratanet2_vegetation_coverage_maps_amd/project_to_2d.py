@@ -45,6 +45,8 @@ def project_to_plotwise_coverages(pred_pointwise, clouds, args, model=None):
     cache = getattr(model, "_last_cloud_dev", None) if model is not None else None
     with torch.cuda.device(pred_pointwise.device):
         clouds_dev = _clouds_on_device(clouds, pred_pointwise.device, cache)
+        if cache is not None:
+            model._last_cloud_dev = None          # used once: do not keep the batch's host and device clouds alive
         return _PlotProject.apply(pred_pointwise, clouds_dev, args.diam_pix)
 
 
