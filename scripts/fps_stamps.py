@@ -34,9 +34,8 @@ if os.environ.get("SN2_FPS_SPECULATE", "1") != "0":
     print(f"  total {tot/rounds:.1f} ticks/super-round = {tot/d[4]:.1f} per sample (s_memtime ticks = shader clocks)")
     o2 = (ctypes.c_ulonglong * 32)()
     lib.sn2_debug_fps_stamps2(o2)
+    print(f"  (C) per-wave top-4 (wave 0, both runs): {o2[24] / (2 * rounds):.1f} ticks/super-round")
     print("  accepted per super-round (both runs), histogram 0..16:", list(o2[:17]))
-    print("  why the prefix ended: tie/hidden %d, not above next max %d, own second max %d, an earlier bucket's second max %d, K reached %d, "
-          "touched by an earlier sample %d" % tuple(o2[17:23]))
 else:
     names = ["(a) tests", "(b) dirty loop", "(c) wave reduce+publish", "barrier wait", "(d) select/next sample"]
     tot = sum(d[:5])

@@ -546,7 +546,9 @@ __global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restri
     float* s_max2 = s_val + NBK;                                   // [NBK] >= the second largest (== s_val: treated as a tie)
     unsigned* s_q = reinterpret_cast<unsigned*>(s_max2 + NBK);     // [NBK] work queue of a super-round: bucket | samples << 11
     float2* s_top = reinterpret_cast<float2*>(s_q + NBK);          // [NW*T] per-wave maxima: (value, bucket | place << 16)
-    int* s_ctl = reinterpret_cast<int*>(s_top + NW * T);           // [0] accepted (0: tie search), [1] done, [2] tie value, [3] queue length
+    float2* s_cand = s_top + NW * T;                               // [K + 2] the selection's candidates in order (+ the next one)
+    int* s_keys = reinterpret_cast<int*>(s_cand + K + 2);          // [64] the selection's integer keys
+    int* s_ctl = s_keys + 64;           // [0] accepted (0: tie search), [1] done, [2] tie value, [3] queue length
     unsigned* s_win = reinterpret_cast<unsigned*>(s_ctl + 4);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -710,80 +712,70 @@ __global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restri
                 if (lane == 0) s_top[wave * T + t] = make_float2(m, __int_as_float(gsel | (t << 16)));
             }
         }
+        STAMP(t3b);
         __syncthreads();
         STAMP(t4);
-        // (D) wave 0: the K+1 largest of the NW*T values in order, acceptance tests, emission
+        // (D) wave 0: the K+1 largest of the NW*T values in order, acceptance tests, emission -- written for latency: this
+        // wave runs alone while the other fifteen wait (reduction chains, one per candidate, took 5300 clocks here).
+        //   ranks: every entry counts the entries above it (integer keys = value bits with the low 6 bits replaced by the
+        //   entry's place, so all keys differ; 16 broadcast LDS reads + 64 compare-and-adds, no chains) and drops itself
+        //   into s_cand[rank];   tests: lane 8 e + j looks at the pair (candidate e, earlier candidate j);
+        //   prefix length: scalar bit arithmetic on two ballots.
         if (wave == 0) {
+            static_assert(K == 8, "the acceptance tests use an 8 x 8 lane grid");
             const float2 tp = s_top[lane < NW * T ? lane : 0];
-            float val = lane < NW * T ? tp.x : -3.f;
-            const int tg = __float_as_int(tp.y);
-            // (measured: ranking the 64 entries by compare-and-count, 5 instructions per entry and lane, is slower than these
-            // K+1 reduction chains: 7800 against 6000 clocks per super-round at K = 8)
-            float cm = -4.f;                  // lane e: value of candidate e
-            int cg = 0;                       //         its bucket
-            bool cbad = true;                 //         tie with another bucket / its wave has no further known value
+            const float val = lane < NW * T ? tp.x : -3.f;
+            const int key = (__float_as_int(val) & ~63) | (63 - lane);
+            s_keys[lane] = key;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int rank = 0;
 #pragma unroll
-            for (int e = 0; e <= K; ++e) {
-                const float m = wave_max_fused(val);
-                const unsigned long long bal = __ballot(val == m);
-                const int owner = __ffsll((long long)bal) - 1;
-                const int g = __builtin_amdgcn_readlane(tg, owner);
-                if (lane == e) {
-                    cm = m;
-                    cg = g & 0xFFFF;
-                    cbad = (__popcll(bal) > 1) || ((g >> 16) >= T - 1);
-                }
-                if (lane == owner) val = -3.f;
+            for (int q4 = 0; q4 < 16; ++q4) {
+                const int4 k4 = reinterpret_cast<const int4*>(s_keys)[q4];
+                rank += (k4.x > key ? 1 : 0) + (k4.y > key ? 1 : 0) + (k4.z > key ? 1 : 0) + (k4.w > key ? 1 : 0);
             }
-            const float mnext = __shfl_down(cm, 1);
-            const bool isc = lane < K;
-            const float4 pt = s_pt[isc ? cg : 0];
-            const float mx2 = s_max2[isc ? cg : 0];
-            bool ok = isc && !cbad && cm > mnext && mx2 < cm && cm > 0.f;
-#ifdef SN2_FPS_STAMPS
-            bool touched = false;
-#endif
+            if (rank <= K) s_cand[rank] = make_float2(val, tp.y);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int e = lane >> 3, jj = lane & 7;
+            const float2 ce = s_cand[e], cj = s_cand[jj], cn = s_cand[e + 1];
+            const float me = ce.x;
+            const int ie = __float_as_int(ce.y), ij = __float_as_int(cj.y);
+            const float4 pte = s_pt[ie & 0xFFFF], ptj = s_pt[ij & 0xFFFF];
+            const float m2e = s_max2[ie & 0xFFFF], m2j = s_max2[ij & 0xFFFF];
+            // strictly above the next maximum even at the keys' 64-ulp resolution (then above every other entry too), own
+            // bucket's second maximum below it, and its wave still has a known next value (a wave's fifth largest is unknown)
+            const bool self_ok = (ie >> 16) < T - 1 && me > 0.f && (__float_as_int(me) >> 6) > (__float_as_int(cn.x) >> 6) && m2e < me;
+            const bool pair_bad = jj < e && (sn2_d2(pte.x, pte.y, pte.z, ptj.x, ptj.y, ptj.z) < me || m2j >= me);
+            const unsigned long long okm = __ballot(self_ok), badm = __ballot(pair_bad);
+            int nj = 0;
 #pragma unroll
-            for (int e = 0; e < K - 1; ++e) {
-                const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.x), e));
-                const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.y), e));
-                const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.z), e));
-                const float jm2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx2), e));
-                if (e < lane && (sn2_d2(pt.x, pt.y, pt.z, jx, jy, jz) < cm || jm2 >= cm)) ok = false;
-#ifdef SN2_FPS_STAMPS
-                if (e < lane && sn2_d2(pt.x, pt.y, pt.z, jx, jy, jz) < cm) touched = true;
-#endif
+            for (int c = 0; c < K; ++c) {
+                const bool okc = ((okm >> (8 * c)) & 1ull) != 0 && ((badm >> (8 * c)) & 0xFFull) == 0;
+                if (okc && nj == c) nj = c + 1;
             }
-            const unsigned long long okm = __ballot(ok);
-            int nj = __ffsll((long long)~okm) - 1;             // length of the accepted prefix
-            nj = nj > K ? K : nj;
 #ifdef SN2_FPS_STAMPS
-            if (b == 0) {
-                // why did the prefix end at candidate nj?  1 tie/hidden, 2 not above the next maximum, 3 own second max,
-                // 4 touched by an earlier sample or an earlier bucket's second max, 5 K reached
-                int why = 5;
-                if (nj < K) {
-                    const bool c1 = cbad, c2 = !(cm > mnext), c3 = !(mx2 < cm);
-                    const int w = c1 ? 1 : (c2 ? 2 : (c3 ? 3 : (touched ? 6 : 4)));
-                    why = __builtin_amdgcn_readlane(w, nj);
-                }
-                if (lane == 0) { g_fps_dbg2[nj] += 1; g_fps_dbg2[16 + why] += 1; }
-            }
+            if (b == 0 && lane == 0) g_fps_dbg2[nj] += 1;
 #endif
             const int rem = M - cnt;
             nj = nj > rem ? rem : nj;
-            if (lane < nj) {
-                s_acc[lane] = make_float4(pt.x, pt.y, pt.z, 0.f);
-                out_idx[cnt + lane] = -1 - __float_as_int(pt.w);
-                cpos_soa[((size_t)b * 3 + 0) * M + cnt + lane] = pt.x;
-                cpos_soa[((size_t)b * 3 + 1) * M + cnt + lane] = pt.y;
-                cpos_soa[((size_t)b * 3 + 2) * M + cnt + lane] = pt.z;
-                reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M + cnt + lane] = make_float4(pt.x, pt.y, pt.z, 0.f);
+            if (jj == 0 && e < nj) {
+                s_acc[e] = make_float4(pte.x, pte.y, pte.z, 0.f);
+                out_idx[cnt + e] = -1 - __float_as_int(pte.w);
+                cpos_soa[((size_t)b * 3 + 0) * M + cnt + e] = pte.x;
+                cpos_soa[((size_t)b * 3 + 1) * M + cnt + e] = pte.y;
+                cpos_soa[((size_t)b * 3 + 2) * M + cnt + e] = pte.z;
+                reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M + cnt + e] = make_float4(pte.x, pte.y, pte.z, 0.f);
             }
+            // no candidate accepted = the maximum is not unique at the keys' resolution: the tie search needs the TRUE maximum
+            // (candidate 0 is only the first of the entries that share the top key)
+            float vtop = 0.f;
+            if (nj == 0) vtop = wave_max_fused(val);
             if (lane == 0) {
                 s_ctl[0] = nj;
                 s_ctl[1] = (cnt + (nj > 0 ? nj : 1) >= M) ? 1 : 0;
-                s_ctl[2] = __builtin_amdgcn_readlane(__float_as_int(cm), 0);
+                s_ctl[2] = __float_as_int(vtop);
                 s_ctl[3] = 0;
                 *s_win = 0xFFFFFFFFu;
             }
@@ -797,8 +789,9 @@ __global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restri
         if (b == 0 && tid == 0) {
             g_fps_dbg[0] += t1 - t0;
             g_fps_dbg[1] += t2 - t1;
-            g_fps_dbg[2] += t5 - t3;
-            g_fps_dbg[3] += (t3 - t2) + (t6 - t5);
+            g_fps_dbg[2] += t5 - t4;
+            g_fps_dbg[3] += (t3 - t2) + (t6 - t5) + (t4 - t3b);
+            g_fps_dbg2[24] += t3b - t3;
             g_fps_dbg[4] += (unsigned long long)(j > 0 ? j : 1);
             g_fps_dbg[5] += (unsigned long long)qn;
             g_fps_dbg[6] += 1;
@@ -851,7 +844,7 @@ __global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restri
 
 template <int SPW, int NW, int K>
 static size_t fps_spec_lds_bytes() {
-    return (size_t)(SPW * NW) * 16 + (size_t)K * 16 + (size_t)(SPW * NW) * 4 * 9 + (size_t)NW * 4 * 8 + 32;
+    return (size_t)(SPW * NW) * 16 + (size_t)K * 16 + (size_t)(SPW * NW) * 4 * 9 + (size_t)NW * 4 * 8 + (size_t)(K + 2) * 8 + 64 * 4 + 32;
 }
 
 #ifndef SN2_FPS_K
@@ -898,6 +891,12 @@ extern "C" int sn2_fps(const float* pos_soa, int B, int N, int M, const int* sta
     hipStream_t st = (hipStream_t)stream;
     if (order_ws && N > 2048 && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
         // bucketed path (exact, see above): up to 128 bucket slots per wave = 131 072 points per plot
+#ifdef SN2_FPS_NW8
+        if (N <= 4096) return launch_fps_bucket<8, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 8192) return launch_fps_bucket<16, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 16384) return launch_fps_bucket<32, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 32768) return launch_fps_bucket<64, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+#endif
         if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
