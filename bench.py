@@ -479,9 +479,10 @@ def main():
                                      "(the geometry passes run beside it on side streams)" if not a.serial else
                            "longest entry point of the step")
         roof_geo = None if a.serial else roofline_of(
-            longest_geometry, "longest entry point overall, off the critical path: fps is M strictly sequential arg-max "
-                              "rounds in one workgroup per plot (latency-bound by construction; 16 of 256 CUs busy); its HBM "
-                              "traffic is 12 B/point once, so an HBM fraction says little about it")
+            longest_geometry, "longest entry point overall, off the critical path: fps is a chain of arg-max rounds in one "
+                              "workgroup per plot (up to 8 exact samples per round; latency-bound: see us_per_sample and "
+                              "workgroups / compute_units); its HBM traffic is 12 B/point once, so the HBM fraction says "
+                              "nothing about it")
         out = {"metric": "plots/s fwd+bwd, 32k-pt synthetic plots, batch 16/GPU", "value": round(world * B / (ms * 1e-3), 2),
                "unit": "plots/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",

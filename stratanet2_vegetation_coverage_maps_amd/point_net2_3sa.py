@@ -150,14 +150,14 @@ class PointNet2ThreeSA(PointNet2):
         aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)
         stats = torch.empty(STAT_SLOTS * 2 * sum(widths), dtype=F32, device=dev)
         cur = [0, 0]
-        bf = self.mma_dtype == "bf16"
-        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur, bf)
-        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur, bf)
-        s.b_sa3 = _blocks_of(self.sa3_module.conv.local_nn, aux, stats, cur, bf)
-        s.b_sa4 = _blocks_of(self.sa4_module.nn, aux, stats, cur, bf)[0]
-        s.b_fp4 = _blocks_of(self.fp4_module.nn, aux, stats, cur, bf)[0]
-        s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur, bf)[0]
-        s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur, bf)[0]
+        bf = lambda prefix: self.mma_dtype == "bf16" and prefix in self.BF16_BLOCKS      # noqa: E731
+        s.b_sa1 = _blocks_of(self.sa1_module.conv.local_nn, aux, stats, cur, bf("sa1_module.conv.local_nn"))
+        s.b_sa2 = _blocks_of(self.sa2_module.conv.local_nn, aux, stats, cur, bf("sa2_module.conv.local_nn"))
+        s.b_sa3 = _blocks_of(self.sa3_module.conv.local_nn, aux, stats, cur, bf("sa3_module.conv.local_nn"))
+        s.b_sa4 = _blocks_of(self.sa4_module.nn, aux, stats, cur, bf("sa4_module.nn"))[0]
+        s.b_fp4 = _blocks_of(self.fp4_module.nn, aux, stats, cur, bf("fp4_module.nn"))[0]
+        s.b_fp3 = _blocks_of(self.fp3_module.nn, aux, stats, cur, bf("fp3_module.nn"))[0]
+        s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur, bf("fp2_module.nn"))[0]
         s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
         s.aux, s.stats = aux, stats
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
