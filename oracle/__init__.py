@@ -28,8 +28,12 @@ Parity status
       kd-tree (points at exactly the radius, Lambert-sized coordinates): bit for bit.
   `tests/test_oracle_golden_aux.py` holds the restatements to those fixtures; the `-m gpu` tests hold the HIP kernels to
   the same fixtures.  Unpinned remainder: the rounding of a geotransform to integer pixel offsets (rasterio's job).
+* `oracle/check.py`: one training step of the oracle in a chosen precision; the GPU tests use its fp64 evaluation as the
+  yardstick (same fp32 geometry), because the fp32 CPU evaluation is itself ~1e-3 away from the exact network at the
+  metric's size while the HIP path is ~2e-6 away (tests/test_gpu_metric_size.py prints both).
 * Third-party primitives (`oracle/primitives.py`): PARITY UNPINNED -- the reference holds no tests,
   fixtures or golden vectors and the wheels are absent and un-fetchable, so the
   primitives are restated from their published algorithms; every assumption is listed in the
-  docstring of the function that makes it.
+  docstring of the function that makes it, and `tests/test_oracle_primitives.py` pins the restatement to
+  hand-computed known answers and to scipy's kd-tree on exactly those assumptions.
 """
