@@ -983,6 +983,12 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 // instead of 32 768.  A ball with more hits than the LDS list (GQ_LIST) falls back to the full scan for that centroid.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int GQ_LIST = 512;
+#ifndef SN2_GQ_DENSE
+#define SN2_GQ_DENSE 512
+#endif
+constexpr int GQ_DENSE = SN2_GQ_DENSE;   // hits beyond which the bitmap path takes over from the rank sort (measured: switching at 192
+                                         // instead of 512 made the query slower at both sizes, 0.30 vs 0.26 ms at 8 x 131 072, 0.075 vs 0.054 at 16 x 32 768)
+static_assert(GQ_DENSE <= GQ_LIST, "the list holds the sparse balls");
 
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __restrict__ src, int B, int N,
                                                               const float* __restrict__ cpos, int M, float r, float r2,
@@ -991,9 +997,12 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
                                                               int* __restrict__ nbr, int* __restrict__ cnt,
                                                               unsigned long long* __restrict__ total) {
     __shared__ int s_list[4][GQ_LIST];
+    extern __shared__ unsigned gq_bits[];              // [4][(N + 31) / 32]: one bit per source point, per wave (dense balls)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int ci = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
     if (ci >= B * M) return;
+    const int nwords = (N + 31) >> 5;
+    unsigned* bits = gq_bits + (size_t)wib * nwords;
     const int b = ci / M, m = ci - b * M;
     const float cx = cpos[((size_t)b * 3 + 0) * M + m], cy = cpos[((size_t)b * 3 + 1) * M + m],
                 cz = cpos[((size_t)b * 3 + 2) * M + m];
@@ -1024,6 +1033,7 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
     const int ncx = hi3[0] - lo3[0] + 1, ncy = hi3[1] - lo3[1] + 1, ncz = hi3[2] - lo3[2] + 1;
     const int ncell = ncx * ncy * ncz;
     bool overflow = ncell > 64;
+    bool dense = false;                                // more hits than the list holds: the bitmap path below
     if (!overflow) {
         __shared__ int s_pre[4][65], s_p0[4][64];
         int p0 = 0, len = 0;
@@ -1061,13 +1071,63 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
             const unsigned long long mask = __ballot(hit);
             if (mask) {
                 const int nh = __popcll(mask);
-                if (h + nh > GQ_LIST) {
-                    overflow = true;
+                if (h + nh > GQ_DENSE) {
+                    dense = true;
                     break;
                 }
                 if (hit) list[h + __popcll(mask & below)] = ord[p];
                 h += nh;
             }
+        }
+        if (dense) {
+            // A dense ball (the ground layer of a 131 072-point plot puts ~700 points into a 1 m ball): rank-sorting h hits
+            // costs h^2 / 64 steps and the old fallback re-scanned the whole plot (2048 steps per centroid: 0.78 ms at
+            // BASELINE config 5).  Instead: one bit per source point in LDS, the candidates walked once more to set the
+            // hits' bits, then the bitmap read in order -- ascending original index by construction, no sort, any count.
+            for (int i = lane; i < nwords; i += 64) bits[i] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                const bool in = t < T;
+                int lo_i = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int mid = lo_i + step;
+                    if (mid < ncell && s_pre[wib][mid] <= t) lo_i = mid;
+                }
+                const int p = in ? s_p0[wib][lo_i] + (t - s_pre[wib][lo_i]) : 0;
+                const float4 qv = pts[p];
+                if (in && (sn2_d2(qv.x, qv.y, qv.z, cx, cy, cz) < r2)) {
+                    const int oi = ord[p];
+                    atomicOr(&bits[oi >> 5], 1u << (oi & 31));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int* outd = nbr + (size_t)ci * cap;
+            int n = 0;
+            for (int w0 = 0; w0 < nwords; w0 += 64) {
+                unsigned word = (w0 + lane < nwords) ? bits[w0 + lane] : 0u;
+                const int c = __popc(word);
+                if (__ballot(c != 0) == 0ull) continue;
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int tt = __shfl_up(incl, o);
+                    if (lane >= o) incl += tt;
+                }
+                int pos = n + incl - c;
+                while (word) {
+                    const int bit = __ffs(word) - 1;
+                    word &= word - 1;
+                    if (pos < cap) outd[pos] = (w0 + lane) * 32 + bit;
+                    ++pos;
+                }
+                n += __shfl(incl, 63);
+            }
+            if (lane == 0) cnt[ci] = n < cap ? n : cap;
+            return;
         }
     }
     int* out = nbr + (size_t)ci * cap;
@@ -1128,7 +1188,10 @@ extern "C" int sn2_ball_query(const float* src_soa, int B, int N, const float* c
         const int* order = fps_ws;
         const float4* sorted = reinterpret_cast<const float4*>(fps_ws + (size_t)B * N);
         const int* grid = fps_ws + (size_t)5 * B * N;
-        hipLaunchKernelGGL(ball_query_grid_kernel, dim3(sn2_cdiv((long)B * M, 4)), dim3(256), 0, (hipStream_t)stream, src_soa,
+        const size_t lds = (size_t)4 * ((N + 31) / 32) * sizeof(unsigned);       // the dense-ball bitmaps: 64 KB at N = 131 072
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ball_query_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL(ball_query_grid_kernel, dim3(sn2_cdiv((long)B * M, 4)), dim3(256), lds, (hipStream_t)stream, src_soa,
                            B, N, cpos_soa, M, r, r2, cap, order, sorted, grid, nbr, cnt, total);
         if (total) hipLaunchKernelGGL(count_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)cnt, B * M, total);
         SN2_RETURN_LAUNCH();
