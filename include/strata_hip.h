@@ -55,6 +55,8 @@ typedef struct sn2_block {
                                       v_mfma_f32_16x16x32_bf16 / 16x16x16, fp32 accumulate); ReLU, BatchNorm, statistics, the
                                       extremum and everything that decides an index stay fp32 (BASELINE.json configs[4]).
                                       0: exact fp32 products (v_mfma_f32_16x16x4_f32), the reference's precision.          */
+    long long *num_batches_tracked; /* BatchNorm1d's int64 counter (one element) or NULL: += 1 by the training forward,
+                                       inside the statistics finalisation (no launch of its own)                           */
 } sn2_block;
 /* flat[i] += sum_{r=1..replicas-1} flat[r*stride + i], i < n: folds the images of a flat gradient vector into image 0 */
 int sn2_grad_reduce(float *flat, int n, int replicas, int stride, void *stream);
@@ -75,6 +77,11 @@ int sn2_pack_rows(const float *cloud, const float *xyz, int B, int C, int N, flo
 #define SN2_FPS_WS_WORDS(B, N) (5L * (B) * (N) + 4104L * (B))
 int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
             float *cpos_aos, int *order_ws, void *stream);
+/* The same with a hint for the bucketed kernel: waves per plot, 16 (= 0, what sn2_fps uses: shortest pass when FPS runs
+ * alone) or 8 (a 9 % longer pass that leaves half of each occupied CU to concurrent kernels: the setting of a pipelined
+ * loop where the pass runs beside another batch's feature kernels).  Same indices either way. */
+int sn2_fps_waves(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
+                  float *cpos_aos, int *order_ws, int waves, void *stream);
 
 /* radius ball query -- torch_cluster.radius, model/point_net2.py:23-25.
  * For centroid i of plot b: all source points j of plot b with d2 < r2 (strict, canonical fp32 arithmetic; r2 = the
@@ -246,9 +253,10 @@ int sn2_fp_bn_sums(const sn2_fp *p, const float *gamma, const float *beta, float
 int sn2_plot_project_forward(const float *pred_pointwise, const float *cloud_xy, long plot_stride, int B, int N,
                              int D, unsigned long long *keys, int *pix, int *arg, int *nocc, float *pred,
                              void *stream);
-/* d pred (B,4) -> d pred_pointwise (B*N,4), which the caller zeroed. */
-int sn2_plot_project_backward(const float *dpred, const int *arg, const int *nocc, int B, int N, int D,
-                              float *dpointwise, void *stream);
+/* d pred (B,4) -> d pred_pointwise (B*N,4): every row written (a point gets its pixel's gradient iff it is the pixel's
+ * arg-max; pix, arg, nocc from the forward). */
+int sn2_plot_project_backward(const float *dpred, const int *arg, const int *nocc, const int *pix, int B, int N,
+                              int D, float *dpointwise, void *stream);
 
 /* P1 project_to_2d_rasters (:58-113): fixed grid, clipped; rasters (B,3,D,D) [low,med,high], image[y,x], NaN where
  * empty, rows flipped; pix (B*N) int32 out = y_pix*D + x_pix (unflipped).  coverages (B*N,4) row-major. */
@@ -300,7 +308,7 @@ int sn2_loss_backward(const float *pred, const double *gt, int B, const float *p
 /* ---- optimiser step of the timed training step -- torch.optim.Adam as configured in learning/train.py:180-185
  * (L2 weight decay added to the gradient), on flat buffers; grad_scale multiplies the gradient first (1/world). */
 int sn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int *step_dev /* device counter, incremented here */,
+                  float beta2, float eps, float weight_decay, int *step_dev /* two device ints: {steps taken so far (incremented here), 0} */,
                   float grad_scale, void *stream);
 
 #ifdef __cplusplus

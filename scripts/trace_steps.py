@@ -37,3 +37,10 @@ for r in rows:
         others[(r['Queue_Id'], r['Kernel_Name'][:50])].append(r['e'] - r['s'])
 for k, v in sorted(others.items(), key=lambda kv: -sum(kv[1]))[:10]:
     print('side', k, 'n/step %.1f mean %.1f us' % (len(v) / nst, statistics.mean(v) / 1000))
+if len(sys.argv) > 3 and sys.argv[3] == 'seq':          # the last step's launches in order: offset, duration, gap to the previous one
+    a, b = ends[-2], ends[-1]
+    ks = sorted([r for r in rows if r['Queue_Id'] == q and r['s'] >= a and r['e'] <= b], key=lambda r: r['s'])
+    prev = a
+    for i, r in enumerate(ks):
+        print('%3d  +%7.1f us  %6.1f us  gap %5.1f  %s' % (i, (r['s'] - a) / 1000, (r['e'] - r['s']) / 1000, (r['s'] - prev) / 1000, r['Kernel_Name'][:100]))
+        prev = r['e']

@@ -17,7 +17,8 @@ class Block(Structure):  # sn2_block
                 ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("a", c_void_p),
                 ("c", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("stat_slots", c_void_p),
                 ("dW", c_void_p), ("db", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
-                ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("mma_bf16", c_int)]
+                ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("mma_bf16", c_int),
+                ("num_batches_tracked", c_void_p)]
 
 
 class SA(Structure):  # sn2_sa
@@ -50,6 +51,7 @@ SIGNATURES = {
     "sn2_version": [],
     "sn2_pack_rows": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_fps": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sn2_fps_waves": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "sn2_ball_query": [c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_void_p],
     "sn2_three_nn": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -74,7 +76,7 @@ SIGNATURES = {
     "sn2_head_backward": [POINTER(Head), c_void_p],
     "sn2_plot_project_forward": [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p],
-    "sn2_plot_project_backward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sn2_plot_project_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_raster_project": [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                            c_void_p],
     "sn2_mosaic_merge": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

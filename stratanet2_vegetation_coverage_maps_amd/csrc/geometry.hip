@@ -885,18 +885,22 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
     SN2_RETURN_LAUNCH();
 }
 
-extern "C" int sn2_fps(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
-                       float* cpos_aos, int* order_ws, void* stream) {
+extern "C" int sn2_fps_waves(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
+                             float* cpos_aos, int* order_ws, int waves, void* stream) {
     if (!pos_soa || !idx || !cpos_soa || !cpos_aos || B <= 0 || N <= 0 || M <= 0 || M > N) return SN2_EINVAL;
+    if (waves != 0 && waves != 16 && waves != 8) return SN2_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (order_ws && N > 2048 && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
-        // bucketed path (exact, see above): up to 128 bucket slots per wave = 131 072 points per plot
-#ifdef SN2_FPS_NW8
-        if (N <= 4096) return launch_fps_bucket<8, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 8192) return launch_fps_bucket<16, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 16384) return launch_fps_bucket<32, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 32768) return launch_fps_bucket<64, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-#endif
+        // bucketed path (exact, see above): up to 128 bucket slots per wave = 131 072 points per plot.
+        // waves = 8: half the waves per plot.  Alone the pass is 9 % slower (1.37 vs 1.26 ms at 32 x 32 768: fewer loads in
+        // flight), but it leaves half of its CU's wave slots to whatever else runs: beside the feature pass of a pipelined
+        // training loop the STEP is 2.4 % shorter (0.918 vs 0.940 ms; 4 waves: 2.07 ms alone, 0.922 ms per step).
+        if (waves == 8 && N <= 32768) {
+            if (N <= 4096) return launch_fps_bucket<8, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+            if (N <= 8192) return launch_fps_bucket<16, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+            if (N <= 16384) return launch_fps_bucket<32, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+            return launch_fps_bucket<64, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        }
         if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
@@ -914,6 +918,11 @@ extern "C" int sn2_fps(const float* pos_soa, int B, int N, int M, const int* sta
     if (N <= 16384) return launch_fps<16, 1024>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 32768) return launch_fps<32, 1024, true>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     return SN2_ELIMIT;
+}
+
+extern "C" int sn2_fps(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
+                       float* cpos_aos, int* order_ws, void* stream) {
+    return sn2_fps_waves(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, order_ws, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------

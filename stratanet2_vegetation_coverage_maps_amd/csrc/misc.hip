@@ -9,7 +9,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ a, float* __restrict__ c, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, const float* __restrict__ slots, int nslots,
-                                   const unsigned long long* __restrict__ count_dev, long count_imm, int training) {
+                                   const unsigned long long* __restrict__ count_dev, long count_imm, int training,
+                                   long long* __restrict__ num_batches_tracked) {
     // thread = (slot group g, column col of the 2C-wide slot row): consecutive threads read consecutive floats of one slot
     // row (coalesced; one lane per (channel, 16 slots) with a 2C-float stride took 13 us for 1024 slots), every thread adds
     // its slots g, g+G, ... in fp64 in a fixed order, then the G partials of a column are added in a fixed order: the
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
     const int j = 0;
     const float eps = 1e-5f, mom = 0.1f;
     if (!live || j != 0) return;
+    if (training && o == 0 && num_batches_tracked) *num_batches_tracked += 1;   // BatchNorm1d's counter: once per training forward
     float mean, invstd;
     if (training) {
         double n = count_dev ? (double)(*count_dev) : (double)count_imm;
@@ -72,7 +74,7 @@ int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* 
     if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
                        blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
-                       count_dev, count_imm, training);
+                       count_dev, count_imm, training, blk->num_batches_tracked);
     SN2_RETURN_LAUNCH();
 }
 
@@ -159,36 +161,45 @@ extern "C" int sn2_plot_max_backward(const float* dout, const int* arg, int B, i
 // ------------------------------------------------------------------------------------------------------------
 // torch.optim.Adam (amsgrad=False, L2 weight decay folded into the gradient) on flat fp32 buffers.
 // ------------------------------------------------------------------------------------------------------------
-// The step counter lives on the device (adam_tick_kernel increments it, adam_kernel reads it), so a captured hipGraph
-// of the whole training step replays with the right bias corrections.
-__global__ void adam_tick_kernel(int* __restrict__ step) { *step += 1; }
-
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float wd,
-                            const int* __restrict__ step, float gscale) {
+// The step counter lives on the device, so a captured hipGraph of the whole training step replays with the right bias
+// corrections.  step[0] = steps taken so far, step[1] = arrival ticket (zero between launches): every workgroup reads
+// step[0] before it takes a ticket, and the workgroup that takes the last one stores the incremented count -- one launch
+// (a one-thread "tick" kernel in front of this one was 4 us of every step).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
+                                                   float wd, int* __restrict__ step, float gscale) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float t = (float)(*step);
-    const float bc1 = 1.f - powf(b1, t);
-    const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
-    float grad = g[i] * gscale;
-    const float pi = p[i];
-    grad = fmaf(wd, pi, grad);
-    const float mi = m[i] + (1.f - b1) * (grad - m[i]);       // lerp, as torch
-    const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    const int now = __hip_atomic_load(&step[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (i < n) {
+        const float t = (float)now;
+        const float bc1 = 1.f - powf(b1, t);
+        const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
+        float grad = g[i] * gscale;
+        const float pi = p[i];
+        grad = fmaf(wd, pi, grad);
+        const float mi = m[i] + (1.f - b1) * (grad - m[i]);       // lerp, as torch
+        const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+    __syncthreads();                                               // every wave of this workgroup has its count
+    if (threadIdx.x == 0) {
+        const int ticket = atomicAdd(&step[1], 1);
+        if (ticket == (int)gridDim.x - 1) {                        // all workgroups have read step[0]
+            __hip_atomic_store(&step[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&step[0], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 extern "C" int sn2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int* step_dev, float grad_scale,
                              void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || n <= 0) return SN2_EINVAL;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     hipLaunchKernelGGL(adam_kernel, dim3(sn2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (const int*)step_dev, grad_scale);
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
     SN2_RETURN_LAUNCH();
 }
 

@@ -185,24 +185,22 @@ __global__ __launch_bounds__(256) void p2_finalize_kernel(const unsigned long lo
 }
 
 __global__ void p2_backward_kernel(const float* __restrict__ dpred, const int* __restrict__ arg,
-                                   const int* __restrict__ nocc, int B, int N, int D, float* __restrict__ dpw) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int per_plot = D * D * 3;
-    if (i >= B * per_plot) return;
-    const int b = i / per_plot, slot = i % 3;
-    const int n = arg[i];
-    if (n < 0 || n >= N) return;
+                                   const int* __restrict__ nocc, const int* __restrict__ pix, int B, int N, int D,
+                                   float4* __restrict__ dpw) {
+    // gather form: a point receives a pixel's gradient iff it is that pixel's arg-max, so every row of dpointwise is
+    // written exactly once (no zero fill in front, no scatter): one launch
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i - (size_t)b * N);
+    const int* a = arg + ((size_t)b * D * D + pix[i]) * 3;
     const float inv = 1.0f / fmaxf((float)nocc[b], 1.f);
-    float g;
-    int ch;
-    if (slot == 0) {  // low vegetation also feeds bare soil = 1 - low
-        g = (dpred[b * 4 + 0] - dpred[b * 4 + 1]) * inv;
-        ch = 0;
-    } else {
-        ch = slot + 1;
-        g = dpred[b * 4 + ch] * inv;
-    }
-    dpw[((size_t)b * N + n) * 4 + ch] = g;
+    const float4 g = reinterpret_cast<const float4*>(dpred)[b];
+    float4 o;
+    o.x = a[0] == n ? (g.x - g.y) * inv : 0.f;   // low vegetation also feeds bare soil = 1 - low
+    o.y = 0.f;
+    o.z = a[1] == n ? g.z * inv : 0.f;
+    o.w = a[2] == n ? g.w * inv : 0.f;
+    dpw[i] = o;
 }
 
 // P1: rasters (B,3,D,D) [low,med,high], image[y][x], NaN where empty, rows flipped (project_to_2d.py:80-113)
@@ -241,11 +239,11 @@ extern "C" int sn2_plot_project_forward(const float* pred_pointwise, const float
     SN2_RETURN_LAUNCH();
 }
 
-extern "C" int sn2_plot_project_backward(const float* dpred, const int* arg, const int* nocc, int B, int N, int D,
-                                         float* dpointwise, void* stream) {
-    if (!dpred || !arg || !nocc || !dpointwise || B <= 0 || N <= 0 || D <= 0) return SN2_EINVAL;
-    hipLaunchKernelGGL(p2_backward_kernel, dim3(sn2_cdiv((long)B * D * D * 3, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dpred, arg, nocc, B, N, D, dpointwise);
+extern "C" int sn2_plot_project_backward(const float* dpred, const int* arg, const int* nocc, const int* pix, int B, int N,
+                                         int D, float* dpointwise, void* stream) {
+    if (!dpred || !arg || !nocc || !pix || !dpointwise || B <= 0 || N <= 0 || D <= 0) return SN2_EINVAL;
+    hipLaunchKernelGGL(p2_backward_kernel, dim3(sn2_cdiv((long)B * N, 256)), dim3(256), 0, (hipStream_t)stream, dpred, arg,
+                       nocc, pix, B, N, D, reinterpret_cast<float4*>(dpointwise));
     SN2_RETURN_LAUNCH();
 }
 

@@ -47,13 +47,12 @@ class timing:
         return out
 
 
-def _call(name, *args, tag=None):
+def _call(name, *args, tag=None, key=None):
     fn = getattr(_lib.load(), name)
     t = _timing
+    key = key or name                       # the name the entry point is reported under
     if tag is not None:
-        key = f"{name}:{tag}"
-    else:
-        key = name
+        key = f"{key}:{tag}"
     if t is not None and (t.names is None or key in t.names):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -131,8 +130,10 @@ def fps_fills_ws(B: int, N: int, m: int) -> bool:
 
 
 def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True,
-        return_ws: bool = False, out=None):
+        return_ws: bool = False, out=None, waves: int = 0):
     """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
+    waves: 0/16 or 8 waves per plot in the bucketed kernel (include/strata_hip.h: sn2_fps_waves; 8 = the pass that shares its
+    CUs with concurrent kernels, what the pipelined training loop asks for); same indices.
     bucketed=False forces the brute-force kernel (same result; kept for cross-checks).  return_ws=True also returns
     the spatial-order workspace (or None), which `ball_query` over the same points can reuse.
     out = (idx, cpos_soa, cpos_aos, workspace-or-None): caller-owned result buffers (persistent pipelines)."""
@@ -158,8 +159,8 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
         cs = torch.empty(B, 3, m, dtype=F32, device=dev)
         ca = torch.empty(B * m, 4, dtype=F32, device=dev)
         order = torch.empty(fps_ws_words(B, N), dtype=I32, device=dev) if use_ws else None
-    _call("sn2_fps", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), _stream(),
-          tag=f"N={N}")
+    _call("sn2_fps_waves", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), int(waves),
+          _stream(), tag=f"N={N}", key="sn2_fps")
     if return_ws:
         return idx, cs, ca, order
     return idx, cs, ca
@@ -283,6 +284,10 @@ class BlockBuffers:
         blk.running_mean, blk.running_var = _ptr(self.bn.running_mean), _ptr(self.bn.running_var)
         blk.a, blk.c, blk.mean, blk.invstd = (_ptr(self.aux[i]) for i in range(4))
         blk.stat_slots = _ptr(self.stats)
+        nbt = self.bn.num_batches_tracked
+        if nbt is not None:
+            _chk(nbt, I64, None, "num_batches_tracked")
+        blk.num_batches_tracked = _ptr(nbt) if nbt is not None else None
         if with_grads:
             dW, db, dg, dbeta = self.grads
             for t, ref in ((dW, self.lin.weight), (db, self.lin.bias), (dg, self.bn.weight), (dbeta, self.bn.bias)):
@@ -652,13 +657,14 @@ def plot_project_forward(pred_pointwise: torch.Tensor, clouds_dev: torch.Tensor,
     return pred, pix, arg, nocc
 
 
-def plot_project_backward(dpred, arg, nocc, B, N, diam_pix):
+def plot_project_backward(dpred, arg, nocc, pix, B, N, diam_pix):
     D = int(diam_pix)
     _chk(dpred, F32, (B, 4), "dpred")
     _chk(arg, I32, (B * D * D * 3,), "arg")
     _chk(nocc, I32, (B,), "nocc")
-    dpw = torch.zeros(B * N, 4, dtype=F32, device=dpred.device)
-    _call("sn2_plot_project_backward", _ptr(dpred), _ptr(arg), _ptr(nocc), B, N, D, _ptr(dpw), _stream())
+    _chk(pix, I32, (B * N,), "pix")
+    dpw = torch.empty(B * N, 4, dtype=F32, device=dpred.device)
+    _call("sn2_plot_project_backward", _ptr(dpred), _ptr(arg), _ptr(nocc), _ptr(pix), B, N, D, _ptr(dpw), _stream())
     return dpw
 
 
@@ -747,10 +753,10 @@ def loss_backward(pred, gt, proba, pdf, m: float, e: float, grad_total):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):
-    """step_dev: int32 device tensor (1,) holding the number of steps taken so far; incremented by the call."""
+    """step_dev: int32 device tensor (2,) = {number of steps taken so far (incremented by the call), 0}."""
     n = param.numel()
     for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(t, F32, (n,), nme)
-    _chk(step_dev, I32, (1,), "step_dev")
+    _chk(step_dev, I32, (2,), "step_dev")
     _call("sn2_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1, beta2, eps,
           weight_decay, _ptr(step_dev), grad_scale, _stream())

@@ -77,12 +77,15 @@ class _TotalLoss(torch.autograd.Function):
         out = ops.loss_forward(pred, gt, proba, pdf, m, e)
         ctx.save_for_backward(pred, proba, gt, pdf)
         ctx.me = (m, e)
+        ctx.set_materialize_grads(False)     # no zero tensors (= three fill launches per step) for the unused component outputs
         total, l_abs, l_log, l_e = out[0], out[1], out[2], out[3]
         ctx.mark_non_differentiable(l_abs, l_log, l_e)
         return total, l_abs, l_log, l_e
 
     @staticmethod
     def backward(ctx, g, *_):
+        if g is None:
+            return None, None, None, None, None, None
         pred, proba, gt, pdf = ctx.saved_tensors
         m, e = ctx.me
         dpred, dproba = ops.loss_backward(pred, gt, proba, pdf, m, e, g.to(torch.float64).contiguous())

@@ -70,7 +70,9 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.flat.device)   # on the device: graph-replay safe
+        # on the device (graph-replay safe): {steps taken so far, the kernel's arrival ticket}
+        self.step_words = torch.zeros(2, dtype=torch.int32, device=self.flat.device)
+        self.step_dev = self.step_words[:1]
         self.world_size = world_size
         self.process_group = process_group
 
@@ -85,4 +87,4 @@ class FlatAdam:
             raise RuntimeError("FlatAdam.step: no gradient (run backward through PointNet2 first)")
         scale = allreduce_flat_grad(g, self.world_size, self.process_group)   # RCCL over xGMI when world > 1
         ops.adam_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                      self.weight_decay, self.step_dev, scale)
+                      self.weight_decay, self.step_words, scale)

@@ -46,6 +46,8 @@ class TrainPipeline:
         if self.pair and len(slot_inputs) % 2:
             raise ValueError("pair mode needs an even number of slots")
         self.model, self.opt, self.feature_step = model, opt, feature_step
+        # the passes already run beside each other on the side streams: no further fork inside a pass
+        self._geo_kw = {"fork": False, "shared": True} if hasattr(model, "geometry_fork") else {}
         self.inputs = slot_inputs
         self.depth, self.slots = depth, len(slot_inputs)
         dev = slot_inputs[0]["xyz"].device
@@ -75,10 +77,29 @@ class TrainPipeline:
         self.issued = 0                           # geometry passes launched so far
         self.done = 0                             # feature passes launched so far
         self.use_graph = use_graph
+        self.slot_wait = "host"                   # how a geometry pass waits for its slots to be free: _wait_slots
         self.feeder = None                        # optional: feeder(i) -> dict of HOST tensors for batch number i
         # exchange between the backward graph and the Adam graph (always when world > 1; can be forced on one GPU to
         # exercise exactly the launch sequence the multi-GPU run uses)
         self.split_exchange = (getattr(opt, "world_size", 1) > 1) if split_exchange is None else bool(split_exchange)
+
+    def _wait_slots(self, st, ks):
+        """Before a geometry pass overwrites the tables of slots `ks`, the feature passes that last read them must have
+        finished.  `slot_wait == "host"` (default): the HOST waits on the later of their events; the passes are issued
+        `ahead` batches in front, so the device still has one or more whole steps queued while the host waits.
+        `"device"`: `hipStreamWaitEvent` on the side stream.  Measured (scripts/debug_marginal.py): a side stream waiting on
+        events of the main stream costs the MAIN stream 0.07 ms per step even with nothing else on the side streams
+        (0.694 -> 0.766 ms; every recorded event then has to signal another queue), the host wait costs nothing."""
+        evs = [self.slot_done[k] for k in ks if self.slot_done[k] is not None]
+        if len(evs) < len(ks):
+            st.wait_stream(torch.cuda.current_stream(self.dev))      # first use of a slot: after whatever filled it
+        if not evs:
+            return
+        if self.slot_wait == "host":
+            evs[-1].synchronize()                 # recorded in main-stream order: the last one implies the others
+        else:
+            for ev in evs:
+                st.wait_event(ev)
 
     # ---- geometry of batch number i (its inputs must already be in slot i % slots)
     def issue_geometry(self, i=None):
@@ -87,10 +108,7 @@ class TrainPipeline:
             return self._issue_pair(i)
         k = i % self.slots
         st = self.side[i % self.n_streams]
-        if self.slot_done[k] is not None:
-            st.wait_event(self.slot_done[k])      # the feature pass that last read this slot's tables has finished
-        else:
-            st.wait_stream(torch.cuda.current_stream(self.dev))
+        self._wait_slots(st, (k,))                # the feature pass that last read this slot's tables has finished
         with torch.cuda.stream(st):
             d = self.inputs[k]
             if self.feeder is not None:
@@ -98,7 +116,7 @@ class TrainPipeline:
                 # in front of the geometry pass that reads it and behind the feature pass that last read the slot
                 for name, t in self.feeder(i).items():
                     d[name].copy_(t, non_blocking=not getattr(self, 'feeder_blocking', False))
-            self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k])
+            self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k], **self._geo_kw)
             self.geo_ready[k].record(st)
         self.issued = max(self.issued, i + 1)
 
@@ -109,11 +127,7 @@ class TrainPipeline:
         k0, k1 = i % self.slots, (i + 1) % self.slots
         pb = k0 // 2
         st = self.side[(i // 2) % self.n_streams]
-        for k in (k0, k1):
-            if self.slot_done[k] is not None:
-                st.wait_event(self.slot_done[k])
-            else:
-                st.wait_stream(torch.cuda.current_stream(self.dev))
+        self._wait_slots(st, (k0, k1))
         with torch.cuda.stream(st):
             for j, k in ((i, k0), (i + 1, k1)):
                 d = self.inputs[k]
@@ -167,7 +181,7 @@ class TrainPipeline:
                 with torch.cuda.graph(g2, pool=pool):
                     ops.adam_step(self.opt.flat, self.flat_grad[k], self.opt.exp_avg, self.opt.exp_avg_sq, self.opt.lr,
                                   self.opt.betas[0], self.opt.betas[1], self.opt.eps, self.opt.weight_decay,
-                                  self.opt.step_dev, 1.0 / world)
+                                  self.opt.step_words, 1.0 / world)
                 self.graph_opt[k] = g2
         torch.cuda.synchronize(self.dev)
 

@@ -161,6 +161,8 @@ class PointNet2(nn.Module):
     # are VALU streaming kernels bound by HBM, not by arithmetic: they stay fp32.
     BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn", "sa3_module.nn", "fp3_module.nn", "fp2_module.nn")
     mma_dtype = "fp32"
+    fps_waves_shared = 8       # waves per plot of the level-1 FPS when its pass shares the chip with feature kernels
+    geometry_fork = True       # `_geometry`: the three independent chains behind the level-1 FPS on three streams
 
     def set_mma_dtype(self, dtype: str):
         """"fp32" (default: exact fp32 products, the reference's precision) or "bf16": the dense contractions of
@@ -254,51 +256,56 @@ class PointNet2(nn.Module):
         g.ready = None
         return g
 
-    def _geometry(self, xyz, fps_start, out=None):
+    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False):
         """Everything that depends on the point POSITIONS only (no weights, no features): both FPS levels, both ball
         queries, the three 3-NN tables.  In the reference these are the torch_cluster calls inside SAModule / FPModule
         (point_net2.py:22-25, 63).  Because they need no parameters they can run ahead of the feature kernels: see
         `prefetch_geometry`.  `out`: buffers from `alloc_geometry` to write into (no allocation, same addresses every
-        time: what a hipGraph-replayed feature pass needs)."""
+        time: what a hipGraph-replayed feature pass needs).
+        `fork` (default `self.geometry_fork`): after the level-1 FPS the three independent chains -- (a) ball query 1 +
+        its work items, (b) level-2 FPS, ball query 2, the two small 3-NN tables, (c) the per-point 3-NN table + its
+        inverted index -- run on three streams and join before returning (captured into a hipGraph they become parallel
+        branches): the level-2 FPS is 16 workgroups for 0.15 ms, chains (a) and (c) fill the chip beside it.
+        `shared`: the pass runs beside other batches' feature kernels (a pipelined loop, `prefetch_geometry`): the level-1
+        FPS takes `fps_waves_shared` waves per plot (include/strata_hip.h: sn2_fps_waves)."""
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
-        if out is not None:
-            g = out
-            if (g.B, g.N, g.M1, g.M2) != (B, N, M1, M2):
-                raise ValueError("geometry buffers do not match this batch")
-            g.xyz = xyz
-            ops.fps(xyz, M1, fps_start[0], out=(g.idx1, g.pos1_soa, g.pos1_aos, g.ws1))
-            ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
+        g = out if out is not None else self.alloc_geometry(B, N, dev)
+        if (g.B, g.N, g.M1, g.M2) != (B, N, M1, M2):
+            raise ValueError("geometry buffers do not match this batch")
+        g.xyz = xyz
+        fork = self.geometry_fork if fork is None else fork
+        cur = torch.cuda.current_stream(dev)
+        ops.fps(xyz, M1, fps_start[0], out=(g.idx1, g.pos1_soa, g.pos1_aos, g.ws1),
+                waves=self.fps_waves_shared if shared else 0)
+        if fork:
+            if getattr(self, "_fork_streams", None) is None or self._fork_streams[0].device != dev:
+                self._fork_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            sb, sc = self._fork_streams
+            sb.wait_stream(cur)
+            sc.wait_stream(cur)
+        else:
+            sb = sc = cur
+        with torch.cuda.stream(sb):                                        # (b) the level-2 chain
             ops.fps(g.pos1_soa, M2, fps_start[1], out=(g.idx2, g.pos2_soa, g.pos2_aos, g.ws2))
             ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, g.tot2, fps_ws=g.ws2,
                            out=(g.nbr2, g.cnt2))
-            ops.sa_order(g.cnt1, B, M1, out=g.ord1)
             ops.sa_order(g.cnt2, B, M2, out=g.ord2)
             ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
             ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[0])
-            ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1])
+            # the inverted 3-NN tables the backward pass gathers through: positions only, so they belong here
             ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
             ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
+        with torch.cuda.stream(sc):                                        # (c) the per-point table
+            ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1])
             ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
-            return g
-        g = _Saved()
-        g.B, g.N, g.M1, g.M2, g.xyz = B, N, M1, M2, xyz
-        totals = torch.zeros(2, dtype=I64, device=dev)
-        g.idx1, g.pos1_soa, g.pos1_aos, ws1 = ops.fps(xyz, M1, fps_start[0], return_ws=True)
-        g.nbr1, g.cnt1, g.tot1 = ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, totals[0:1], fps_ws=ws1)
-        g.idx2, g.pos2_soa, g.pos2_aos, ws2 = ops.fps(g.pos1_soa, M2, fps_start[1], return_ws=True)
-        g.nbr2, g.cnt2, g.tot2 = ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, totals[1:2],
-                                                fps_ws=ws2)
-        g.ord1, g.ord2 = ops.sa_order(g.cnt1, B, M1), ops.sa_order(g.cnt2, B, M2)
-        pos3 = torch.zeros(B, 3, 1, dtype=F32, device=dev)      # GlobalSAModule: pos = zeros (point_net2.py:40)
-        g.knn3 = ops.three_nn(pos3, g.pos2_soa, 1)
-        g.knn2 = ops.three_nn(g.pos2_soa, g.pos1_soa, 3)
-        g.knn1 = ops.three_nn(g.pos1_soa, xyz, 3)
-        # the inverted 3-NN tables the backward pass gathers through: positions only, so they belong here
-        g.inv3 = ops.interp_index(g.knn3, B, M2, 1)
-        g.inv2 = ops.interp_index(g.knn2, B, M1, M2)
-        g.inv1 = ops.interp_index(g.knn1, B, N, M1, src_pos=g.pos1_aos)
+        # (a)
+        ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
+        ops.sa_order(g.cnt1, B, M1, out=g.ord1)
+        if fork:
+            cur.wait_stream(sb)
+            cur.wait_stream(sc)
         return g
 
     def alloc_geometry_pair(self, B, N, device=None):
@@ -338,7 +345,8 @@ class PointNet2(nn.Module):
         M1, M2 = self._sizes(N)
         if (gp.B, gp.N) != (B2, N):
             raise ValueError("geometry buffers do not match this batch pair")
-        ops.fps(xyz2, M1, fps_start2[0], out=(gp.idx1, gp.pos1_soa, gp.pos1_aos, gp.ws1))
+        # 8 waves per plot: this pass runs beside other batches' feature kernels (sn2_fps_waves)
+        ops.fps(xyz2, M1, fps_start2[0], out=(gp.idx1, gp.pos1_soa, gp.pos1_aos, gp.ws1), waves=self.fps_waves_shared)
         ops.ball_query(xyz2, gp.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, gp.tot1, fps_ws=gp.ws1, out=(gp.nbr1, gp.cnt1))
         ops.fps(gp.pos1_soa, M2, fps_start2[1], out=(gp.idx2, gp.pos2_soa, gp.pos2_aos, gp.ws2))
         ops.ball_query(gp.pos1_soa, gp.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, gp.tot2, fps_ws=gp.ws2,
@@ -379,7 +387,7 @@ class PointNet2(nn.Module):
             xyz_d.record_stream(side)
             fs.record_stream(side)
             with torch.cuda.stream(side):
-                g = self._geometry(xyz_d, fs)
+                g = self._geometry(xyz_d, fs, shared=True)
                 g.fps_start = fs
                 g.ready = torch.cuda.Event()
                 g.ready.record(side)
@@ -457,8 +465,6 @@ class PointNet2(nn.Module):
         s.drop_keep = drop_keep
         ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, drop_mask=drop_keep,
                                        drop_p=self.drop))
-        if training:
-            torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)], 1)
         return cov, proba, s
 
     # ---- descriptors (shared by forward and backward; gradient views are attached for the backward call)

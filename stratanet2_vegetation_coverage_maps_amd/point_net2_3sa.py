@@ -185,8 +185,6 @@ class PointNet2ThreeSA(PointNet2):
         s.drop_keep = drop_keep
         ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, drop_mask=drop_keep,
                                        drop_p=self.drop))
-        if training:
-            torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)], 1)
         return cov, proba, s
 
     def _sa3l_desc(self, s, dout=None, dfeat=None, g=False):

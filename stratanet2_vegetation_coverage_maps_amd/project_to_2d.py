@@ -16,16 +16,15 @@ class _PlotProject(torch.autograd.Function):
     def forward(ctx, pred_pointwise, clouds_dev, diam_pix):
         B, _, N = clouds_dev.shape
         pred, pix, arg, nocc = ops.plot_project_forward(pred_pointwise.contiguous(), clouds_dev, diam_pix)
-        ctx.save_for_backward(arg, nocc)
+        ctx.save_for_backward(arg, nocc, pix)
         ctx.dims = (B, N, int(diam_pix))
-        ctx.pix = pix
         return pred
 
     @staticmethod
     def backward(ctx, dpred):
-        arg, nocc = ctx.saved_tensors
+        arg, nocc, pix = ctx.saved_tensors
         B, N, D = ctx.dims
-        return ops.plot_project_backward(dpred.contiguous().float(), arg, nocc, B, N, D), None, None
+        return ops.plot_project_backward(dpred.contiguous().float(), arg, nocc, pix, B, N, D), None, None
 
 
 def _clouds_on_device(clouds, device, model_cache=None):

@@ -44,6 +44,15 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
     assert torch.equal(i_b, i_f) and torch.equal(cs_b, cs_f)
     ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, start)
     assert torch.equal(i_b.cpu().long(), ref)
+    # eight waves per plot (sn2_fps_waves: the pass that shares its CUs in a pipelined loop): the same samples, and the
+    # same workspace for the ball query behind it
+    i_8, cs_8, _, ws8 = ops.fps(dev, M, start.to(DEV, torch.int32), waves=8, return_ws=True)
+    assert torch.equal(i_8, i_f) and torch.equal(cs_8, cs_f)
+    nbr8, cnt8, _ = ops.ball_query(dev, cs_8, 1.0, 64, fps_ws=ws8)
+    nbr_f, cnt_f, _ = ops.ball_query(dev, cs_f, 1.0, 64)
+    assert torch.equal(cnt8, cnt_f)
+    live = torch.arange(64, device=DEV)[None, :] < cnt_f[:, None]
+    assert torch.equal(nbr8[live], nbr_f[live])
 
 
 @pytest.mark.parametrize("B,N,M", [(1, 131072, 1024), (2, 65536, 300), (1, 100000, 257)])
