@@ -168,14 +168,18 @@ __global__ __launch_bounds__(256) void fp_bwd_bn_small_kernel(int R, int h_strid
     const float mu = on ? mean[o] : 0.f, is = on ? invstd[o] : 0.f;
     float sb = 0.f, sg = 0.f;
     const long r0 = (long)blockIdx.x * 64;
-#pragma unroll 4
-    for (int i = w; i < 64; i += 4) {
-        const long r = r0 + i;
-        if (r < R && on) {
-            const float hh = h[(size_t)r * h_stride + o], dd = dy[(size_t)r * h_stride + o];
-            sb += dd;
-            sg = fmaf(dd, (hh - mu) * is, sg);
-        }
+    float hv[16], dv[16];                               // all 32 loads in flight (four at a time: 10.7 us for 4096 rows)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const long r = r0 + w + 4 * u;
+        const bool ok = r < R && on;
+        hv[u] = ok ? h[(size_t)r * h_stride + o] : mu;
+        dv[u] = ok ? dy[(size_t)r * h_stride + o] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        sb += dv[u];
+        sg = fmaf(dv[u], (hv[u] - mu) * is, sg);
     }
     s_part[0][w][o] = sb;
     s_part[1][w][o] = sg;
@@ -523,6 +527,52 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(int n_src, int R_per
         }
     }
     if (on) dsrc[(size_t)s * dsrc_stride + lane] += (g0 + g1) + (g2 + g3);
+}
+
+// The same for LONG lists (the global level: one source per plot, every target row on its list): one workgroup of WAVES
+// waves per source, wave w takes the entries w, w + WAVES, ... in blocks of 64, the partial sums are added in wave order
+// (one wave walking 256 entries, eight in flight, took 15 us).
+template <int CA, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void interp_gather_long_kernel(int n_src, int R_per_plot, int S, int dsrc_stride,
+                                                                        const int* __restrict__ off, const int* __restrict__ cnt,
+                                                                        const int* __restrict__ inv_row,
+                                                                        const float* __restrict__ inv_w,
+                                                                        const float* __restrict__ du, float* __restrict__ dsrc) {
+    __shared__ float s_part[WAVES][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = blockIdx.x;
+    const int b = s / S;
+    const int n = cnt[s], st = off[s];
+    const float* dub = du + (size_t)b * R_per_plot * CA;
+    const bool on = lane < CA;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    for (int base = wave * 8; base < n; base += WAVES * 8) {           // eight entries per wave and turn, all in flight
+        const int m = (n - base) < 8 ? (n - base) : 8;
+        const int rj = lane < m ? inv_row[st + base + lane] : 0;        // entries past the end: row 0 with weight 0
+        const float wj = lane < m ? inv_w[st + base + lane] : 0.f;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = __builtin_amdgcn_readlane(rj, u);
+            v[u] = on ? dub[(size_t)r * CA + lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) {
+            g0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), u)), v[u], g0);
+            g1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), u + 1)), v[u + 1], g1);
+            g2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), u + 2)), v[u + 2], g2);
+            g3 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wj), u + 3)), v[u + 3], g3);
+        }
+    }
+    s_part[wave][lane] = (g0 + g1) + (g2 + g3);
+    __syncthreads();
+    if (wave == 0 && on) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += s_part[w][lane];
+        dsrc[(size_t)s * dsrc_stride + lane] += t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- source-side form
@@ -915,6 +965,90 @@ __global__ __launch_bounds__(256) void fp_bwd_src_dw_kernel(int n_src, int src_s
     }
 }
 
+// The four waves of a 64-row workgroup build the rows' inputs [u | 1] together in LDS, s_q[64][QS]; wave g builds the rows
+// 16 g .. 16 g + 15.  A row's interpolated part is CA / 4 float4 quads: that many consecutive lanes share a row, so one load
+// instruction covers 64 / (CA / 4) whole source rows -- with one row per lane every instruction touched 64 different cache
+// lines and the four waves queued behind the CU's one address unit (17 000 clocks of a 46 000-clock kernel).  The same
+// arithmetic, element by element, as build_input.  Columns past CA + CB are left alone.
+template <int CA, int CB, bool KNN>
+__device__ __forceinline__ void stage_inputs(float* __restrict__ s_q, int QS, int g, int lane, long r0, int R, int R_per_plot,
+                                             int S_per_plot, const float* __restrict__ src, int src_stride,
+                                             const float* __restrict__ src_a, const float* __restrict__ src_c,
+                                             const int* __restrict__ knn_idx, const float* __restrict__ knn_w,
+                                             const float* __restrict__ skip, int skip_stride) {
+    constexpr int CI = CA + CB, QA = (CA + 3) / 4;
+    constexpr int LPR = QA <= 8 ? 8 : (QA <= 16 ? 16 : (QA <= 32 ? 32 : 64));     // lanes per row (a power of two >= QA)
+    static_assert(QA <= 64, "at most 256 interpolated channels");
+    constexpr int RPI = 64 / LPR;                     // rows per load instruction
+    const int q = lane & (LPR - 1);
+    const bool qon = q < QA;
+    const int qc = qon ? q : 0;
+    float a4[4] = {1.f, 1.f, 1.f, 1.f}, c4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (src_a) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * qc + t < CA) a4[t] = src_a[4 * qc + t], c4[t] = src_c[4 * qc + t];
+    }
+#pragma unroll
+    for (int st = 0; st < 16 / RPI; ++st) {
+        const int row = 16 * g + st * RPI + lane / LPR;
+        const long r = r0 + row;
+        const size_t rr = r < R ? (size_t)r : (size_t)(R - 1);
+        float v[4];
+        if constexpr (KNN) {
+            const size_t base = (rr / R_per_plot) * S_per_plot;
+            const int i0 = knn_idx[rr * 3 + 0], i1 = knn_idx[rr * 3 + 1], i2 = knn_idx[rr * 3 + 2];
+            const float w0 = knn_w[rr * 3 + 0], w1 = knn_w[rr * 3 + 1], w2 = knn_w[rr * 3 + 2];
+            const float inv = 1.0f / ((w0 + w1) + w2);
+            const float4 a = reinterpret_cast<const float4*>(src + (base + i0) * src_stride)[qc];
+            const float4 b = reinterpret_cast<const float4*>(src + (base + i1) * src_stride)[qc];
+            const float4 c = reinterpret_cast<const float4*>(src + (base + i2) * src_stride)[qc];
+            v[0] = ((a.x * w0 + b.x * w1) + c.x * w2) * inv, v[1] = ((a.y * w0 + b.y * w1) + c.y * w2) * inv;
+            v[2] = ((a.z * w0 + b.z * w1) + c.z * w2) * inv, v[3] = ((a.w * w0 + b.w * w1) + c.w * w2) * inv;
+        } else {
+            const float4 a = reinterpret_cast<const float4*>(src + rr * src_stride)[qc];
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w;
+        }
+        if (src_a) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaf(a4[t], v[t], c4[t]);
+        }
+        if (qon) {
+            if (CA % 4 == 0 || q < QA - 1) {
+                *reinterpret_cast<float4*>(&s_q[row * QS + 4 * q]) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (4 * q + t < CA) s_q[row * QS + 4 * q + t] = v[t];
+            }
+        }
+    }
+    if constexpr (CB > 0 && CB % 4 == 0 && ((CB / 4) & (CB / 4 - 1)) == 0 && CB <= 64) {
+        constexpr int QB = CB / 4, RPB = 64 / QB;     // the skip part the same way
+#pragma unroll
+        for (int st = 0; st < (16 + RPB - 1) / RPB; ++st) {
+            const int rl = st * RPB + lane / QB;      // 0..15 within the wave's rows
+            const int row = 16 * g + rl;
+            const long r = r0 + row;
+            const size_t rr = r < R ? (size_t)r : (size_t)(R - 1);
+            if (rl < 16) {
+                const float4 a = reinterpret_cast<const float4*>(skip + rr * skip_stride)[lane & (QB - 1)];
+                float* d = &s_q[row * QS + CA + 4 * (lane & (QB - 1))];
+                d[0] = a.x, d[1] = a.y, d[2] = a.z, d[3] = a.w;
+            }
+        }
+    } else if constexpr (CB > 0) {
+        if (lane < 16) {
+            const int row = 16 * g + lane;
+            const long r = r0 + row;
+            const size_t rr = r < R ? (size_t)r : (size_t)(R - 1);
+#pragma unroll
+            for (int k = 0; k < CB; ++k) s_q[row * QS + CA + k] = skip[rr * skip_stride + k];
+        }
+    }
+    if (lane < 16) s_q[(16 * g + lane) * QS + CI] = 1.0f;       // the bias column
+}
+
 // ---------------------------------------------------------------------------------------------- small layers
 // Layers with few rows (SA3, FP3, FP2: 4k-16k rows, up to 96 -> 64 channels) gain nothing from one long FMA stream per
 // lane: 4096 rows are only 64 waves on a 1024-SIMD chip and each wave would issue >6000 dependent FMAs (the first
@@ -944,62 +1078,11 @@ __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot
     const long r = (long)blockIdx.x * 64 + lane;
     const bool valid = r < R;
     const size_t rr = valid ? (size_t)r : (size_t)(R - 1);
-    for (int i = threadIdx.x; i < 64 * QS; i += 256) s_q[i] = 0.f;
-    __syncthreads();
-    {
-        float* uq = s_q + lane * QS;
-        const cfp sa = as_const(src_a), sc = as_const(src_c);
-        if constexpr (KNN) {
-            const size_t base = (rr / R_per_plot) * S_per_plot;
-            const int i0 = knn_idx[rr * 3 + 0], i1 = knn_idx[rr * 3 + 1], i2 = knn_idx[rr * 3 + 2];
-            const float w0 = knn_w[rr * 3 + 0], w1 = knn_w[rr * 3 + 1], w2 = knn_w[rr * 3 + 2];
-            const float inv = 1.0f / ((w0 + w1) + w2);
-            const float4* s0 = reinterpret_cast<const float4*>(src + (base + i0) * src_stride);
-            const float4* s1 = reinterpret_cast<const float4*>(src + (base + i1) * src_stride);
-            const float4* s2 = reinterpret_cast<const float4*>(src + (base + i2) * src_stride);
+    stage_inputs<CA, CB, KNN>(s_q, QS, g, lane, (long)blockIdx.x * 64, R, R_per_plot, S_per_plot, src, src_stride, src_a, src_c,
+                              knn_idx, knn_w, skip, skip_stride);
+    if (g == 2) {                            // K padding of the contraction: finite (0 x garbage would be NaN)
 #pragma unroll
-            for (int q0 = 0; q0 < QA; q0 += 4) {
-                const int q = q0 + g;
-                if (q < QA) {
-                    const float4 a = s0[q], b = s1[q], c = s2[q];
-                    float v[4] = {((a.x * w0 + b.x * w1) + c.x * w2) * inv, ((a.y * w0 + b.y * w1) + c.y * w2) * inv,
-                                  ((a.z * w0 + b.z * w1) + c.z * w2) * inv, ((a.w * w0 + b.w * w1) + c.w * w2) * inv};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (4 * q + t < CA) uq[4 * q + t] = src_a ? fmaf(sa[4 * q + t], v[t], sc[4 * q + t]) : v[t];
-                }
-            }
-        } else {
-            const float4* s0 = reinterpret_cast<const float4*>(src + rr * src_stride);
-#pragma unroll
-            for (int q0 = 0; q0 < QA; q0 += 4) {
-                const int q = q0 + g;
-                if (q < QA) {
-                    const float4 a = s0[q];
-                    const float v[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (4 * q + t < CA) uq[4 * q + t] = src_a ? fmaf(sa[4 * q + t], v[t], sc[4 * q + t]) : v[t];
-                }
-            }
-        }
-        if constexpr (CB > 0 && CB % 4 == 0) {
-            const float4* sk = reinterpret_cast<const float4*>(skip + rr * skip_stride);
-#pragma unroll
-            for (int q0 = 0; q0 < CB / 4; q0 += 4) {
-                const int q = q0 + g;
-                if (q < CB / 4) {
-                    const float4 a = sk[q];
-                    uq[CA + 4 * q + 0] = a.x, uq[CA + 4 * q + 1] = a.y, uq[CA + 4 * q + 2] = a.z, uq[CA + 4 * q + 3] = a.w;
-                }
-            }
-        } else if constexpr (CB > 0) {
-            if (g == 1) {
-#pragma unroll
-                for (int k = 0; k < CB; ++k) uq[CA + k] = skip[rr * skip_stride + k];
-            }
-        }
-        if (g == 3) uq[CI] = 1.0f;           // the bias column
+        for (int k = CK; k < 4 * KB; ++k) s_q[lane * QS + k] = 0.f;
     }
     // B operand: lane (qq, cc) keeps [W | bias][o = 16 g + cc][k = 4 kb + qq]
     const int qq = lane >> 4, cc = lane & 15;
@@ -1059,10 +1142,27 @@ __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot
     }
 }
 
+#ifdef SN2_SPLIT_STAMPS
+// diagnostic build only (never shipped): phase stamps of thread 0 of one workgroup of fp_bwd_split_kernel<64, 32, 64>
+__device__ unsigned long long g_split_dbg[16];
+extern "C" int sn2_debug_split_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_dbg), sizeof(g_split_dbg));
+}
+#define FSTAMP(i)                                                                                   \
+    if (CA == 64 && CB == 32 && blockIdx.x == 7 && threadIdx.x == 0) {                              \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        g_split_dbg[i] = t_;                                                                        \
+    }
+#else
+#define FSTAMP(i)
+#endif
+
 // LDS of fp_bwd_split_kernel: inputs [64][QS] + per-wave dp [4][64][16] + the input-gradient slab(s) [1 or 4][64][CI|1]
+// + the BatchNorm vectors [5][64]
 template <int CI>
 constexpr size_t fp_split_lds_bytes(int slabs) {
-    return (size_t)(64 * OuterAcc<16, CI + 1>::QS + 4 * 64 * 16 + slabs * 64 * (CI | 1)) * 4;
+    return (size_t)(64 * OuterAcc<16, CI + 1>::QS + 4 * 64 * 16 + slabs * 64 * (CI | 1) + 5 * 64) * 4;
 }
 template <int CI>
 constexpr bool fp_split_du_seq() { return fp_split_lds_bytes<CI>(4) > 150 * 1024; }   // one slab, the waves take turns
@@ -1090,30 +1190,56 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     const long r = (long)blockIdx.x * 64 + lane;
     const bool valid = r < R;
     const size_t rr = valid ? (size_t)r : (size_t)(R - 1);
-    for (int i = threadIdx.x; i < 64 * QS + 4 * 64 * 16; i += 256) smem[i] = 0.f;
-    __syncthreads();
-    if (g == 0) {
-        float u[CI + 1];
-        build_input<CA, CB, KNN>(src, src_stride, as_const(src_a), as_const(src_c), knn_idx, knn_w, skip, skip_stride, rr,
-                                 (rr / R_per_plot) * S_per_plot, u);
-#pragma unroll
-        for (int k = 0; k <= CI; ++k) s_q[lane * QS + k] = u[k];
+    FSTAMP(0);
+    // no clearing pass over the staging regions (it cost 4000 clocks + a barrier): the input columns past CI only feed
+    // output columns nobody reads, the channel pads of s_p are written below
+    FSTAMP(1);
+    stage_inputs<CA, CB, KNN>(s_q, QS, g, lane, (long)blockIdx.x * 64, R, R_per_plot, S_per_plot, src, src_stride, src_a, src_c,
+                              knn_idx, knn_w, skip, skip_stride);
+    // d pre-activation: the block's 64 x CO tile of h and dy read thread-linearly as float4 quads (whole rows per load
+    // instruction, as above), the five per-channel vectors of the BatchNorm backward staged in LDS
+    constexpr int HS4 = (CO + 3) / 4, NU = (64 * HS4 + 255) / 256;
+    float* s_par = s_du + (DU_SEQ ? 1 : 4) * 64 * CIP;       // [5][64]: mean, invstd, gamma, dbeta, dgamma
+    if (threadIdx.x < CO) {
+        const int o = threadIdx.x;
+        s_par[0 * 64 + o] = mean[o], s_par[1 * 64 + o] = invstd[o], s_par[2 * 64 + o] = gamma[o];
+        s_par[3 * 64 + o] = dbeta[o], s_par[4 * 64 + o] = dgamma[o];
     }
-    float dp[COG];
+    float4 hv[NU], dv[NU];
 #pragma unroll
-    for (int t = 0; t < COG; ++t) {
-        const int o = g * COG + t;
-        dp[t] = 0.f;
-        if (o < CO) {
-            const float hh = h[rr * h_stride + o], dd = dy[rr * h_stride + o];
-            const float is = invstd[o];
-            const float xh = (hh - mean[o]) * is;
-            const float dh = gamma[o] * is * (dd - dbeta[o] * invR - xh * dgamma[o] * invR);
-            dp[t] = (valid && hh > 0.f) ? dh : 0.f;
+    for (int u = 0; u < NU; ++u) {
+        const int i4 = threadIdx.x + 256 * u, row = i4 / HS4, qd = i4 - row * HS4;
+        const long rw = (long)blockIdx.x * 64 + row;
+        const size_t ra = (i4 < 64 * HS4 && rw < R) ? (size_t)rw : (size_t)(R - 1);
+        hv[u] = reinterpret_cast<const float4*>(h + ra * h_stride)[i4 < 64 * HS4 ? qd : 0];
+        dv[u] = reinterpret_cast<const float4*>(dy + ra * h_stride)[i4 < 64 * HS4 ? qd : 0];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        if (t >= COG || g * COG + t >= CO) s_p[(g * 64 + lane) * 16 + t] = 0.f;   // K padding of dp . W: finite
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i4 = threadIdx.x + 256 * u, row = i4 / HS4, qd = i4 - row * HS4;
+        const bool live = i4 < 64 * HS4 && (long)blockIdx.x * 64 + row < R;
+        const float hq[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w}, dq[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+        if (i4 < 64 * HS4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = 4 * qd + t;
+                if (o < CO) {
+                    const float hh = hq[t], dd = dq[t];
+                    const float is = s_par[1 * 64 + o];
+                    const float xh = (hh - s_par[0 * 64 + o]) * is;
+                    const float dh = s_par[2 * 64 + o] * is * (dd - s_par[3 * 64 + o] * invR - xh * s_par[4 * 64 + o] * invR);
+                    s_p[((o / COG) * 64 + row) * 16 + (o % COG)] = (live && hh > 0.f) ? dh : 0.f;
+                }
+            }
         }
-        s_p[(g * 64 + lane) * 16 + t] = dp[t];
     }
+    FSTAMP(2);
     __syncthreads();
+    FSTAMP(3);
     // dW|db rows of this channel group: rows of the block are the MFMA K dimension
     f32x4 acc[TK];
 #pragma unroll
@@ -1143,6 +1269,7 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
             }
         }
     }
+    FSTAMP(4);
     // partial input gradient of this channel group, dp_g (64 x 16) . W_g (16 x CI), on the matrix cores: A[row][o] read
     // back from this wave's staged dp rows, B[o][col] = the group's weight rows in registers (as per-lane FMA chains with
     // scalar-loaded weights this was the longest part of the kernel: 16 x 96 FMAs per lane for FP3)
@@ -1195,29 +1322,50 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
             if (DU_SEQ) __syncthreads();
         }
     }
+    FSTAMP(5);
     __syncthreads();
+    FSTAMP(6);
     auto du_sum = [&](int row, int k) {
         if (DU_SEQ) return s_du[row * CIP + k];
         return (s_du[(0 * 64 + row) * CIP + k] + s_du[(1 * 64 + row) * CIP + k]) +
                (s_du[(2 * 64 + row) * CIP + k] + s_du[(3 * 64 + row) * CIP + k]);
     };
     const long r0 = (long)blockIdx.x * 64;
+    // accumulated outputs: all the old values are loaded before the first is used (one dependent load per loop turn made
+    // this write-out 12 000 clocks, a quarter of the kernel)
     if (du_out) {
-        for (int i = threadIdx.x; i < 64 * CA; i += 256) {
-            const int row = i / CA, k = i - row * CA;
-            if (r0 + row < R) {
+        constexpr int NI = (64 * CA + 255) / 256;
+        float old[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / CA, k = i - row * CA;
+            old[u] = (!KNN && i < 64 * CA && r0 + row < R) ? du_out[(size_t)(r0 + row) * du_stride + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / CA, k = i - row * CA;
+            if (i < 64 * CA && r0 + row < R) {
                 float* dst = du_out + (size_t)(r0 + row) * du_stride + k;
                 if (KNN) *dst = du_sum(row, k);
-                else *dst += du_sum(row, k);
+                else *dst = old[u] + du_sum(row, k);
             }
         }
     }
     if (CB > 0 && dskip) {
-        for (int i = threadIdx.x; i < 64 * CB; i += 256) {
-            const int row = i / CB, k = i - row * CB;
-            if (r0 + row < R) dskip[(size_t)(r0 + row) * dskip_stride + k] += du_sum(row, CA + k);
+        constexpr int NI = (64 * CB + 255) / 256;
+        float old[NI > 0 ? NI : 1];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / (CB > 0 ? CB : 1), k = i - row * CB;
+            old[u] = (i < 64 * CB && r0 + row < R) ? dskip[(size_t)(r0 + row) * dskip_stride + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = threadIdx.x + 256 * u, row = i / (CB > 0 ? CB : 1), k = i - row * CB;
+            if (i < 64 * CB && r0 + row < R) dskip[(size_t)(r0 + row) * dskip_stride + k] = old[u] + du_sum(row, CA + k);
         }
     }
+    FSTAMP(7);
     {
         const int r4 = lane >> 4, c16 = lane & 15, img = sn2_grad_image(rep_k, rep_stride);
 #pragma unroll
@@ -1231,6 +1379,7 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
                 }
             }
     }
+    FSTAMP(8);
 }
 
 int pick_grid(long R, int threads, int rows_per_lane) {
@@ -1424,9 +1573,14 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
         const int* inv_row = x.inv_row;
         const float* inv_w = x.inv_w;
         const int n_src = B * S;
-        hipLaunchKernelGGL((interp_gather_kernel<CA>), dim3(sn2_cdiv(n_src, 4)), dim3(256), 0, st, n_src, Rp, S,
-                           p->dsrc_stride, (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
-                           (const float*)p->du_scratch, p->dsrc);
+        if ((long)Rp >= 128L * S && CA <= 64)     // >= 128 entries per list on average: a workgroup per source
+            hipLaunchKernelGGL((interp_gather_long_kernel<CA, 16>), dim3(n_src), dim3(1024), 0, st, n_src, Rp, S,
+                               p->dsrc_stride, (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
+                               (const float*)p->du_scratch, p->dsrc);
+        else
+            hipLaunchKernelGGL((interp_gather_kernel<CA>), dim3(sn2_cdiv(n_src, 4)), dim3(256), 0, st, n_src, Rp, S,
+                               p->dsrc_stride, (const int*)off, (const int*)cnt, (const int*)inv_row, (const float*)inv_w,
+                               (const float*)p->du_scratch, p->dsrc);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
