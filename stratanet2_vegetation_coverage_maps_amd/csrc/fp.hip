@@ -1644,13 +1644,12 @@ struct HeadOut {
 
 // drop_mask / drop_scale: F.dropout(relu(lin1), p) of model/point_net2.py:142 -- bit j of the row's word set = channel j kept
 // and scaled by 1/(1-p); drop_mask == nullptr: no dropout.  z1 holds the values lin2 reads (after the dropout).
-__device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, cfp fa, cfp fc, cfp W1, cfp b1, cfp W2,
-                                         cfp b2, size_t r, HeadOut& o, const int* __restrict__ drop_mask = nullptr,
-                                         float drop_scale = 1.f) {
-    const float4* fr = reinterpret_cast<const float4*>(f + r * f_stride);
+// fv: the row's nine float4 quads (36 floats, 34 used)
+__device__ __forceinline__ void head_row_v(const float4 (&fv)[9], cfp fa, cfp fc, cfp W1, cfp b1, cfp W2, cfp b2, size_t r,
+                                           HeadOut& o, const int* __restrict__ drop_mask = nullptr, float drop_scale = 1.f) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-        const float4 v = fr[q];
+        const float4 v = fv[q];
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1690,18 +1689,130 @@ __device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stri
     o.dens = 1.0f / (1.0f + expf(-s[4]));
 }
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(int R, int f_stride, const float* __restrict__ f,
-                                                       const float* __restrict__ fa, const float* __restrict__ fc,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ W2, const float* __restrict__ b2,
-                                                       float* __restrict__ cov, float* __restrict__ proba,
-                                                       const int* __restrict__ drop_mask, float drop_scale) {
-    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += (long)gridDim.x * 256) {
-        HeadOut o;
-        head_row(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), opaque(as_const(W1)), opaque(as_const(b1)),
-                 opaque(as_const(W2)), opaque(as_const(b2)), (size_t)r, o, drop_mask, drop_scale);
-        reinterpret_cast<float4*>(proba)[r] = make_float4(o.p[0], o.p[1], o.p[2], o.p[3]);
-        reinterpret_cast<float4*>(cov)[r] = make_float4(o.p[0] * o.dens, o.p[1] * o.dens, o.p[2] * o.dens, o.p[3] * o.dens);
+__device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, cfp fa, cfp fc, cfp W1, cfp b1, cfp W2,
+                                         cfp b2, size_t r, HeadOut& o, const int* __restrict__ drop_mask = nullptr,
+                                         float drop_scale = 1.f) {
+    const float4* fr = reinterpret_cast<const float4*>(f + r * f_stride);
+    float4 fv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) fv[q] = fr[q];
+    head_row_v(fv, fa, fc, W1, b1, W2, b2, r, o, drop_mask, drop_scale);
+}
+
+// a wave re-reads LDS words other lanes of the SAME wave wrote: the LDS executes a wave's instructions in order, the compiler
+// must not move the accesses across this point (the regions are reused under different element types)
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+constexpr int HEAD_T_QUADS = 64 * 9;   // a wave's 64 consecutive rows of 36 floats: 9216 contiguous bytes, nine quads per lane
+
+// The head forward on the matrix cores (rows of exactly 36 floats).  Per wave and turn 64 consecutive rows:
+//   global -> LDS (nine fully coalesced float4 loads; one row per lane, 144-byte stride, touched 64 lines per load) -> lin1: A[row][k] = fa_k f + fc_k read back from LDS
+//   in the MFMA operand layout (stride 36: conflict-free), B = W1^T in nine registers per lane, bias = accumulator start
+//   -> ReLU (+ dropout) in the result layout -> z1 to LDS [64][20] -> lin2 the same way (four k-steps, five live outputs)
+//   -> scores to LDS [64][8] -> one row per lane: softmax, sigmoid, two coalesced float4 stores.
+// 52 MFMAs per 64 rows instead of 624 FMA instructions per row-lane fed by scalar weight loads.  It is NOT faster than that
+// form (24-28 us for 92 MB either way: the kernel streams at 3.3-3.8 TB/s and fp32 MFMA has the packed-VALU rate, 2 x the
+// scalar-operand FMA rate); it frees the VALU and scalar cache for whatever runs beside it.  The backward keeps its
+// row-per-lane form: 188 padded MFMAs per 64 rows would take as long as its 1250 FMAs per row do now.
+__global__ __launch_bounds__(256) void head_fwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
+                                                            const float* __restrict__ fc, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ W2,
+                                                            const float* __restrict__ b2, float* __restrict__ cov,
+                                                            float* __restrict__ proba, const int* __restrict__ drop_mask,
+                                                            float drop_scale) {
+    __shared__ float4 s_t[4 * HEAD_T_QUADS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* st4 = s_t + wave * HEAD_T_QUADS;
+    float* st = reinterpret_cast<float*>(st4);
+    float* zt = st;                    // [64][20] after lin1 has read the rows
+    float* sc = st + 64 * 20;          // [64][8]
+    const int n = lane & 15, kq = lane >> 4;
+    float w1[9], ak[9], ck[9], w2[4];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+        const int k = 4 * ks + kq;
+        w1[ks] = k < 34 ? W1[n * 34 + k] : 0.f;
+        ak[ks] = k < 34 ? fa[k] : 0.f;
+        ck[ks] = k < 34 ? fc[k] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w2[ks] = n < 5 ? W2[n * 16 + 4 * ks + kq] : 0.f;
+    const float bias1 = b1[n], bias2 = n < 5 ? b2[n] : 0.f;
+    for (long r0 = ((long)blockIdx.x * 4 + wave) * 64; r0 < R; r0 += (long)gridDim.x * 256) {
+        {
+            const float4* chunk = reinterpret_cast<const float4*>(f) + r0 * 9;
+            const long lim = (R - r0) * 9;
+            float4 t[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int e = lane + 64 * k;
+                t[k] = e < lim ? chunk[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) st4[lane + 64 * k] = t[k];
+        }
+        WAVE_LDS_SYNC();
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = f32x4{bias1, bias1, bias1, bias1};
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                const float v = st[(16 * t + n) * 36 + 4 * ks + kq];
+                const float a = (4 * ks + kq < 34) ? fmaf(ak[ks], v, ck[ks]) : 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w1[ks], acc[t], 0, 0, 0);
+            }
+        }
+        WAVE_LDS_SYNC();
+        // acc[t][j]: row 16 t + 4 kq + j, hidden channel n
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 16 * t + 4 * kq + j;
+                float z = fmaxf(acc[t][j], 0.f);
+                if (drop_mask) {
+                    const long r = r0 + row;
+                    const int keep = drop_mask[r < R ? r : R - 1];
+                    z = ((keep >> n) & 1) ? z * drop_scale : 0.f;
+                }
+                zt[row * 20 + n] = z;
+            }
+        WAVE_LDS_SYNC();
+        f32x4 s2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s2[t] = f32x4{bias2, bias2, bias2, bias2};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[(16 * t + n) * 20 + 4 * ks + kq], w2[ks], s2[t], 0, 0, 0);
+        }
+        if (n < 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[(16 * t + 4 * kq + j) * 8 + n] = s2[t][j];
+        }
+        WAVE_LDS_SYNC();
+        const long r = r0 + lane;
+        const float4 s03 = *reinterpret_cast<const float4*>(&sc[lane * 8]);
+        const float s4 = sc[lane * 8 + 4];
+        WAVE_LDS_SYNC();
+        const float sv[4] = {s03.x, s03.y, s03.z, s03.w};
+        const float m = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        float e[4], den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            e[i] = expf(sv[i] - m);
+            den += e[i];
+        }
+        float pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pr[i] = e[i] / den;
+        const float dens = 1.0f / (1.0f + expf(-s4));
+        if (r < R) {
+            reinterpret_cast<float4*>(proba)[r] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+            reinterpret_cast<float4*>(cov)[r] = make_float4(pr[0] * dens, pr[1] * dens, pr[2] * dens, pr[3] * dens);
+        }
     }
 }
 
@@ -1876,8 +1987,9 @@ int check_head(const sn2_head* p) {
 extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     SN2_TRY(check_head(p));
     if (!p->coverages || !p->proba) return SN2_EINVAL;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f_stride,
-                       p->f, p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba, p->drop_mask,
+    // check_head: rows of exactly 36 floats (34 channels)
+    hipLaunchKernelGGL(head_fwd_mfma_kernel, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
+                       p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba, p->drop_mask,
                        p->drop_mask ? p->drop_scale : 1.f);
     SN2_RETURN_LAUNCH();
 }
