@@ -141,7 +141,7 @@ DOMINANT_KERNEL = {
     "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>",
     "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34>",
     "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512>",
-    "sn2_head_forward": "head_fwd_kernel", "sn2_head_backward": "head_bwd_kernel",
+    "sn2_head_forward": "head_fwd_mfma_kernel", "sn2_head_backward": "head_bwd_kernel",
     "sn2_three_nn:T=32768": "three_nn_grid_kernel", "sn2_pack_rows": "pack_rows_kernel",
 }
 

@@ -19,10 +19,12 @@ timeout -k 10 300 python scripts/bench_inference.py > $OUT/inf.log 2>&1 && line 
 cd /tmp && export TMPDIR=/tmp &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/prof.log 2>&1 &&
 line $OUT/prof.log > $OUT/${R}_bench_under_rocprof.json && cp $(find $OUT/prof -name "*kernel_stats.csv" | tail -1) $OUT/${R}_kernel_stats.csv && echo "kernel stats done" &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -- python3 $ROOT/bench.py --serial --eager --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_serial.log 2>&1 &&
+cp $(find $OUT/prof_serial -name "*kernel_stats.csv" | tail -1) $OUT/${R}_kernel_stats_serial.csv && echo "serial kernel stats done" &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --serial --eager --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 && echo "fetch pass done" &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --serial --eager --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 && echo "write pass done" &&
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --serial --eager --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1 && cp $(find $OUT/pmc_sq -name "*counter_collection.csv" | tail -1) $OUT/${R}_pmc_sq.csv && echo "sq pass done" &&
 cd $ROOT && python scripts/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | tail -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | tail -1) $OUT/${R}_pmc_traffic.json && echo "pmc summary done" &&
-python scripts/roofline_table.py $OUT/${R}_bench.json $OUT/${R}_kernel_stats.csv $OUT/${R}_pmc_traffic.json $OUT/${R}_pmc_sq.csv $OUT/${R}_roofline_table > /dev/null && echo "roofline table done"
-rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+python scripts/roofline_table.py $OUT/${R}_bench.json $OUT/${R}_kernel_stats_serial.csv $OUT/${R}_pmc_traffic.json $OUT/${R}_pmc_sq.csv $OUT/${R}_roofline_table > /dev/null && echo "roofline table done"
+rm -rf $OUT/prof $OUT/prof_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 ls -la $OUT

@@ -5,7 +5,8 @@ GEMMs) against the chip's peak") from the rocprofv3 outputs of scripts/refresh_p
     python scripts/roofline_table.py <bench.json> <kernel_stats.csv> <pmc_traffic.json> <sq_counter_collection.csv> <out prefix>
 
 Columns per device kernel (one launch, C2 ref-arch sizes; E1, E2 = the measured message counts of the bench line):
-  us            average duration, rocprofv3 --kernel-trace --stats
+  us            average duration, rocprofv3 --kernel-trace --stats of the UNPIPELINED eager run (one stream: in the pipelined run
+                the position-only kernels overlap feature kernels and their durations include the contention)
   compulsory    HBM bytes that must move: index entries + first touch of every row read + results written
   L2 gather     bytes gathered again out of the (L2 / Infinity-Cache resident) row tables: NOT compulsory HBM traffic
   PMC           FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes (gfx950 half-count of wide reads corrected: guide)
@@ -56,7 +57,7 @@ K["scatter_max_kernel<0>"] = ("plot-wise projection: scatter-max", (8 + 16 + 4) 
 K["fp_fwd_rows_kernel<34, 8, 34>"] = ("FP1 forward, row pass (source-side form)", (24 + 32 + 144) * R, 3 * 144 * R, 0)
 K["fp_bwd_rows_kernel<34, 8, 34, 512>"] = ("FP1 backward, row pass", (288 + 32 + 144) * R, None, 0)
 K["fp_bwd_src_kernel<34, 8, 34>"] = ("FP1 backward, source pass (gather through the inverted index)", 24 * R + 2 * 144 * M1 * B, 144 * R, 0)
-K["head_fwd_kernel"] = ("head forward", (144 + 32) * R, None, 0)
+K["head_fwd_mfma_kernel"] = ("head forward (lin1, lin2 on the matrix cores)", (144 + 32) * R, None, 2 * (16 * 35 + 5 * 17) * R)
 K["head_bwd_kernel"] = ("head backward", (144 + 32 + 144) * R, None, 2 * (16 * 35 + 16 * 17) * R)
 K["three_nn_grid_kernel"] = ("3-NN of the N points among the level-1 centroids", 16 * R + 16 * M1 * B + 24 * R, None, 0)
 K["pack_rows_kernel"] = ("row packing", (44 + 48) * R, None, 0)

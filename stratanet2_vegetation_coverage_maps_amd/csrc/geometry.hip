@@ -1067,7 +1067,10 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
         // four blocks of 64 candidates per turn, their positions AND original indices all requested before the first test:
         // one round trip per 256 candidates (block by block, with the index fetched for the hits only, a centroid with 250
         // candidates waited for eight dependent loads: 54 us per launch at 16 x 32 768)
-        constexpr int GQ_INFLIGHT = 4;
+#ifndef SN2_GQ_INFLIGHT
+#define SN2_GQ_INFLIGHT 4
+#endif
+        constexpr int GQ_INFLIGHT = SN2_GQ_INFLIGHT;
         for (int t0 = 0; t0 < T && !dense; t0 += 64 * GQ_INFLIGHT) {
             float4 qv[GQ_INFLIGHT];
             int oi[GQ_INFLIGHT];

@@ -108,11 +108,11 @@ def r2_threshold(r: float) -> float:
 
 
 # ---------------------------------------------------------------------------------------------- geometry
-def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor) -> torch.Tensor:
+def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, C, N = cloud.shape
     _chk(cloud, F32, (B, C, N), "cloud")
     _chk(xyz, F32, (B, 3, N), "xyz")
-    rows0 = torch.empty(B * N, 12, dtype=F32, device=cloud.device)
+    rows0 = torch.empty(B * N, 12, dtype=F32, device=cloud.device) if out is None else _chk(out, F32, (B * N, 12), "out")
     _call("sn2_pack_rows", _ptr(cloud), _ptr(xyz), B, C, N, _ptr(rows0), _stream())
     return rows0
 

@@ -256,7 +256,7 @@ class PointNet2(nn.Module):
         g.ready = None
         return g
 
-    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False):
+    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False):
         """Everything that depends on the point POSITIONS only (no weights, no features): both FPS levels, both ball
         queries, the three 3-NN tables.  In the reference these are the torch_cluster calls inside SAModule / FPModule
         (point_net2.py:22-25, 63).  Because they need no parameters they can run ahead of the feature kernels: see
@@ -266,6 +266,8 @@ class PointNet2(nn.Module):
         its work items, (b) level-2 FPS, ball query 2, the two small 3-NN tables, (c) the per-point 3-NN table + its
         inverted index -- run on three streams and join before returning (captured into a hipGraph they become parallel
         branches): the level-2 FPS is 16 workgroups for 0.15 ms, chains (a) and (c) fill the chip beside it.
+        `defer_join` (with `fork`): return without joining; `g._join = (stream of chain b, stream of chain c)` for the caller
+        to wait on where it first needs them (`_forward_impl`: the first set-abstraction level starts beside chain b).
         `shared`: the pass runs beside other batches' feature kernels (a pipelined loop, `prefetch_geometry`): the level-1
         FPS takes `fps_waves_shared` waves per plot (include/strata_hip.h: sn2_fps_waves)."""
         dev = xyz.device
@@ -303,7 +305,10 @@ class PointNet2(nn.Module):
         # (a)
         ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
         ops.sa_order(g.cnt1, B, M1, out=g.ord1)
-        if fork:
+        g._join = None
+        if fork and defer_join:
+            g._join = (sb, sc)
+        elif fork:
             cur.wait_stream(sb)
             cur.wait_stream(sc)
         return g
@@ -387,7 +392,9 @@ class PointNet2(nn.Module):
             xyz_d.record_stream(side)
             fs.record_stream(side)
             with torch.cuda.stream(side):
-                g = self._geometry(xyz_d, fs, shared=True)
+                # one stream per pass: several passes are in flight on their own lanes already, and a fork inside each
+                # (three more streams + their events) cost the parcel loop 18 % (33 300 -> 27 100 plots/s)
+                g = self._geometry(xyz_d, fs, shared=True, fork=False)
                 g.fps_start = fs
                 g.ready = torch.cuda.Event()
                 g.ready.record(side)
@@ -412,12 +419,27 @@ class PointNet2(nn.Module):
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
+        cur_stream = torch.cuda.current_stream(dev)
+        rows0, packed = None, None
         if geo is None:
-            geo = self._geometry(xyz, fps_start)
+            if self.geometry_fork:
+                # the row packing needs the inputs only: beside the level-1 FPS (16 workgroups) instead of behind it
+                rows0 = torch.empty(B * N, 12, dtype=F32, device=dev)
+                if getattr(self, "_pack_stream", None) is None or self._pack_stream.device != dev:
+                    self._pack_stream = torch.cuda.Stream(device=dev)
+                self._pack_stream.wait_stream(cur_stream)
+                with torch.cuda.stream(self._pack_stream):
+                    ops.pack_rows(cloud, xyz, out=rows0)
+                    packed = torch.cuda.Event()
+                    packed.record(self._pack_stream)
+            geo = self._geometry(xyz, fps_start, defer_join=True)
         elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
             raise ValueError("prefetched geometry does not match this batch")
+        join = getattr(geo, "_join", None)
+        geo._join = None
         s = _Saved()
-        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws", "fps_start")})
+        s.__dict__.update({k: v for k, v in geo.__dict__.items()
+                           if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws", "fps_start", "_join")})
         s.xyz = xyz
         # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd and the per-workgroup statistics
         # slots (written before they are read: no zero fill)
@@ -435,12 +457,18 @@ class PointNet2(nn.Module):
         s.aux, s.stats = aux, stats
 
         # ---- level 0 rows: [8 features | x y z 0]
-        s.rows0 = ops.pack_rows(cloud, xyz)
+        if packed is not None:
+            cur_stream.wait_event(packed)
+            s.rows0 = rows0
+        else:
+            s.rows0 = ops.pack_rows(cloud, xyz)
         # ---- SA1: gather + MLP[11,16,16] + BN + max over the ball-query lists     (point_net2.py:131, 21-29)
         s.ext1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
         s.arg1 = torch.empty(B * M1, 16, dtype=I32, device=dev)
         s.x1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
         ops.sa_forward(self._sa1_desc(s), training)
+        if join is not None:
+            cur_stream.wait_stream(join[0])      # chain b of the forked geometry pass: level-2 tables, small 3-NN tables
         # ---- SA2: MLP[19,32]                                                     (:132)
         s.ext2 = torch.empty(B * M2, 32, dtype=F32, device=dev)
         s.arg2 = torch.empty(B * M2, 32, dtype=I32, device=dev)
@@ -458,6 +486,8 @@ class PointNet2(nn.Module):
         s.h2 = torch.empty(B * M1, 36, dtype=F32, device=dev)
         ops.fp_forward(self._fp2_desc(s), training)
         s.h1 = torch.empty(B * N, 36, dtype=F32, device=dev)
+        if join is not None:
+            cur_stream.wait_stream(join[1])      # chain c: the per-point 3-NN table and its inverted index
         ops.fp_forward(self._fp1_desc(s), training)
         # ---- head                                                                  (:141-151)
         cov = torch.empty(B * N, 4, dtype=F32, device=dev)

@@ -94,7 +94,9 @@ class PointNet2ThreeSA(PointNet2):
         g.ready = None
         return g
 
-    def _geometry(self, xyz, fps_start, out=None):
+    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False):
+        """As `PointNet2._geometry` with the third ball-query level; one stream (`fork` is accepted and ignored), `shared` =
+        the level-1 FPS with `fps_waves_shared` waves per plot."""
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2, M3 = self._sizes3(N)
@@ -107,7 +109,8 @@ class PointNet2ThreeSA(PointNet2):
         for lvl, (M, mod) in enumerate(((M1, self.sa1_module), (M2, self.sa2_module), (M3, self.sa3_module)), 1):
             ws = getattr(g, f"ws{lvl}")
             cs = getattr(g, f"pos{lvl}_soa")
-            ops.fps(src, M, fps_start[lvl - 1], out=(getattr(g, f"idx{lvl}"), cs, getattr(g, f"pos{lvl}_aos"), ws))
+            ops.fps(src, M, fps_start[lvl - 1], out=(getattr(g, f"idx{lvl}"), cs, getattr(g, f"pos{lvl}_aos"), ws),
+                    waves=self.fps_waves_shared if (shared and lvl == 1) else 0)
             ops.ball_query(src, cs, mod.r, cap, getattr(g, f"tot{lvl}"), fps_ws=ws,
                            out=(getattr(g, f"nbr{lvl}"), getattr(g, f"cnt{lvl}")))
             ops.sa_order(getattr(g, f"cnt{lvl}"), B, M, out=getattr(g, f"ord{lvl}"))

@@ -33,3 +33,52 @@ def test_3sa_forward_backward_vs_oracle(B, N, ratio1):
     fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred, tol_grad=2e-3)
     print(f"\n[3sa {B} x {N}] vs the fp64 oracle:\n  {report}")
     assert not fails, "\n".join(fails)
+
+
+def test_3sa_in_the_pipelined_loop_matches_the_plain_loop():
+    """`bench.py --arch 3sa` drives this model through TrainPipeline (one geometry pass per batch on side streams, feature
+    graphs per slot): the same losses as the plain loop."""
+    from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters
+    from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
+    N, B, depth, steps = 4096, 2, 2, 6
+
+    def setup():
+        args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0, ratio3=0.25, r3=4.0)
+        model = PointNet2ThreeSA(args)
+        model.load_state_dict(network.init_state_dict_3sa(2))
+        model = model.cuda().train()
+        flatten_parameters(model)
+        opt = FlatAdam(model, lr=0.0, eps=1e-3)          # lr 0: every step must reproduce the plain loop's loss
+        slots = []
+        for j in range(depth + 1):
+            h = make_batch(B, N, first_plot=300 + j * B)
+            slots.append({"cloud": h["cloud"].cuda(), "xyz": h["xyz"].cuda(),
+                          "fps_start": torch.full((3, B), j, dtype=torch.int32, device="cuda"),
+                          "gt": h["coverages"].cuda(), "pdf": h["pdf_all"].cuda()})
+
+        def fstep(inp, geo=None):
+            opt.zero_grad()
+            cd = {"cloud": inp["cloud"], "xyz": inp["xyz"], "fps_start": inp["fps_start"]}
+            if geo is not None:
+                cd["geometry"] = geo
+            cov, proba = model(cd)
+            pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
+            loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
+            loss.backward()
+            return loss
+        return model, opt, slots, fstep
+
+    model, opt, slots, fstep = setup()
+    ref = []
+    for i in range(steps):
+        ref.append(float(fstep(slots[i % len(slots)]).detach()))
+        opt.step()
+    model2, opt2, slots2, fstep2 = setup()
+    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth)
+    assert not pipe.pair
+    pipe.capture()
+    pipe.prime()
+    got = [float(pipe.step().detach()) for _ in range(steps)]
+    pipe.drain()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
