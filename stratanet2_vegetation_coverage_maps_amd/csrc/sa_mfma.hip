@@ -153,16 +153,20 @@ __global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
                     best[t][io][r] = -INFINITY;
                     barg[t][io][r] = 0x7FFFFFFF;
                 }
-        if (nmax == 0) continue;                                         // an empty position
         const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
         // the neighbour indices of a step are fetched one step ahead: index load -> row gather -> MFMA chain is what a
-        // step waits for, and the first link does not depend on the step before
+        // step waits for, and the first link does not depend on the step before.  The FIRST step's indices are requested
+        // together with the counts (the address needs the centroid only; entries past the count are masked afterwards):
+        // work item -> {count, position, indices} -> rows, one dependent round trip less per item
         int jn[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = eoff * t + c;
-            jn[t] = e < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
+            jn[t] = e < a.cap ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) jn[t] = eoff * t + c < nn[t] ? jn[t] : 0;
+        if (nmax == 0) continue;                                         // an empty position
         for (int e0 = 0; e0 < nmax; e0 += estep) {
             // ---- layer 1: gather straight into the B-operand layout, 4 message tiles
             f32x4 D1[TO1][4];
@@ -482,14 +486,16 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
                 arv[t][io][0] = av.x; arv[t][io][1] = av.y; arv[t][io][2] = av.z; arv[t][io][3] = av.w;
             }
         }
-        if (nmax == 0) continue;                                         // an empty position
         const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
-        int jn[4];                                                       // neighbour indices, fetched one step ahead
+        int jn[4];                                 // neighbour indices, fetched one step ahead (the first step's: with the counts)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = eoff * t + c;
-            jn[t] = e < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
+            jn[t] = e < a.cap ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) jn[t] = eoff * t + c < nn[t] ? jn[t] : 0;
+        if (nmax == 0) continue;                                         // an empty position
         for (int e0 = 0; e0 < nmax; e0 += estep) {
             f32x4 D1[TO1][4];
             float bks[4][KB1];
