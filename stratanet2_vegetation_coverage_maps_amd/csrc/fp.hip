@@ -1420,7 +1420,10 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
                                p->src_stride, p->src, p->src_a, p->src_c, p->blk.W, p->src_ws);
             const long n_grp = sn2_cdiv(R, 64 / ((CO + 3) / 4));
             int grid = sn2_cdiv(n_grp, 8);
-            if (grid > SN2_STAT_SLOTS) grid = SN2_STAT_SLOTS;
+            // two workgroups per CU: at 143 VGPRs three waves fit a SIMD, so 1024 workgroups ran as one full round and a
+            // third of a second one (0.057 ms; 768: 0.056; 512: 0.052; 384: 0.058)
+            const int cap_fwd_rows = 2 * sn2_cu_count() < SN2_STAT_SLOTS ? 2 * sn2_cu_count() : SN2_STAT_SLOTS;
+            if (grid > cap_fwd_rows) grid = cap_fwd_rows;
             hipLaunchKernelGGL((fp_fwd_rows_kernel<CA, CB, CO>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
                                p->skip_stride, (const float*)p->src_ws, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.b, p->h,
                                training ? p->blk.stat_slots : (float*)nullptr);
@@ -1713,7 +1716,7 @@ constexpr int HEAD_T_QUADS = 64 * 9;   // a wave's 64 consecutive rows of 36 flo
 // form (24-28 us for 92 MB either way: the kernel streams at 3.3-3.8 TB/s and fp32 MFMA has the packed-VALU rate, 2 x the
 // scalar-operand FMA rate); it frees the VALU and scalar cache for whatever runs beside it.  The backward keeps its
 // row-per-lane form: 188 padded MFMAs per 64 rows would take as long as its 1250 FMAs per row do now.
-__global__ __launch_bounds__(256) void head_fwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
+__global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
                                                             const float* __restrict__ fc, const float* __restrict__ W1,
                                                             const float* __restrict__ b1, const float* __restrict__ W2,
                                                             const float* __restrict__ b2, float* __restrict__ cov,

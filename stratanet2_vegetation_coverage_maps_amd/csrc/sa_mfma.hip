@@ -61,7 +61,7 @@ __device__ __forceinline__ float row_sum(float v) {
 
 // PASS 0: statistics of block 0 only (nl == 2);  PASS 1: full forward, statistics of the last block, extremum
 template <int CF, int NL, int C1, int C2, int PASS, bool BF16>
-__global__ __launch_bounds__(256) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
+__global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
     constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16, CS = PASS == 0 ? C1 : CL, TOS = CS / 16;
     static_assert(CF % 4 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "tile shapes");
