@@ -36,6 +36,9 @@ if os.environ.get("SN2_FPS_SPECULATE", "1") != "0":
     lib.sn2_debug_fps_stamps2(o2)
     print(f"  (C) per-wave top-4 (wave 0, both runs): {o2[24] / (2 * rounds):.1f} ticks/super-round")
     print("  accepted per super-round (both runs), histogram 0..16:", list(o2[:17]))
+    if o2[25]:
+        print(f"  wave 0's queue entries (both runs): {o2[25]}; with a changed point {o2[26] / o2[25]:.2f}; needing the maximum recomputed "
+              f"{o2[27] / o2[25]:.2f}; samples per entry {o2[28] / o2[25]:.2f}; changed points per entry {o2[29] / o2[25]:.1f}")
 else:
     names = ["(a) tests", "(b) dirty loop", "(c) wave reduce+publish", "barrier wait", "(d) select/next sample"]
     tot = sum(d[:5])

@@ -662,6 +662,17 @@ __global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restri
                 const bool real = p[u] < N;
                 const bool changed = real && nd < d0;
                 if (changed) fps_st_dist(pts, p[u], nd);
+#ifdef SN2_FPS_STAMPS
+                if (b == 0 && wave == 0 && lane == 0) {
+                    g_fps_dbg2[25] += 1;                                                     // entries
+                    g_fps_dbg2[26] += __ballot(changed) != 0ull ? 1 : 0;                     // ... with a changed point
+                    g_fps_dbg2[27] += (__ballot(changed && d0 == U[u]) == 0ull && U[u] != INFINITY) ? 0 : 1;   // ... slow path
+                    g_fps_dbg2[28] += __popc(ent[u] >> 11);                                  // samples per entry
+                    g_fps_dbg2[29] += __popcll(__ballot(changed));                           // changed points
+                }
+#endif
+                // five of six queue entries change no point at all (the box test is necessary, not sufficient: fps_stamps.py)
+                if (__ballot(changed) == 0ull) continue;
                 // nothing of the bucket's maximum moved (no changed point held it): its (max, point) stand, and its
                 // second-max entry stays an UPPER bound of the true one, which is all the acceptance tests need
                 if (__ballot(changed && d0 == U[u]) == 0ull && U[u] != INFINITY) continue;
