@@ -256,7 +256,7 @@ class PointNet2(nn.Module):
         g.ready = None
         return g
 
-    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False):
+    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False, inverted=True):
         """Everything that depends on the point POSITIONS only (no weights, no features): both FPS levels, both ball
         queries, the three 3-NN tables.  In the reference these are the torch_cluster calls inside SAModule / FPModule
         (point_net2.py:22-25, 63).  Because they need no parameters they can run ahead of the feature kernels: see
@@ -268,6 +268,8 @@ class PointNet2(nn.Module):
         branches): the level-2 FPS is 16 workgroups for 0.15 ms, chains (a) and (c) fill the chip beside it.
         `defer_join` (with `fork`): return without joining; `g._join = (stream of chain b, stream of chain c)` for the caller
         to wait on where it first needs them (`_forward_impl`: the first set-abstraction level starts beside chain b).
+        `inverted=False`: skip the inverted 3-NN tables (only the backward pass gathers through them: an eval-mode forward
+        does not need them -- a tenth of the geometry pass of the parcel loop); `g.has_inverted` records it.
         `shared`: the pass runs beside other batches' feature kernels (a pipelined loop, `prefetch_geometry`): the level-1
         FPS takes `fps_waves_shared` waves per plot (include/strata_hip.h: sn2_fps_waves)."""
         dev = xyz.device
@@ -297,11 +299,14 @@ class PointNet2(nn.Module):
             ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
             ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[0])
             # the inverted 3-NN tables the backward pass gathers through: positions only, so they belong here
-            ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
-            ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
+            if inverted:
+                ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
+                ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
         with torch.cuda.stream(sc):                                        # (c) the per-point table
             ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1])
-            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+            if inverted:
+                ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+        g.has_inverted = bool(inverted)
         # (a)
         ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
         ops.sa_order(g.cnt1, B, M1, out=g.ord1)
@@ -394,7 +399,7 @@ class PointNet2(nn.Module):
             with torch.cuda.stream(side):
                 # one stream per pass: several passes are in flight on their own lanes already, and a fork inside each
                 # (three more streams + their events) cost the parcel loop 18 % (33 300 -> 27 100 plots/s)
-                g = self._geometry(xyz_d, fs, shared=True, fork=False)
+                g = self._geometry(xyz_d, fs, shared=True, fork=False, inverted=self.training)
                 g.fps_start = fs
                 g.ready = torch.cuda.Event()
                 g.ready.record(side)
@@ -432,11 +437,17 @@ class PointNet2(nn.Module):
                     ops.pack_rows(cloud, xyz, out=rows0)
                     packed = torch.cuda.Event()
                     packed.record(self._pack_stream)
-            geo = self._geometry(xyz, fps_start, defer_join=True)
+            geo = self._geometry(xyz, fps_start, defer_join=True, inverted=training)
         elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
             raise ValueError("prefetched geometry does not match this batch")
         join = getattr(geo, "_join", None)
         geo._join = None
+        if training and not getattr(geo, "has_inverted", True):
+            # tables prefetched in eval mode, forward in training mode: the backward pass needs the inverted indices
+            ops.interp_index(geo.knn3, B, M2, 1, out=geo.inv3)
+            ops.interp_index(geo.knn2, B, M1, M2, out=geo.inv2)
+            ops.interp_index(geo.knn1, B, N, M1, out=geo.inv1, src_pos=geo.pos1_aos)
+            geo.has_inverted = True
         s = _Saved()
         s.__dict__.update({k: v for k, v in geo.__dict__.items()
                            if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws", "fps_start", "_join")})

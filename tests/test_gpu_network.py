@@ -225,6 +225,31 @@ def test_prefetched_geometry_gives_identical_results():
     assert torch.equal(cov_a, cov_b) and torch.equal(proba_a, proba_b)
 
 
+def test_geometry_prefetched_in_eval_mode_serves_a_training_step():
+    """An eval-mode geometry pass skips the inverted 3-NN tables (only the backward gathers through them); a training
+    forward over such a handle builds them itself: same gradients as the plain training step."""
+    N = 4096
+    args = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(2, N, first_plot=9)
+    d["fps_start"] = torch.tensor([[5, 77], [3, 1]])
+    grads = []
+    for prefetch_in_eval in (False, True):
+        m = _model(args, network.init_state_dict(2))
+        cd = {"cloud": d["cloud"], "xyz": d["xyz"], "fps_start": d["fps_start"]}
+        if prefetch_in_eval:
+            m.eval()
+            geo = m.prefetch_geometry(d)
+            assert geo.has_inverted is False
+            cd["geometry"] = geo
+        m.train()
+        cov, proba = m(cd)
+        (cov.sum() + (proba * proba).sum()).backward()
+        torch.cuda.synchronize()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy())
+    scale = np.abs(grads[0]).max()
+    np.testing.assert_allclose(grads[1], grads[0], rtol=0, atol=1e-5 * scale)     # float atomics in the weight gradients
+
+
 def test_kde_lookup_matches_scipy_interp1d():
     """Device lookup of the KDE-mixture densities vs the reference's way (scipy interp1d on the CPU): fp64, same operation
     order -> equal to the last bit on equidistant knots (FFTKDE's grid) and on irregular, unsorted ones."""
