@@ -79,7 +79,8 @@ int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *id
             float *cpos_aos, int *order_ws, void *stream);
 /* The same with a hint for the bucketed kernel: waves per plot, 16 (= 0, what sn2_fps uses: shortest pass when FPS runs
  * alone) or 8 (a 9 % longer pass that leaves half of each occupied CU to concurrent kernels: the setting of a pipelined
- * loop where the pass runs beside another batch's feature kernels).  Same indices either way. */
+ * loop where the pass runs beside another batch's feature kernels); 1 = one sample per arg-max round (round 1's kernel,
+ * kept for cross-checks and timing comparisons).  Same indices whichever runs. */
 int sn2_fps_waves(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
                   float *cpos_aos, int *order_ws, int waves, void *stream);
 

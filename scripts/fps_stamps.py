@@ -13,9 +13,10 @@ B, N, M = 16, 32768, 1024
 xyz = make_batch(B, N)["xyz"].cuda()
 idx = torch.empty(B, M, dtype=torch.int32, device="cuda"); cs = torch.empty(B, 3, M, device="cuda"); ca = torch.empty(B * M, 4, device="cuda")
 ws = torch.empty(5 * B * N + 4104 * B, dtype=torch.int32, device="cuda")
-lib.sn2_fps.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 6
+lib.sn2_fps_waves.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
+WAVES = 1 if os.environ.get("SN2_FPS_SPECULATE", "1") == "0" else 0
 def run():
-    rc = lib.sn2_fps(xyz.data_ptr(), B, N, M, None, idx.data_ptr(), cs.data_ptr(), ca.data_ptr(), ws.data_ptr(), None)
+    rc = lib.sn2_fps_waves(xyz.data_ptr(), B, N, M, None, idx.data_ptr(), cs.data_ptr(), ca.data_ptr(), ws.data_ptr(), WAVES, None)
     assert rc == 0, rc
 run(); torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 8)()

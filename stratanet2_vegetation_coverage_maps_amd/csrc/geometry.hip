@@ -863,26 +863,15 @@ static size_t fps_spec_lds_bytes() {
                           // with 12, 5.6 with 16 -- the prefix mostly ends at a candidate touched by an earlier one -- while
                           // the selection's cost grows with K)
 #endif
-// SN2_FPS_SPECULATE=0 in the environment selects the one-sample-per-round kernel (cross-checks and timing comparisons
-// only; both produce the same indices).
-static bool fps_use_speculation() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SN2_FPS_SPECULATE");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
 template <int SPW, int NW = 16>
 static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* start, int* ws, int* idx, float* cs,
-                             float* ca, hipStream_t st) {
+                             float* ca, hipStream_t st, bool speculate = true) {
     int* order = ws;                                               // B*N ints
     float4* sorted = reinterpret_cast<float4*>(ws + (size_t)B * N);   // B*N float4 (16-byte aligned: B*N*4 bytes offset
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
     int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
     hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid);
-    if (fps_use_speculation()) {
+    if (speculate) {
         constexpr int K = SN2_FPS_K;
         const size_t lds = fps_spec_lds_bytes<SPW, NW, K>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_spec_kernel<SPW, NW, K>),
@@ -899,7 +888,8 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
 extern "C" int sn2_fps_waves(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
                              float* cpos_aos, int* order_ws, int waves, void* stream) {
     if (!pos_soa || !idx || !cpos_soa || !cpos_aos || B <= 0 || N <= 0 || M <= 0 || M > N) return SN2_EINVAL;
-    if (waves != 0 && waves != 16 && waves != 8) return SN2_EINVAL;
+    if (waves != 0 && waves != 16 && waves != 8 && waves != 1) return SN2_EINVAL;
+    const bool spec = waves != 1;      // 1: the one-sample-per-round kernel (round 1's; cross-checks and timing comparisons)
     hipStream_t st = (hipStream_t)stream;
     if (order_ws && N > 2048 && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
         // bucketed path (exact, see above): up to 128 bucket slots per wave = 131 072 points per plot.
@@ -912,12 +902,12 @@ extern "C" int sn2_fps_waves(const float* pos_soa, int B, int N, int M, const in
             if (N <= 16384) return launch_fps_bucket<32, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
             return launch_fps_bucket<64, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         }
-        if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 32768) return launch_fps_bucket<32>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 65536) return launch_fps_bucket<64>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-        if (N <= 131072) return launch_fps_bucket<128>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
+        if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
+        if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
+        if (N <= 32768) return launch_fps_bucket<32>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
+        if (N <= 65536) return launch_fps_bucket<64>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
+        if (N <= 131072) return launch_fps_bucket<128>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
         return SN2_ELIMIT;
     }
     if (N <= 256) return launch_fps<1, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);

@@ -133,7 +133,7 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
         return_ws: bool = False, out=None, waves: int = 0):
     """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
     waves: 0/16 or 8 waves per plot in the bucketed kernel (include/strata_hip.h: sn2_fps_waves; 8 = the pass that shares its
-    CUs with concurrent kernels, what the pipelined training loop asks for); same indices.
+    CUs with concurrent kernels, what the pipelined training loop asks for; 1 = the one-sample-per-round kernel); same indices.
     bucketed=False forces the brute-force kernel (same result; kept for cross-checks).  return_ws=True also returns
     the spatial-order workspace (or None), which `ball_query` over the same points can reuse.
     out = (idx, cpos_soa, cpos_aos, workspace-or-None): caller-owned result buffers (persistent pipelines)."""

@@ -48,6 +48,8 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
     # same workspace for the ball query behind it
     i_8, cs_8, _, ws8 = ops.fps(dev, M, start.to(DEV, torch.int32), waves=8, return_ws=True)
     assert torch.equal(i_8, i_f) and torch.equal(cs_8, cs_f)
+    i_1, cs_1, _ = ops.fps(dev, M, start.to(DEV, torch.int32), waves=1)       # one sample per arg-max round (round 1's kernel)
+    assert torch.equal(i_1, i_f) and torch.equal(cs_1, cs_f)
     nbr8, cnt8, _ = ops.ball_query(dev, cs_8, 1.0, 64, fps_ws=ws8)
     nbr_f, cnt_f, _ = ops.ball_query(dev, cs_f, 1.0, 64)
     assert torch.equal(cnt8, cnt_f)
