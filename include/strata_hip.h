@@ -186,9 +186,9 @@ typedef struct sn2_fp {
     float *scatter_ws;              /* backward workspace when knn_idx and dsrc are given: SN2_INTERP_WS_WORDS(B,R,S)
                                        32-bit words (inverted index of the 3-NN table)                           */
     int scatter_ready;              /* non-zero: scatter_ws already holds the index (sn2_interp_index)           */
-    const int *bn_sums_done;        /* device int or NULL: 1 = blk.dgamma / blk.dbeta already hold this BatchNorm's
-                                       gradients (sn2_head_bn_sums / sn2_fp_bn_sums): the pass over the rows that
-                                       sn2_fp_backward launches for them returns at once                         */
+    const int *bn_sums_done;        /* non-NULL (the `ok` word of sn2_head_bn_sums / sn2_fp_bn_sums): blk.dgamma /
+                                       blk.dbeta already hold this BatchNorm's gradients, sn2_fp_backward launches no
+                                       pass over the rows for them.  NULL: it does                                  */
     float *src_ws;                  /* workspace SN2_FP_SRC_WS_WORDS(B,S,cout) floats or NULL.  Given with knn_idx on a
                                        layer of more than 64*SN2_STAT_SLOTS rows with cb % 4 == 0 (the per-point layer),
                                        everything linear in the interpolation is done once per SOURCE row: forward
@@ -234,15 +234,17 @@ typedef struct sn2_head {
 int sn2_head_forward(const sn2_head *p, void *stream);
 int sn2_head_backward(const sn2_head *p, void *stream);
 /* After sn2_head_backward: the gradients of the BatchNorm whose output the head reads (FP1's), obtained from lin1's weight
- * and bias gradients instead of a pass over all rows (derivation in fp.hip).  gamma, beta: that BatchNorm's parameters;
- * dgamma, dbeta: ACCUMULATED; *ok (device int) = 1 when done, 0 when some |gamma| <= 1e-4 makes the identity unusable
- * (nothing added then: hand `ok` to sn2_fp_backward as bn_sums_done and its ordinary pass runs). */
-int sn2_head_bn_sums(const sn2_head *p, const float *gamma, const float *beta, float *dgamma, float *dbeta, int *ok,
-                     void *stream);
+ * and bias gradients instead of a pass over all rows (derivation in fp.hip).  gamma, beta, mean, invstd: that BatchNorm's
+ * parameters and saved batch statistics; dgamma, dbeta: ACCUMULATED, complete on return.  *ok (device int) = 1 when the
+ * identity was used, 0 when some |gamma| <= 1e-4 made it unusable and the kernel summed over the rows itself (p->f = the
+ * BatchNorm's input rows, p->dy = the gradient of its output).  Hand `ok` to the producer's sn2_fp_backward as bn_sums_done. */
+int sn2_head_bn_sums(const sn2_head *p, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                     float *dgamma, float *dbeta, int *ok, void *stream);
 /* The same for the BatchNorm whose output an FP block interpolates (its columns 0..ca-1), after that block's
- * sn2_fp_backward: the interpolation weights of a row sum to 1, so the identity carries over. */
-int sn2_fp_bn_sums(const sn2_fp *p, const float *gamma, const float *beta, float *dgamma, float *dbeta, int *ok,
-                   void *stream);
+ * sn2_fp_backward: the interpolation weights of a row sum to 1, so the identity carries over (p->src = the BatchNorm's
+ * input rows, p->dsrc = the gradient of its output). */
+int sn2_fp_bn_sums(const sn2_fp *p, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                   float *dgamma, float *dbeta, int *ok, void *stream);
 
 /* ---- 2D projections -- model/project_to_2d.py -------------------------------------------------------------- */
 

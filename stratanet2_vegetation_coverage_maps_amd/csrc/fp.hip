@@ -1481,9 +1481,11 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     // waves per workgroup (one workgroup per CU): as many as the staging regions and 256 VGPRs per lane allow
     constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 8 <= 150 * 1024) ? 8 : ((Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : 2);
     const int R = p->B * p->R_per_plot;
-    // bn_sums_done (device int or NULL): 1 = dgamma / dbeta of this block's BatchNorm already came from the consumer's
-    // gradients (sn2_head_bn_sums / sn2_fp_bn_sums) and the pass over the rows returns at once
-    if (R <= (1 << 16)) {
+    // bn_sums_done (non-NULL): dgamma / dbeta of this block's BatchNorm already came from sn2_head_bn_sums / sn2_fp_bn_sums
+    if (p->bn_sums_done) {
+        // sn2_head_bn_sums / sn2_fp_bn_sums already completed dgamma / dbeta of this block (by the identity or by their
+        // own pass over the rows)
+    } else if (R <= (1 << 16)) {
         hipLaunchKernelGGL((fp_bwd_bn_small_kernel<CO>), dim3(sn2_cdiv(R, 64)), dim3(256), 0, st, R, p->h_stride, p->h, p->dy,
                            p->blk.mean, p->blk.invstd, p->blk.dgamma, p->blk.dbeta, p->bn_sums_done);
     } else {
@@ -1935,13 +1937,17 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
 //   dgamma[o] = sum_rows dy[.][o]*xhat[.][o] = sum_j W[j][col0+o] * G[j][o],  G[j][o] = sum_r dpre[r][j] * sum_k w_rk xhat[idx_rk][o]
 // and dW[j][col0+o] = sum_r dpre[r][j]*u[r][o] = gamma[o]*G[j][o] + beta[o]*db[j], so G = (dW - beta*db) / gamma.
 // C dot products of length cout instead of a pass over all rows (FP1's BatchNorm: 0.03 ms and 150 MB at C2).  Needs
-// |gamma| > 1e-4 on every channel (else the caller's ordinary pass runs: see `ok`); accumulated in fp64.
-// ok (device int): set to 1 when every |gamma| is large enough for the division and the sums were added, to 0 otherwise --
-// sn2_fp_backward then runs its ordinary pass over the rows (its BN kernels return at once when *ok == 1).
+// |gamma| > 1e-4 on every channel; accumulated in fp64.  When some |gamma| is too small for the division the same
+// workgroups make the ordinary pass themselves, one channel each over all rows (h = the BatchNorm's input rows, dyv = the
+// gradient of its output that the consumer's backward left: slow -- a strided column per workgroup -- and rare), so the
+// sums are complete either way and sn2_fp_backward launches no kernel of its own for them (three launches per step that
+// did nothing but read a flag).  ok (device int): 1 = the identity was used, 0 = the pass over the rows.
 __global__ __launch_bounds__(256) void bn_sums_from_consumer_kernel(
     int C, int cout, int cin, int col0, const float* __restrict__ W, const float* __restrict__ dW,
     const float* __restrict__ db, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok, int rep_k, int rep_stride) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok, int rep_k, int rep_stride,
+    const float* __restrict__ h, int h_stride, const float* __restrict__ dyv, int dy_stride, long R,
+    const float* __restrict__ mean, const float* __restrict__ invstd) {
     // one workgroup per channel o of the BatchNorm; its threads share the (consumer row j, gradient image r) pairs
     __shared__ int s_ok;
     __shared__ double s_red[2][4];
@@ -1952,7 +1958,27 @@ __global__ __launch_bounds__(256) void bn_sums_from_consumer_kernel(
         if (!(fabsf(gamma[c]) > 1e-4f)) s_ok = 0;               // also catches NaN
     __syncthreads();
     if (o == 0 && threadIdx.x == 0) *ok = s_ok;
-    if (!s_ok) return;
+    if (!s_ok) {
+        const float mu = mean[o], is = invstd[o];
+        double sb = 0.0, sg = 0.0;
+        for (long r = threadIdx.x; r < R; r += 256) {
+            const float dd = dyv[(size_t)r * dy_stride + o], hh = h[(size_t)r * h_stride + o];
+            sb += (double)dd;
+            sg += (double)(dd * ((hh - mu) * is));
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            sb += __shfl_xor(sb, m);
+            sg += __shfl_xor(sg, m);
+        }
+        if (lane == 0) s_red[0][wave] = sb, s_red[1][wave] = sg;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            dbeta[o] += (float)((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
+            dgamma[o] += (float)((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+        }
+        return;
+    }
     const int images = rep_k > 1 ? rep_k : 1;                   // the consumer's (dW, db) images are summed on the fly
     const double g = (double)gamma[o], b = (double)beta[o];
     double sb = 0.0, sg = 0.0;
@@ -1997,23 +2023,26 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     SN2_RETURN_LAUNCH();
 }
 
-extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                                int* ok, void* stream) {
+extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const float* beta, const float* mean,
+                                const float* invstd, float* dgamma, float* dbeta, int* ok, void* stream) {
     SN2_TRY(check_head(p));
-    if (!p->dW1 || !p->db1 || !gamma || !beta || !dgamma || !dbeta || !ok) return SN2_EINVAL;
+    if (!p->dW1 || !p->db1 || !p->dy || !gamma || !beta || !mean || !invstd || !dgamma || !dbeta || !ok) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(p->cin), dim3(256), 0, (hipStream_t)stream, p->cin, 16, p->cin, 0, p->W1,
                        (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta, ok, p->grad_replicas,
-                       p->grad_replica_stride);
+                       p->grad_replica_stride, p->f, p->f_stride, (const float*)p->dy, p->f_stride, (long)p->R, mean, invstd);
     SN2_RETURN_LAUNCH();
 }
 
-extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* beta, float* dgamma, float* dbeta,
-                              int* ok, void* stream) {
+extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                              float* dgamma, float* dbeta, int* ok, void* stream) {
     SN2_TRY(check_fp(p));
-    if (!p->knn_idx || !p->blk.dW || !p->blk.db || !gamma || !beta || !dgamma || !dbeta || !ok || p->ca > 64) return SN2_EINVAL;
+    if (!p->knn_idx || !p->blk.dW || !p->blk.db || !p->dsrc || !gamma || !beta || !mean || !invstd || !dgamma || !dbeta || !ok ||
+        p->ca > 64)
+        return SN2_EINVAL;
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(p->ca), dim3(256), 0, (hipStream_t)stream, p->ca, p->blk.cout, p->blk.cin, 0,
                        (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta, ok,
-                       p->blk.grad_replicas, p->blk.grad_replica_stride);
+                       p->blk.grad_replicas, p->blk.grad_replica_stride, p->src, p->src_stride, (const float*)p->dsrc,
+                       p->dsrc_stride, (long)p->B * p->S_per_plot, mean, invstd);
     SN2_RETURN_LAUNCH();
 }
 

@@ -504,13 +504,14 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     return d
 
 
-def fp_bn_sums(d: FP, gamma, beta, dgamma, dbeta, ok):
-    """After fp_backward(d): dgamma/dbeta (ACCUMULATED) of the BatchNorm whose output block d interpolates, from d's own
-    weight and bias gradients (include/strata_hip.h: sn2_fp_bn_sums)."""
-    for t, n in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+def fp_bn_sums(d: FP, gamma, beta, mean, invstd, dgamma, dbeta, ok):
+    """After fp_backward(d): dgamma/dbeta (ACCUMULATED, complete) of the BatchNorm whose output block d interpolates, from d's
+    own weight and bias gradients -- or, where a |gamma| is too small for that, summed over the rows by the same kernel
+    (include/strata_hip.h: sn2_fp_bn_sums).  mean, invstd: the BatchNorm's saved batch statistics."""
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk(t, F32, (d.ca,), n)
     _chk(ok, I32, (1,), "ok")
-    _call("sn2_fp_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(ok), _stream())
+    _call("sn2_fp_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(ok), _stream())
 
 
 def fp_forward(d: FP, training: bool):
@@ -623,12 +624,13 @@ def head_backward(d: Head):
     _call("sn2_head_backward", d, _stream())
 
 
-def head_bn_sums(d: Head, gamma, beta, dgamma, dbeta, ok):
-    """After head_backward: dgamma/dbeta (ACCUMULATED) of the BatchNorm feeding lin1, from lin1's gradients."""
-    for t, n in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+def head_bn_sums(d: Head, gamma, beta, mean, invstd, dgamma, dbeta, ok):
+    """After head_backward: dgamma/dbeta (ACCUMULATED, complete) of the BatchNorm feeding lin1, from lin1's gradients (or by
+    the kernel's own pass over the rows where a |gamma| is too small)."""
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _chk(t, F32, (d.cin,), n)
     _chk(ok, I32, (1,), "ok")
-    _call("sn2_head_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(ok), _stream())
+    _call("sn2_head_bn_sums", d, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(ok), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- projections

@@ -78,6 +78,7 @@ class TrainPipeline:
         self.done = 0                             # feature passes launched so far
         self.use_graph = use_graph
         self.slot_wait = "host"                   # how a geometry pass waits for its slots to be free: _wait_slots
+        self.feeder_blocking = False              # diagnostic: make the feeder's host-to-device copies synchronous
         self.feeder = None                        # optional: feeder(i) -> dict of HOST tensors for batch number i
         # exchange between the backward graph and the Adam graph (always when world > 1; can be forced on one GPU to
         # exercise exactly the launch sequence the multi-GPU run uses)
@@ -115,7 +116,7 @@ class TrainPipeline:
                 # the next batch arrives from the host (pinned buffers): its copy into the slot rides on the side stream,
                 # in front of the geometry pass that reads it and behind the feature pass that last read the slot
                 for name, t in self.feeder(i).items():
-                    d[name].copy_(t, non_blocking=not getattr(self, 'feeder_blocking', False))
+                    d[name].copy_(t, non_blocking=not self.feeder_blocking)
             self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k], **self._geo_kw)
             self.geo_ready[k].record(st)
         self.issued = max(self.issued, i + 1)
@@ -133,7 +134,7 @@ class TrainPipeline:
                 d = self.inputs[k]
                 if self.feeder is not None:
                     for name, t in self.feeder(j).items():
-                        d[name].copy_(t, non_blocking=not getattr(self, 'feeder_blocking', False))
+                        d[name].copy_(t, non_blocking=not self.feeder_blocking)
                 h = k - k0
                 self.xyz2[pb][h * B:(h + 1) * B].copy_(d["xyz"], non_blocking=True)
                 self.fs2[pb][:, h * B:(h + 1) * B].copy_(d["fps_start"], non_blocking=True)

@@ -557,22 +557,25 @@ class PointNet2(nn.Module):
         ops.head_backward(hd)
         # FP1's BatchNorm gradients fall out of lin1's (hip_ops.head_bn_sums): no extra pass over the B*N rows
         bn1 = self.fp1_module.nn[0][2]
-        bn_ok = torch.empty(3, dtype=I32, device=dev)      # per BatchNorm: did the shortcut apply (else the row pass runs)
-        ops.head_bn_sums(hd, bn1.weight.detach(), bn1.bias.detach(), views[id(bn1.weight)], views[id(bn1.bias)], bn_ok[0:1])
+        bn_ok = torch.empty(3, dtype=I32, device=dev)      # per BatchNorm: did the shortcut apply (else the same kernel's row pass)
+        ops.head_bn_sums(hd, bn1.weight.detach(), bn1.bias.detach(), s.b_fp1.aux[2], s.b_fp1.aux[3], views[id(bn1.weight)],
+                         views[id(bn1.bias)], bn_ok[0:1])
         # FP1 -> d(fp2 output)
         dy2 = buf["dy2"].view(B * M1, 36)
         d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 36, dtype=F32, device=dev), with_grads=True,
                             interp_index=s.inv1, bn_sums_done=bn_ok[0:1])
         ops.fp_backward(d1)
         bn2 = self.fp2_module.nn[0][2]      # FP2's BatchNorm feeds FP1's interpolation: its gradients from FP1's dW, db
-        ops.fp_bn_sums(d1, bn2.weight.detach(), bn2.bias.detach(), views[id(bn2.weight)], views[id(bn2.bias)], bn_ok[1:2])
+        ops.fp_bn_sums(d1, bn2.weight.detach(), bn2.bias.detach(), s.b_fp2.aux[2], s.b_fp2.aux[3], views[id(bn2.weight)],
+                       views[id(bn2.bias)], bn_ok[1:2])
         # FP2 -> d(fp3 output), d x1
         dy3, dx1 = buf["dy3"].view(B * M2, 64), buf["dx1"].view(B * M1, 16)
         d2 = self._fp2_desc(s, dy=dy2, dsrc=dy3, dskip=dx1, du_scratch=torch.empty(B * M1, 64, dtype=F32, device=dev),
                             with_grads=True, interp_index=s.inv2, bn_sums_done=bn_ok[1:2])
         ops.fp_backward(d2)
         bn3 = self.fp3_module.nn[0][2]      # and FP3's from FP2's
-        ops.fp_bn_sums(d2, bn3.weight.detach(), bn3.bias.detach(), views[id(bn3.weight)], views[id(bn3.bias)], bn_ok[2:3])
+        ops.fp_bn_sums(d2, bn3.weight.detach(), bn3.bias.detach(), s.b_fp3.aux[2], s.b_fp3.aux[3], views[id(bn3.weight)],
+                       views[id(bn3.bias)], bn_ok[2:3])
         # FP3 -> d x3, d x2
         dx3, dx2 = buf["dx3"].view(B, 64), buf["dx2"].view(B * M2, 32)
         ops.fp_backward(self._fp3_desc(s, dy=dy3, dsrc=dx3, dskip=dx2,

@@ -228,25 +228,26 @@ class PointNet2ThreeSA(PointNet2):
         def bn_of(mod):
             return mod.nn[0][2]
 
-        def sums(fn, d, bn, k):
-            fn(d, bn.weight.detach(), bn.bias.detach(), views[id(bn.weight)], views[id(bn.bias)], bn_ok[k:k + 1])
+        def sums(fn, d, bn, blk, k):
+            fn(d, bn.weight.detach(), bn.bias.detach(), blk.aux[2], blk.aux[3], views[id(bn.weight)], views[id(bn.bias)],
+               bn_ok[k:k + 1])
 
-        sums(ops.head_bn_sums, hd, bn_of(self.fp1_module), 0)
+        sums(ops.head_bn_sums, hd, bn_of(self.fp1_module), s.b_fp1, 0)
         dy2, dy3, dy4 = buf["dy2"].view(B * M1, 36), buf["dy3"].view(B * M2, 64), buf["dy4"].view(B * M3, 64)
         dx1, dx2, dx3 = buf["dx1"].view(B * M1, 16), buf["dx2"].view(B * M2, 32), buf["dx3"].view(B * M3, 64)
         dxg, dy_sa4 = buf["dxg"].view(B, 64), buf["dy_sa4"].view(B * M3, 64)
         d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=e(B * N, 36), with_grads=True, interp_index=s.inv1,
                             bn_sums_done=bn_ok[0:1])
         ops.fp_backward(d1)
-        sums(ops.fp_bn_sums, d1, bn_of(self.fp2_module), 1)
+        sums(ops.fp_bn_sums, d1, bn_of(self.fp2_module), s.b_fp2, 1)
         d2 = self._fp2_desc(s, dy=dy2, dsrc=dy3, dskip=dx1, du_scratch=e(B * M1, 64), with_grads=True, interp_index=s.inv2,
                             bn_sums_done=bn_ok[1:2])
         ops.fp_backward(d2)
-        sums(ops.fp_bn_sums, d2, bn_of(self.fp3_module), 2)
+        sums(ops.fp_bn_sums, d2, bn_of(self.fp3_module), s.b_fp3, 2)
         d3 = self._fp3_desc(s, dy=dy3, dsrc=dy4, dskip=dx2, du_scratch=e(B * M2, 64), with_grads=True, interp_index=s.inv3,
                             bn_sums_done=bn_ok[2:3])
         ops.fp_backward(d3)
-        sums(ops.fp_bn_sums, d3, bn_of(self.fp4_module), 3)
+        sums(ops.fp_bn_sums, d3, bn_of(self.fp4_module), s.b_fp4, 3)
         ops.fp_backward(self._fp4_desc(s, dy=dy4, dsrc=dxg, dskip=dx3, du_scratch=e(B * M3, 64), with_grads=True,
                                        interp_index=s.inv4, bn_sums_done=bn_ok[3:4]))
         ops.plot_max_backward(dxg, s.argg, B, M3, 64, dy_sa4)
