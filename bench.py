@@ -286,7 +286,7 @@ def main():
     flatten_parameters(model)
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
     # depth+1 resident batches (the pipeline's slots); batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
-    n_slots = 1 if a.serial else (a.depth + 1 if (a.no_pair or a.arch != "ref") else 2 * a.depth + 2)
+    n_slots = 1 if a.serial else (a.depth + 1 if a.no_pair else 2 * a.depth + 2)
     slots = []
     for j in range(n_slots):
         host = make_batch(B, N_POINTS, first_plot=j * world * B + shard_of_rank(rank, B)[0])

@@ -60,7 +60,7 @@ class TrainPipeline:
                 self.geo_pairs.append(gp)
                 self.geo[2 * pb], self.geo[2 * pb + 1] = g0, g1
                 self.xyz2.append(torch.empty(2 * B, 3, N, dtype=slot_inputs[0]["xyz"].dtype, device=dev))
-                self.fs2.append(torch.zeros(2, 2 * B, dtype=torch.int32, device=dev))
+                self.fs2.append(torch.zeros(slot_inputs[0]["fps_start"].shape[0], 2 * B, dtype=torch.int32, device=dev))
         else:
             self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
         self.B = B

@@ -65,8 +65,70 @@ class PointNet2ThreeSA(PointNet2):
         return self._sizes3(N)[:2]
 
     # ------------------------------------------------------------------------------------------ geometry
-    alloc_geometry_pair = None      # the two-batches-per-pass geometry of pipeline.TrainPipeline is built for the reference
-    _geometry_pair = None           # architecture only
+    def alloc_geometry_pair(self, B, N, device=None):
+        """As `PointNet2.alloc_geometry_pair` with the third ball-query level: buffers of one geometry pass over TWO batches
+        and the two per-batch views the feature passes read."""
+        dev = torch.device(device if device is not None else self.lin1.weight.device)
+        M1, M2, M3 = self._sizes3(N)
+        gp = self.alloc_geometry(2 * B, N, dev)
+        e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
+        halves = []
+        for h in range(2):
+            g = _Saved()
+            g.B, g.N, g.M1, g.M2, g.M3 = B, N, M1, M2, M3
+            pl = slice(h * B, (h + 1) * B)
+            for lvl, M in ((1, M1), (2, M2), (3, M3)):
+                rows = slice(h * B * M, (h + 1) * B * M)
+                setattr(g, f"idx{lvl}", getattr(gp, f"idx{lvl}")[pl])
+                setattr(g, f"pos{lvl}_soa", getattr(gp, f"pos{lvl}_soa")[pl])
+                setattr(g, f"pos{lvl}_aos", getattr(gp, f"pos{lvl}_aos")[rows])
+                setattr(g, f"nbr{lvl}", getattr(gp, f"nbr{lvl}")[rows])
+                setattr(g, f"cnt{lvl}", getattr(gp, f"cnt{lvl}")[rows])
+                setattr(g, f"ord{lvl}", e(ops.sa_order_len(B, M), dt=I32))
+                setattr(g, f"ws{lvl}", None)
+            for name, R in (("knn4", M3), ("knn3", M2), ("knn2", M1), ("knn1", N)):
+                rows = slice(h * B * R, (h + 1) * B * R)
+                t = getattr(gp, name)
+                setattr(g, name, (t[0][rows], t[1][rows]))
+            g.totals = torch.zeros(3, dtype=I64, device=dev)
+            g.tot1, g.tot2, g.tot3 = g.totals[0:1], g.totals[1:2], g.totals[2:3]
+            g.inv4, g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M3, 1), (M2, M3), (M1, M2), (N, M1)))
+            g.nn_ws = None
+            g.ready = None
+            halves.append(g)
+        return gp, tuple(halves)
+
+    def _geometry_pair(self, xyz2, fps_start2, gp, halves):
+        """`_geometry` for two batches at once: xyz2 (2B,3,N), fps_start2 (3,2B); FPS, ball queries and 3-NN tables on the 2B
+        plots in one launch each (into `gp`), the per-batch products (message totals, work items, inverted indices) per half."""
+        B2, _, N = xyz2.shape
+        B = B2 // 2
+        M1, M2, M3 = self._sizes3(N)
+        if (gp.B, gp.N) != (B2, N):
+            raise ValueError("geometry buffers do not match this batch pair")
+        cap = _p2.MAX_NEIGHBORS
+        src = xyz2
+        for lvl, (M, mod) in enumerate(((M1, self.sa1_module), (M2, self.sa2_module), (M3, self.sa3_module)), 1):
+            ws, cs = getattr(gp, f"ws{lvl}"), getattr(gp, f"pos{lvl}_soa")
+            ops.fps(src, M, fps_start2[lvl - 1], out=(getattr(gp, f"idx{lvl}"), cs, getattr(gp, f"pos{lvl}_aos"), ws),
+                    waves=self.fps_waves_shared if lvl == 1 else 0)
+            ops.ball_query(src, cs, mod.r, cap, getattr(gp, f"tot{lvl}"), fps_ws=ws,
+                           out=(getattr(gp, f"nbr{lvl}"), getattr(gp, f"cnt{lvl}")))
+            src = cs
+        ops.three_nn(gp.posg, gp.pos3_soa, 1, out=gp.knn4)
+        ops.three_nn(gp.pos3_soa, gp.pos2_soa, 3, out=gp.knn3, ws=gp.nn_ws[0])
+        ops.three_nn(gp.pos2_soa, gp.pos1_soa, 3, out=gp.knn2, ws=gp.nn_ws[1])
+        ops.three_nn(gp.pos1_soa, xyz2, 3, out=gp.knn1, ws=gp.nn_ws[2])
+        for h, g in enumerate(halves):
+            g.xyz = xyz2[h * B:(h + 1) * B]
+            for lvl, M in ((1, M1), (2, M2), (3, M3)):
+                ops.count_sum(getattr(g, f"cnt{lvl}"), getattr(g, f"tot{lvl}"))
+                ops.sa_order(getattr(g, f"cnt{lvl}"), B, M, out=getattr(g, f"ord{lvl}"))
+            ops.interp_index(g.knn4, B, M3, 1, out=g.inv4)
+            ops.interp_index(g.knn3, B, M2, M3, out=g.inv3)
+            ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
+            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+        return halves
 
     def alloc_geometry(self, B, N, device=None):
         dev = torch.device(device if device is not None else self.lin1.weight.device)

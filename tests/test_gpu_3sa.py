@@ -35,12 +35,14 @@ def test_3sa_forward_backward_vs_oracle(B, N, ratio1):
     assert not fails, "\n".join(fails)
 
 
-def test_3sa_in_the_pipelined_loop_matches_the_plain_loop():
-    """`bench.py --arch 3sa` drives this model through TrainPipeline (one geometry pass per batch on side streams, feature
-    graphs per slot): the same losses as the plain loop."""
+@pytest.mark.parametrize("pair", [False, True])
+def test_3sa_in_the_pipelined_loop_matches_the_plain_loop(pair):
+    """`bench.py --arch 3sa` drives this model through TrainPipeline (geometry passes on side streams -- one per batch, or one
+    per two batches in pair mode --, feature graphs per slot): the same losses as the plain loop."""
     from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters
     from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
-    N, B, depth, steps = 4096, 2, 2, 6
+    N, B, depth, steps = 4096, 2, 2, 8 if pair else 6
+    n_slots = 2 * depth + 2 if pair else depth + 1
 
     def setup():
         args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0, ratio3=0.25, r3=4.0)
@@ -50,7 +52,7 @@ def test_3sa_in_the_pipelined_loop_matches_the_plain_loop():
         flatten_parameters(model)
         opt = FlatAdam(model, lr=0.0, eps=1e-3)          # lr 0: every step must reproduce the plain loop's loss
         slots = []
-        for j in range(depth + 1):
+        for j in range(n_slots):
             h = make_batch(B, N, first_plot=300 + j * B)
             slots.append({"cloud": h["cloud"].cuda(), "xyz": h["xyz"].cuda(),
                           "fps_start": torch.full((3, B), j, dtype=torch.int32, device="cuda"),
@@ -75,7 +77,7 @@ def test_3sa_in_the_pipelined_loop_matches_the_plain_loop():
         opt.step()
     model2, opt2, slots2, fstep2 = setup()
     pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth)
-    assert not pipe.pair
+    assert pipe.pair == pair
     pipe.capture()
     pipe.prime()
     got = [float(pipe.step().detach()) for _ in range(steps)]
