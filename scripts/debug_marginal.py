@@ -10,7 +10,7 @@ from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_para
 from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
 from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
 
-B, N = 16, 32768
+B, N = int(os.environ.get("PLOTS", "16")), int(os.environ.get("POINTS", "32768"))
 args = make_args(cuda=0, subsample_size=N, ratio1=1024 / N, r1=1.0, ratio2=0.25, r2=2.0)
 torch.manual_seed(0)
 model = PointNet2(args).train()
