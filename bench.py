@@ -24,14 +24,84 @@ import sys
 import time
 
 
+def _gpu_numa_nodes():
+    """NUMA node of every GPU in HIP device order, read from sysfs (KFD topology -> PCI location -> numa_node) without
+    touching the GPU; [] when the box does not expose it."""
+    import glob
+    out = []
+    try:
+        nodes = sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda d: int(os.path.basename(d)))
+        for nd in nodes:
+            props = dict(l.split()[:2] for l in open(os.path.join(nd, "properties")) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue                                   # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7}"
+            out.append(int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read()))
+    except (OSError, ValueError, KeyError):
+        return []
+    return out
+
+
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def rank_cpu_share(local_rank, local_world):
+    """The host cores of one rank: its share of the cores of the NUMA node its GPU hangs off (so that the launch thread, the
+    pinned staging buffers and the CPU baseline stay local to the GPU), or -- when sysfs does not say -- a contiguous
+    1/local_world slice of the cores this process may use.  -> (sorted core list, "numa<k>" | "slice")."""
+    allowed = sorted(os.sched_getaffinity(0))
+    numa = _gpu_numa_nodes()
+    if len(numa) >= local_world and all(n >= 0 for n in numa[:local_world]):
+        try:
+            mine = numa[local_rank]
+            node_cpus = sorted(_parse_cpulist(open(f"/sys/devices/system/node/node{mine}/cpulist").read()) & set(allowed))
+            peers = [r for r in range(local_world) if numa[r] == mine]
+            share = len(node_cpus) // len(peers)
+            if share >= 1:
+                k = peers.index(local_rank)
+                return node_cpus[k * share:(k + 1) * share], f"numa{mine}"
+        except OSError:
+            pass
+    share = len(allowed) // max(1, local_world)
+    if share >= 1:
+        return allowed[local_rank * share:(local_rank + 1) * share], "slice"
+    return allowed, "shared"
+
+
+def pin_rank(local_rank, local_world):
+    """Give this rank its own cores (`rank_cpu_share`) and size OpenMP to them; called before torch is imported.  With one
+    rank nothing is pinned (the whole allowance is the rank's)."""
+    if local_world <= 1:
+        return sorted(os.sched_getaffinity(0)), "all"
+    cpus, how = rank_cpu_share(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        how = "unpinned"
+    os.environ["OMP_NUM_THREADS"] = str(max(1, len(cpus)))
+    return cpus, how
+
+
 def _spawn_ranks_if_needed():
     """`python bench.py --gpus N` typed as is (no launcher): start the N ranks as fresh child processes -- one per GPU,
     the same environment torch.distributed.run would give them -- wait, and exit with their worst return code.  Runs
-    before torch or the HIP library are imported: this process never touches a GPU, so starting children is safe."""
+    before torch or the HIP library are imported: this process never touches a GPU, so starting children is safe.
+    Every rank (started here or by torch.distributed.run) then pins itself to its share of the host cores (`pin_rank`)."""
     if "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        cpus, how = pin_rank(int(os.environ.get("LOCAL_RANK", "0")), lw)
+        os.environ["SN2_BENCH_PINNED"] = f"{how}:{len(cpus)}"
         if os.environ.get("SN2_BENCH_LAUNCH_CHECK"):       # tests/test_host_api.py: what environment did the rank get?
-            print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}),
-                  flush=True)
+            d = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")}
+            d["affinity"], d["affinity_pinned"] = sorted(os.sched_getaffinity(0)), how in ("slice",) or how.startswith("numa")
+            print(json.dumps(d), flush=True)
             sys.exit(0 if os.environ["SN2_BENCH_LAUNCH_CHECK"] != "fail" or os.environ["RANK"] != "1" else 3)
         return
     p = argparse.ArgumentParser(add_help=False)
@@ -49,7 +119,6 @@ def _spawn_ranks_if_needed():
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     while procs:
@@ -220,6 +289,201 @@ def cpu_baseline():
                       f"torch {torch.get_num_threads()} threads + scipy cKDTree"}
 
 
+def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slots):
+    """Model, optimiser, resident input slots and the feature-step closure of one training workload (the step of
+    /root/reference/learning/train.py:52-66 minus exchange + optimiser)."""
+    from types import SimpleNamespace
+    args = make_args(cuda=local_rank, subsample_size=n_points, ratio1=M1 / n_points, r1=1.0, ratio2=0.25, r2=2.0)
+    args.mma_dtype = "bf16" if dtype == "bf16" else "fp32"
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    if arch == "3sa":
+        from stratanet2_vegetation_coverage_maps_amd.point_net2_3sa import PointNet2ThreeSA
+        args.ratio3, args.r3 = 0.25, 4.0
+        model = PointNet2ThreeSA(args).train()
+        model.set_mma_dtype(args.mma_dtype)
+    else:
+        model = PointNet2(args).train()
+    n_fps = 3 if arch == "3sa" else 2
+    flatten_parameters(model)
+    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
+    # batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
+    slots = []
+    for j in range(n_slots):
+        host = make_batch(B, n_points, first_plot=j * world * B + shard_of_rank(rank, B)[0])
+        slots.append({"cloud": host["cloud"].to(dev), "xyz": host["xyz"].to(dev),
+                      "fps_start": torch.zeros(n_fps, B, dtype=torch.int32, device=dev),
+                      "gt": host["coverages"].to(dev), "pdf": host["pdf_all"].to(dev)})
+
+    def feature_step(inp, geo=None):
+        """zero_grad -> forward -> plot-wise projection -> loss -> backward (everything but exchange + Adam)"""
+        opt.zero_grad(set_to_none=True)
+        cd = {"cloud": inp["cloud"], "xyz": inp["xyz"], "fps_start": inp["fps_start"]}
+        if geo is not None:
+            cd["geometry"] = geo
+        cov, proba = model(cd)
+        pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
+        loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
+        loss.backward()
+        return loss
+
+    return SimpleNamespace(args=args, model=model, opt=opt, slots=slots, feature_step=feature_step, n_fps=n_fps)
+
+
+def step_model_figures(B, n_points, m1, m2, e1, e2):
+    """compulsory HBM bytes (2.2 x forward) and dense-layer flops (3 x forward - 352 E1) of ONE training step
+    of the reference architecture at the measured message counts."""
+    E1p, E2p = e1 / B, e2 / B                                                    # messages per plot
+    fwd_flops = 864 * E1p + 1216 * E2p + 4480 * m2 + 12288 * m2 + 5440 * m1 + 2856 * n_points + 1248 * n_points
+    fwd_bytes = 368 * n_points + 8 * (E1p + E2p) + 16 * (m1 + m2) + 8 * (16 * m1 + 32 * m2 + 64 + 64 * m2 + 34 * m1) + 48 * m1 + 16 * m2
+    return B * 2.2 * fwd_bytes, B * (3 * fwd_flops - 352 * E1p)
+
+
+def secondary_train_leg(dev, arch, B, n_points, dtype, steps, warmup, depth=3):
+    """One more training configuration through the SAME software-pipelined loop as the headline (pair mode, one hipGraph per
+    slot), compact: ms/step, plots/s and the whole step against both roofs.  Single GPU, inputs resident."""
+    from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
+    w = build_training(dev, dev.index or 0, 0, 1, B, n_points, arch, dtype, 2 * depth + 2)
+    pipe = TrainPipeline(w.model, w.opt, w.feature_step, w.slots, depth=depth)
+    pipe.capture()
+    pipe.prime()
+    for _ in range(warmup):
+        pipe.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = pipe.step()
+    pipe.drain()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    with torch.no_grad():
+        _, _, saved = w.model._forward_impl(w.slots[0]["xyz"], w.slots[0]["cloud"], w.slots[0]["fps_start"], False)
+        e1, e2 = int(saved.tot1.item()), int(saved.tot2.item())
+        m1, m2 = saved.M1, saved.M2
+    by, fl = step_model_figures(B, n_points, m1, m2, e1, e2)       # the reference architecture's terms (3sa: a lower bound)
+    peak = {"f32": 157.3e12, "bf16": 2.5e15}[dtype]
+    out = {"arch": arch, "plots_per_gpu": B, "points_per_plot": n_points, "dtype": dtype, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(ms, 4), "plots_per_s": round(B / (ms * 1e-3), 2), "loss": round(float(loss.item()), 6),
+           "messages_sa1": e1, "messages_sa2": e2,
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(by / (ms * 1e-3) / 1e9, 2),
+                        "frac": round(by / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4), "compulsory_bytes": int(by),
+                        "dense_flops": int(fl), "mfma_frac": round(fl / (ms * 1e-3) / peak, 4),
+                        "what": "whole step: SURVEY.md 8d compulsory bytes / dense flops of the reference architecture's "
+                                "layers at the measured message counts over ms_per_step"}}
+    del pipe, w
+    torch.cuda.empty_cache()
+    return out
+
+
+def inference_leg(dev, plots=2048, points=10000, batch=128, repeat=3, prefetch=3, cpu_sample_plots=8):
+    """BASELINE configs[3] (SURVEY.md 8d "C4"): parcel inference -- 2048 overlapping 10 m plots x 10 000 points tiling one
+    parcel, eval forward + fixed-grid max rasters + the ordered weighted mosaic merge (predict.py:96-141), inputs resident.
+    Median of `repeat` whole-parcel runs; roofline on SURVEY 8d's 368 B/point forward figure; the oracle's eval forward +
+    rasters on a bounded sample of the same plots as the CPU baseline."""
+    from stratanet2_vegetation_coverage_maps_amd import inference
+    args = make_args(cuda=dev.index or 0, subsample_size=points)           # reference defaults: ratios .25/.25, r sqrt2/sqrt8
+    torch.manual_seed(0)
+    model = PointNet2(args).eval()
+    cols, stride = 64, 5.0                                                 # plot centres every 5 m: each pixel sees ~12 plots
+    rows = (plots + cols - 1) // cols
+    batches, sample = [], None
+    for s in range(0, plots, batch):
+        nb = min(batch, plots - s)
+        d = make_batch(nb, points, first_plot=s)
+        if sample is None:
+            sample = {"cloud": d["cloud"][:cpu_sample_plots].clone(), "xyz": d["xyz"][:cpu_sample_plots].clone()}
+        k = torch.arange(s, s + nb)
+        c = torch.stack([10.0 + stride * (k % cols), 10.0 + stride * (k // cols)], 1).double()
+        batches.append({"cloud": d["cloud"].to(dev), "xyz": d["xyz"].to(dev), "plot_center": c,
+                        "fps_start": torch.zeros(2, nb, dtype=torch.int64)})
+    H, W = int(20 + stride * (rows - 1)), int(20 + stride * (cols - 1))
+
+    def run():
+        mos = inference.ParcelMosaic(0.0, float(H), H, W, args, dev)
+        n = inference.predict_parcel(model, batches, mos, args, prefetch=prefetch)
+        return mos, n
+
+    run()                                                        # warm-up (allocator, lazy module load)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(repeat):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        mos, n = run()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+    med = sorted(times)[len(times) // 2]
+    cover = float((~torch.isnan(mos.result()[0])).float().mean())
+    by = 368 * points * n                                        # SURVEY.md 8d: compulsory forward bytes per point
+    out = {"workload": f"C4: {plots} plots x {points} pts, B={batch} per launch, reference defaults (ratios .25/.25, r sqrt2/sqrt8), "
+                       f"eval forward + rasters + ordered mosaic merge, geometry prefetch {prefetch}, inputs resident",
+           "seconds_per_parcel": round(med, 5), "plots_per_s": round(n / med, 1), "runs_s": [round(t, 5) for t in times],
+           "statistic": f"median of {repeat}", "parcel_pix": [H, W], "covered_frac": round(cover, 3), "dtype": "f32",
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(by / med / 1e9, 2),
+                        "frac": round(by / med / (HBM_PEAK_GBS * 1e9), 5), "compulsory_bytes": int(by),
+                        "what": "whole parcel: 368 B/point (SURVEY.md 8d forward figure) x points x plots over seconds_per_parcel"}}
+    # CPU baseline: the oracle's eval forward + fixed-grid rasters on the first plots of the same parcel
+    from oracle import network, projection
+    ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    torch.set_num_threads(ncores)
+    sd = network.init_state_dict(0)
+    ctimes = []
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.perf_counter()
+            cov, _, _ = network.forward(sd, sample["cloud"], sample["xyz"], args, training=False, use_kdtree=True)
+            covb = cov.view(cpu_sample_plots, points, 4)
+            for i in range(cpu_sample_plots):
+                projection.project_to_2d_rasters(sample["cloud"][i], covb[i].t(), args)
+            ctimes.append(time.perf_counter() - t0)
+            if it >= 1 and sum(ctimes[1:]) > 8.0:
+                break
+    ct = sum(ctimes[1:]) / len(ctimes[1:])
+    out["cpu_baseline"] = {"value": round(cpu_sample_plots / ct, 3), "unit": "plots/s", "cores": ncores, "kind": "port",
+                           "sample": f"{cpu_sample_plots} plots x {points} pts of the same parcel, oracle eval forward + rasters, mean of "
+                                     f"{len(ctimes) - 1} passes after 1 warm-up"}
+    del batches, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def dropin_eager_leg(dev, B, n_points, steps=10, warmup=3):
+    """The drop-in as a user of the reference would run it: the loop of /root/reference/learning/train.py:46-66 -- CPU-resident
+    batches as the DataLoader collates them, `model(cloud_data)` (which uploads them), `project_to_plotwise_coverages`, the
+    three loss terms as plain torch ops, `loss.backward()`, `torch.optim.Adam.step()`, the three `.item()` reads -- eager, no
+    TrainPipeline, no hipGraph, no prefetch, random FPS starts (the reference's are unseeded too)."""
+    args = make_args(cuda=dev.index or 0, subsample_size=n_points, ratio1=M1 / n_points, r1=1.0, ratio2=0.25, r2=2.0)
+    torch.manual_seed(0)
+    model = PointNet2(args).train()
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)          # learning/train.py:182
+    batches = [make_batch(B, n_points, first_plot=j * B) for j in range(4)]               # host tensors
+    times = []
+    for it in range(warmup + steps):
+        d = batches[it % len(batches)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cloud_data = {"cloud": d["cloud"], "xyz": d["xyz"]}
+        clouds = cloud_data["cloud"]
+        gt = d["coverages"].cuda(dev)
+        optimizer.zero_grad(set_to_none=True)
+        cov, proba = model(cloud_data)
+        pred = project_to_plotwise_coverages(cov, clouds, args)
+        loss_abs = losses.get_absolute_loss(pred, gt)
+        loss_log = losses.get_NLL_loss(proba, d["pdf_all"].cuda(dev))     # the reference evaluates its KDE on the CPU and uploads
+        loss_e = losses.get_entropy_loss(proba)
+        loss = loss_abs + args.m * loss_log + args.e * loss_e
+        loss.backward()
+        optimizer.step()
+        _ = (loss_abs.item(), loss_log.item(), loss.item())
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[warmup:])[len(times[warmup:]) // 2]
+    del model, optimizer
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(t * 1e3, 3), "plots_per_s": round(B / t, 1), "statistic": f"median of {steps} steps after {warmup} warm-ups",
+            "what": f"learning/train.py:46-66 as written, {B} plots x {n_points} pts per step from HOST tensors (40 MB H2D per step), "
+                    "torch.optim.Adam, plain torch loss ops, eager launches, geometry and features back to back"}
+
+
 def main():
     global N_POINTS
     ap = argparse.ArgumentParser()
@@ -250,6 +514,9 @@ def main():
                          "matrix cores (SA levels and the dense layers over centroids), fp32 accumulate, fp32 everywhere else")
     ap.add_argument("--split-exchange", action="store_true",
                     help="one GPU: use the multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (BASELINE configs 2 (3sa-arch), 4, 5 and the eager drop-in loop) that a default "
+                         "single-GPU run of the metric's workload attaches under \"secondary\"")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -272,44 +539,15 @@ def main():
             torch.distributed.init_process_group(backend)
 
     B, N_POINTS = a.plots, a.points
-    args = workload_args(local_rank)
-    args.mma_dtype = "bf16" if a.dtype == "bf16" else "fp32"
-    torch.manual_seed(0)                       # identical initial weights on every rank
-    if a.arch == "3sa":
-        from stratanet2_vegetation_coverage_maps_amd.point_net2_3sa import PointNet2ThreeSA
-        args.ratio3, args.r3 = 0.25, 4.0
-        model = PointNet2ThreeSA(args).train()
-        model.set_mma_dtype(args.mma_dtype)
-    else:
-        model = PointNet2(args).train()
-    n_fps = 3 if a.arch == "3sa" else 2
-    flatten_parameters(model)
-    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
-    # depth+1 resident batches (the pipeline's slots); batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
+    # depth+1 resident batches (the pipeline's slots)
     n_slots = 1 if a.serial else (a.depth + 1 if a.no_pair else 2 * a.depth + 2)
-    slots = []
-    for j in range(n_slots):
-        host = make_batch(B, N_POINTS, first_plot=j * world * B + shard_of_rank(rank, B)[0])
-        slots.append({"cloud": host["cloud"].to(dev), "xyz": host["xyz"].to(dev),
-                      "fps_start": torch.zeros(n_fps, B, dtype=torch.int32, device=dev),
-                      "gt": host["coverages"].to(dev), "pdf": host["pdf_all"].to(dev)})
+    w = build_training(dev, local_rank, rank, world, B, N_POINTS, a.arch, a.dtype, n_slots)
+    args, model, opt, slots, feature_step = w.args, w.model, w.opt, w.slots, w.feature_step
     data = slots[0]
 
     if hasattr(model, "geometry_fork"):
         model.geometry_fork = False      # eager steps are timed per entry point (HIP events): one stream; the captured
                                          # unpipelined step forks (capture_serial)
-
-    def feature_step(inp, geo=None):
-        """zero_grad -> forward -> plot-wise projection -> loss -> backward (everything but exchange + Adam)"""
-        opt.zero_grad(set_to_none=True)
-        cd = {"cloud": inp["cloud"], "xyz": inp["xyz"], "fps_start": inp["fps_start"]}
-        if geo is not None:
-            cd["geometry"] = geo
-        cov, proba = model(cd)
-        pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
-        loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
-        loss.backward()
-        return loss
 
     def step():
         """the unpipelined step on slot 0: geometry, features, exchange, Adam back to back on the current stream"""
@@ -478,11 +716,7 @@ def main():
                     "timing": ("HIP events inside the timed region" if mode == "serial/eager" else
                                "HIP events over 5 unpipelined eager steps right after the timed region"), "note": note}
         # ---- the whole step against both roofs: compulsory HBM bytes and dense-layer flops of ONE step
-        E1p, E2p = e1 / B, e2 / B                                                    # messages per plot
-        fwd_flops = 864 * E1p + 1216 * E2p + 4480 * m2 + 12288 * m2 + 5440 * m1 + 2856 * N_POINTS + 1248 * N_POINTS
-        step_flops = B * (3 * fwd_flops - 352 * E1p)
-        fwd_bytes = 368 * N_POINTS + 8 * (E1p + E2p) + 16 * (m1 + m2) + 8 * (16 * m1 + 32 * m2 + 64 + 64 * m2 + 34 * m1) + 48 * m1 + 16 * m2
-        step_bytes = B * 2.2 * fwd_bytes
+        step_bytes, step_flops = step_model_figures(B, N_POINTS, m1, m2, e1, e2)
         MFMA_PEAK = {"f32": 157.3e12, "bf16": 2.5e15}[a.dtype]
         whole_step = {"compulsory_bytes": int(step_bytes), "hbm_frac": round(step_bytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
                       "dense_flops": int(step_flops), "mfma_frac": round(step_flops / (ms * 1e-3) / MFMA_PEAK, 4),
@@ -504,7 +738,9 @@ def main():
                                        ("ref-arch" if a.arch == "ref" else "3sa-arch (not in the reference: throughput only)")) +
                                       f": {B} plots/GPU x {N_POINTS} pts, SA npoint " +
                                       ("1024/256 + global, r 1/2 m, " if a.arch == "ref" else "1024/256/64 + global, r 1/2/4 m, ") +
-                                      "train step fwd+P2+loss+bwd+Adam, inputs resident in HBM" +
+                                      "train step fwd+P2+loss+bwd+Adam, " +
+                                      ("inputs resident in HBM" if not a.host_inputs else
+                                       "EVERY batch copied from pinned host memory inside the timed region (not the metric's convention)") +
                                       (", bf16 operands on the matrix cores (SA levels, SA3/FP3/FP2), fp32 accumulate" if a.dtype == "bf16" else ""),
                           "mode": mode + ("" if a.serial else
                                           ": every step runs one feature pass (this batch); the position-only kernels (FPS, "
@@ -513,7 +749,8 @@ def main():
                                           "; distinct batches in the slots"),
                           "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
-               "loss": round(loss_value, 6), "roofline": roof, "kernels": kernels}
+               "loss": round(loss_value, 6), "roofline": roof, "kernels": kernels,
+               "host_cores_of_this_rank": os.environ.get("SN2_BENCH_PINNED", f"all:{len(os.sched_getaffinity(0))}")}
         if roof is not None:
             roof["whole_step"] = whole_step
         if roof_geo is not None:
@@ -529,6 +766,28 @@ def main():
             out["unpipelined"] = {"ms_per_step": round(serial_ms, 4), "plots_per_s": round(B / (serial_ms * 1e-3), 2),
                                   "what": "the same step with geometry and features of ONE batch back to back on one "
                                           "stream, captured as one hipGraph (single-batch latency; not the headline value)"}
+        default_workload = (B, N_POINTS, a.arch, a.dtype) == (PLOTS_PER_GPU, 32768, "ref", "f32") and not (a.serial or a.eager or a.host_inputs)
+        if world == 1 and default_workload and not a.no_secondary:
+            # ---- the other configurations BASELINE.json names, driver-timed in the same run (compact legs; never `value`)
+            pipe = graph = None                         # the headline's pipeline, graphs and resident batches are done with
+            slots.clear()
+            torch.cuda.empty_cache()
+            sec = {}
+            legs = (("config2_3sa_arch", lambda: secondary_train_leg(dev, "3sa", 16, 32768, "f32", 100, 10)),
+                    ("config5_128k_f32", lambda: secondary_train_leg(dev, "ref", 8, 131072, "f32", 50, 6)),
+                    ("config5_128k_bf16", lambda: secondary_train_leg(dev, "ref", 8, 131072, "bf16", 50, 6)),
+                    ("config4_parcel_inference", lambda: inference_leg(dev)),
+                    ("dropin_eager", lambda: dropin_eager_leg(dev, 16, 32768)))
+            for name, fn in legs:
+                log(f"secondary leg: {name}")
+                try:
+                    sec[name] = fn()
+                    log(f"  {name}: " + json.dumps({k: v for k, v in sec[name].items() if k in ('ms_per_step', 'plots_per_s', 'seconds_per_parcel')}))
+                except Exception as exc:                     # noqa: BLE001  (a failed leg must not lose the headline line)
+                    sec[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    log(f"  {name} FAILED: {sec[name]['error']}")
+                    torch.cuda.synchronize()
+            out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()

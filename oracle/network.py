@@ -83,6 +83,23 @@ class _LinearBF16(torch.autograd.Function):
 
 
 BF16_LAYERS = ()      # prefixes of the blocks evaluated with bf16 operands (set through `forward(..., bf16_layers=)`)
+BN_STATS_F64 = False  # training-mode BatchNorm: batch mean / variance summed in fp64, everything else in the input's dtype
+                      # (set through `forward(..., bn_stats_f64=True)`; isolates torch's fp32 batch-statistics error)
+
+
+def _batch_norm_f64_stats(x, rm, rv, gamma, beta, momentum=0.1, eps=1e-5):
+    """torch BatchNorm1d in training mode (biased variance to normalise, unbiased into running_var) with ONLY the two
+    batch statistics evaluated in fp64: mean and variance are summed in double and rounded to x's dtype once, the
+    normalisation, the affine and every gradient stay in x's dtype."""
+    xd = x.double()
+    mean = xd.mean(0)
+    var = (xd - mean).pow(2).mean(0)
+    n = x.shape[0]
+    with torch.no_grad():
+        rm.mul_(1 - momentum).add_(momentum * mean.to(rm.dtype))
+        rv.mul_(1 - momentum).add_(momentum * (var * (n / max(n - 1, 1))).to(rv.dtype))
+    invstd = (var + eps).rsqrt().to(x.dtype)
+    return (x - mean.to(x.dtype)) * invstd * gamma + beta
 
 
 def _mlp(x, sd, prefix, n_blocks, training, new_stats):
@@ -95,8 +112,11 @@ def _mlp(x, sd, prefix, n_blocks, training, new_stats):
         x = F.relu(x)
         rm = sd[f"{prefix}.{i}.2.running_mean"].clone()
         rv = sd[f"{prefix}.{i}.2.running_var"].clone()
-        x = F.batch_norm(x, rm, rv, sd[f"{prefix}.{i}.2.weight"], sd[f"{prefix}.{i}.2.bias"],
-                         training=training, momentum=0.1, eps=1e-5)
+        if BN_STATS_F64 and training:
+            x = _batch_norm_f64_stats(x, rm, rv, sd[f"{prefix}.{i}.2.weight"], sd[f"{prefix}.{i}.2.bias"])
+        else:
+            x = F.batch_norm(x, rm, rv, sd[f"{prefix}.{i}.2.weight"], sd[f"{prefix}.{i}.2.bias"],
+                             training=training, momentum=0.1, eps=1e-5)
         if new_stats is not None:
             new_stats[f"{prefix}.{i}.2.running_mean"] = rm
             new_stats[f"{prefix}.{i}.2.running_var"] = rv
@@ -111,15 +131,16 @@ def _fps_regular(pos_long, B, n, ratio, start):
 
 def forward(sd: Dict[str, torch.Tensor], cloud: torch.Tensor, xyz: torch.Tensor, args, training: bool,
             fps_start: Optional[Sequence[torch.Tensor]] = None, use_kdtree: bool = False, details: bool = False,
-            dropout_mask: Optional[torch.Tensor] = None, bf16_layers: Sequence[str] = ()):
+            dropout_mask: Optional[torch.Tensor] = None, bf16_layers: Sequence[str] = (), bn_stats_f64: bool = False):
     """cloud (B,10,N), xyz (B,3,N) fp32 CPU tensors (the DataLoader collate of `loader.py:73-87`).
     fps_start = (start1 (B,), start2 (B,)) LOCAL start indices of the two FPS calls (None -> 0).
     dropout_mask (B*N,16), non-zero = keep: the mask F.dropout (point_net2.py:142) would have drawn (None: torch draws).
     bf16_layers: prefixes of the (Linear, ReLU, BN) stacks whose Linear layers take bfloat16 operands (`_LinearBF16`).
+    bn_stats_f64: training-mode BatchNorm statistics summed in fp64, everything else in `cloud`'s dtype (`BN_STATS_F64`).
     Returns (coverages_pointwise (B*N,4), proba_pointwise (B*N,4), extras) where extras holds the new BN
     running statistics (training) and, with details=True, the intermediate tensors."""
-    global BF16_LAYERS
-    BF16_LAYERS = tuple(bf16_layers)
+    global BF16_LAYERS, BN_STATS_F64
+    BF16_LAYERS, BN_STATS_F64 = tuple(bf16_layers), bool(bn_stats_f64)
     B, _, N = cloud.shape
     # long form (B*N, f), plot-major (point_net2.py:155-158), drop normalised x,y (:118)
     pos0 = xyz.permute(0, 2, 1).reshape(B * N, 3).contiguous()
@@ -217,9 +238,9 @@ def init_state_dict_3sa(seed: int = 0):
     return sd
 
 
-def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False, bf16_layers=()):
-    global BF16_LAYERS
-    BF16_LAYERS = tuple(bf16_layers)
+def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False, bf16_layers=(), bn_stats_f64=False):
+    global BF16_LAYERS, BN_STATS_F64
+    BF16_LAYERS, BN_STATS_F64 = tuple(bf16_layers), bool(bn_stats_f64)
     B, _, N = cloud.shape
     pos0 = xyz.permute(0, 2, 1).reshape(B * N, 3).contiguous()
     x0 = cloud.permute(0, 2, 1).reshape(B * N, -1)[:, 2:].contiguous()

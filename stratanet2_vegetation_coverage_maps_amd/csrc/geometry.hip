@@ -225,6 +225,7 @@ __global__ __launch_bounds__(NT) void spatial_order_kernel(const float* __restri
             gb[ORDER_CELLS] = N;
             float* gf = reinterpret_cast<float*>(gb + ORDER_CELLS + 1);
             gf[0] = lo[0]; gf[1] = lo[1]; gf[2] = lo[2]; gf[3] = sc[0]; gf[4] = sc[1]; gf[5] = sc[2];
+            gb[GRID_WORDS - 1] = 0;   // the pad word: nobody reads it, but a workspace handed on is defined in every word
         }
     }
     __syncthreads();

@@ -472,6 +472,10 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     else:
         d.skip, d.skip_stride = None, 0
     block.fill(d.blk, with_grads)
+    if R > 64 * _lib.STAT_SLOTS:
+        # bfloat16 operands exist on the matrix-core kernels of the layers over centroids (<= 64 * SN2_STAT_SLOTS rows);
+        # a block with more rows (FP2 at the reference's default ratio1 = 0.5: 262 144 rows) runs its fp32 row kernels
+        d.blk.mma_bf16 = 0
     d.h, d.h_stride = _ptr(h), hs
     if dy is not None:
         _chk(dy, F32, (R, hs), "dy")

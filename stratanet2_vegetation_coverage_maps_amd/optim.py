@@ -37,16 +37,21 @@ def broadcast_bn_buffers(model, world_size: int, src: int = 0, group=None) -> in
     cnts = [b for n, b in model.named_buffers() if n.endswith("num_batches_tracked")]
     if world_size <= 1 or not bufs:
         return 0
-    flat = torch.cat([b.reshape(-1).float() for b in bufs] + [c.reshape(-1).float() for c in cnts])
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
     torch.distributed.broadcast(flat, src=src, group=group)
     o = 0
     for b in bufs:
         b.copy_(flat[o:o + b.numel()].view_as(b))
         o += b.numel()
-    for c in cnts:
-        c.copy_(flat[o:o + 1].view_as(c).to(c.dtype))
-        o += 1
-    return int(flat.numel())
+    n = int(flat.numel())
+    if cnts:
+        # the int64 `num_batches_tracked` counters travel as int64 (a float32 carries integers only up to 2^24)
+        ic = torch.stack([c.reshape(()).to(torch.int64) for c in cnts])
+        torch.distributed.broadcast(ic, src=src, group=group)
+        for c, v in zip(cnts, ic):
+            c.copy_(v.to(c.dtype))
+        n += int(ic.numel())
+    return n
 
 
 def flatten_parameters(model) -> torch.Tensor:
@@ -75,6 +80,23 @@ class FlatAdam:
         self.step_dev = self.step_words[:1]
         self.world_size = world_size
         self.process_group = process_group
+
+    def reset(self):
+        """Forget the optimiser state: moments, step count AND the Adam kernel's arrival ticket (`step_words[1]`: the last
+        workgroup of a launch advances `step_words[0]` and zeroes the ticket; a ticket left non-zero -- state restored by
+        hand, a launch that was aborted -- would keep the count from ever advancing again)."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_words.zero_()
+
+    def state_dict(self):
+        """What to save: the moments and the step count (`step_words[0]`; the ticket word is not state)."""
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": int(self.step_words[0].item())}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_words.copy_(torch.tensor([int(sd["step"]), 0], dtype=torch.int32))   # ticket zeroed whatever it was
 
     def zero_grad(self, set_to_none=True):
         for p in self.model.parameters():

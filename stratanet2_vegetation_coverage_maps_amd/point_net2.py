@@ -168,7 +168,9 @@ class PointNet2(nn.Module):
         """"fp32" (default: exact fp32 products, the reference's precision) or "bf16": the dense contractions of
         `BF16_BLOCKS` -- forward, input gradient, weight gradient -- take bfloat16 operands on v_mfma_f32_16x16x32_bf16 /
         16x16x16 with fp32 accumulation; ReLU, BatchNorm, statistics, every arg-max and all position-only kernels stay
-        fp32, so the index structures are the same bits in both modes."""
+        fp32, so the index structures are the same bits in both modes.  A dense block with more than 64 * SN2_STAT_SLOTS
+        (65 536) rows -- FP2 at the reference's default ratio1 = 0.5 on 32 768-point plots -- has no bfloat16 kernel and
+        runs in fp32 (`hip_ops.fp_desc`)."""
         if dtype not in ("fp32", "bf16"):
             raise ValueError("mma_dtype must be 'fp32' or 'bf16'")
         self.mma_dtype = dtype

@@ -156,9 +156,11 @@ class PointNet2ThreeSA(PointNet2):
         g.ready = None
         return g
 
-    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False):
-        """As `PointNet2._geometry` with the third ball-query level; one stream (`fork` is accepted and ignored), `shared` =
-        the level-1 FPS with `fps_waves_shared` waves per plot."""
+    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False, inverted=True):
+        """As `PointNet2._geometry` with the third ball-query level; one stream (`fork` / `defer_join` are accepted and
+        ignored: nothing is forked, so there is nothing to join), `shared` = the level-1 FPS with `fps_waves_shared` waves
+        per plot, `inverted=False` = skip the inverted 3-NN tables (an eval-mode forward never gathers through them;
+        `g.has_inverted` records it and a later training-mode forward builds them)."""
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2, M3 = self._sizes3(N)
@@ -181,11 +183,19 @@ class PointNet2ThreeSA(PointNet2):
         ops.three_nn(g.pos3_soa, g.pos2_soa, 3, out=g.knn3, ws=g.nn_ws[0])
         ops.three_nn(g.pos2_soa, g.pos1_soa, 3, out=g.knn2, ws=g.nn_ws[1])
         ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[2])
+        if inverted:
+            self._inverted_tables(g)
+        g.has_inverted = bool(inverted)
+        g._join = None
+        return g
+
+    @staticmethod
+    def _inverted_tables(g):
+        B, N, M1, M2, M3 = g.B, g.N, g.M1, g.M2, g.M3
         ops.interp_index(g.knn4, B, M3, 1, out=g.inv4)
         ops.interp_index(g.knn3, B, M2, M3, out=g.inv3)
         ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
         ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
-        return g
 
     def _stage_positions(self, cloud_data, dev):
         xyz_d = cloud_data["xyz"].to(device=dev, dtype=F32, non_blocking=True).contiguous()
@@ -205,11 +215,16 @@ class PointNet2ThreeSA(PointNet2):
         B, _, N = xyz.shape
         M1, M2, M3 = self._sizes3(N)
         if geo is None:
-            geo = self._geometry(xyz, fps_start)
+            geo = self._geometry(xyz, fps_start, inverted=training)
         elif (geo.B, geo.N, geo.M1, geo.M2, geo.M3) != (B, N, M1, M2, M3):
             raise ValueError("prefetched geometry does not match this batch")
+        if training and not getattr(geo, "has_inverted", True):
+            # tables prefetched in eval mode, forward in training mode: the backward pass needs the inverted indices
+            self._inverted_tables(geo)
+            geo.has_inverted = True
         s = _Saved()
-        s.__dict__.update({k: v for k, v in geo.__dict__.items() if k not in ("ready", "stream", "totals", "nn_ws", "fps_start")})
+        s.__dict__.update({k: v for k, v in geo.__dict__.items()
+                           if k not in ("ready", "stream", "totals", "nn_ws", "fps_start", "_join", "has_inverted")})
         s.xyz = xyz
         widths = [16, 16, 32, 64, 64, 64, 64, 34, 34]
         aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)

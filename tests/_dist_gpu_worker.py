@@ -41,13 +41,13 @@ def rank_main(rank, world, port, backend, q):
         scale = allreduce_flat_grad(g, world)                            # the ONE exchange of the data-parallel path
         mean = torch.stack(singles).mean(0)
         err = float(((g * scale) - mean).abs().max() / mean.abs().max())
-        opt.step()                                                       # all-reduces again (sum of sums) -- use a fresh grad
-        g2 = shard_grad(rank)
-        opt.step()
+        for _ in range(2):                                               # two exchanged steps on fresh gradients
+            shard_grad(rank)                                             # (opt.step() does the exchange itself)
+            opt.step()
         params = model._flat_params.clone()
         gathered = [torch.empty_like(params) for _ in range(world)]
         dist.all_gather(gathered, params)
-        drift = float((gathered[0] - gathered[1]).abs().max())
+        drift = max(float((gathered[0] - t).abs().max()) for t in gathered[1:])
         q.put((rank, "ok", err, drift, int(g.numel())))
         dist.destroy_process_group()
     except Exception as exc:                                             # noqa: BLE001

@@ -36,8 +36,8 @@ def _worker(rank, world, port, out):
     try:
         from stratanet2_vegetation_coverage_maps_amd.optim import allreduce_flat_grad, shard_of_rank
         from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args
-        torch.set_num_threads(2)
-        N, per_rank = 512, 2
+        torch.set_num_threads(2 if world <= 2 else 1)
+        N, per_rank = (512, 2) if world <= 2 else (256, 1)
         args = make_args(subsample_size=N, ratio1=0.125, r1=1.5, ratio2=0.25, r2=3.0)
         assert shard_of_rank(rank, per_rank) == (rank * per_rank, per_rank)
         g = _shard_grad(rank, per_rank, N, args)
@@ -48,20 +48,26 @@ def _worker(rank, world, port, out):
         # the optional second exchange: rank 0's BatchNorm running statistics to everyone (520 floats + 7 counters)
         from stratanet2_vegetation_coverage_maps_amd.optim import broadcast_bn_buffers
         bnm = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.BatchNorm1d(8), torch.nn.BatchNorm1d(8))
+        big = 2 ** 24 + 1                                           # not representable in float32: the counters travel as int64
         with torch.no_grad():
-            for b in bnm.buffers():
-                b.fill_(float(rank + 1))
+            for name, b in bnm.named_buffers():
+                b.fill_(big + rank if name.endswith("num_batches_tracked") else float(rank + 1))
         n = broadcast_bn_buffers(bnm, world)
         assert n == 2 * 16 + 2
-        assert all(float(b.float().mean()) == 1.0 for b in bnm.buffers())
+        for name, b in bnm.named_buffers():
+            if name.endswith("num_batches_tracked"):
+                assert b.dtype == torch.int64 and int(b) == big
+            else:
+                assert float(b.mean()) == 1.0
         out[rank] = 1
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_gloo_allreduce_of_flat_gradient():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_gloo_allreduce_of_flat_gradient(world):
+    """world 2, and the node's size 8 (tiny shards: the exchange and sharding code is what runs, 8 processes of 1 thread)."""
     port = 29500 + (os.getpid() % 2000)
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    assert dict(out) == {0: 1, 1: 1}
+    assert dict(out) == {r: 1 for r in range(world)}

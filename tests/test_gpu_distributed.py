@@ -17,12 +17,15 @@ def _ctx():
     return mp.get_context("forkserver")          # started clean in conftest.pytest_configure
 
 
-def test_allreduced_gradient_is_the_mean_of_the_shard_gradients():
+@pytest.mark.parametrize("world", [2, 4])
+def test_allreduced_gradient_is_the_mean_of_the_shard_gradients(world):
+    """world 4 = as many ranks as one card may carry beside the pytest process (the box allows six GPU processes): the
+    rank arithmetic beyond two (shards, scale 1/world, replicas in step) with the HIP backward."""
     from _dist_gpu_worker import rank_main
     ctx = _ctx()
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 1000
-    procs = [ctx.Process(target=rank_main, args=(r, 2, port, "gloo", q)) for r in range(2)]
+    port = 29600 + os.getpid() % 1000 + world
+    procs = [ctx.Process(target=rank_main, args=(r, world, port, "gloo", q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in procs)

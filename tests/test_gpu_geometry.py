@@ -50,6 +50,20 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
     assert torch.equal(i_8, i_f) and torch.equal(cs_8, cs_f)
     i_1, cs_1, _ = ops.fps(dev, M, start.to(DEV, torch.int32), waves=1)       # one sample per arg-max round (round 1's kernel)
     assert torch.equal(i_1, i_f) and torch.equal(cs_1, cs_f)
+    # the workspace is written in EVERY word (round 2 saw the pad word of the last plot's cell table keep the allocation's
+    # old contents: no kernel reads it, but a buffer handed to other kernels should not hold undefined words): pre-fill two
+    # buffers with different patterns -- whatever the kernel leaves untouched differs between them.  The order of duplicated
+    # points inside a cell and the running distances depend on LDS atomics / the wave count, so compare the cell table and the
+    # multiset of sorted positions, and require that no word kept its fill pattern.
+    def _filled(pattern, waves):
+        w = torch.full((ops.fps_ws_words(B, N),), pattern, dtype=torch.int32, device=DEV)
+        out = (torch.empty(B, M, dtype=torch.int32, device=DEV), torch.empty(B, 3, M, device=DEV), torch.empty(B * M, 4, device=DEV), w)
+        ops.fps(dev, M, start.to(DEV, torch.int32), out=out, waves=waves)
+        return w
+    wa, wb = _filled(0x01010101, 8), _filled(0x7E7E7E7E, 16)
+    assert int((wa == 0x01010101).sum()) == 0 and int((wb == 0x7E7E7E7E).sum()) == 0
+    assert torch.equal(wa[5 * B * N:], wb[5 * B * N:])                                  # cell starts, bounding boxes, pad words
+    assert torch.equal(wa[:B * N].view(B, N).sort(1).values, wb[:B * N].view(B, N).sort(1).values)    # a permutation of 0..N-1
     nbr8, cnt8, _ = ops.ball_query(dev, cs_8, 1.0, 64, fps_ws=ws8)
     nbr_f, cnt_f, _ = ops.ball_query(dev, cs_f, 1.0, 64)
     assert torch.equal(cnt8, cnt_f)

@@ -19,15 +19,17 @@ TOL = 1e-4
 B, N = 16, 32768
 
 
-def _oracle(arch, sd, d, args, fs, dtype):
+def _oracle(arch, sd, d, args, fs, dtype, bn_stats_f64=False):
     s = {k: (v.to(dtype) if v.is_floating_point() else v).clone() for k, v in sd.items()}
     for k in network.param_keys(s):
         s[k].requires_grad_(True)
     cloud = d["cloud"].to(dtype)
     if arch == "3sa":
-        cov, proba, _ = network.forward_3sa(s, cloud, d["xyz"], args, training=True, fps_start=fs, use_kdtree=True)
+        cov, proba, _ = network.forward_3sa(s, cloud, d["xyz"], args, training=True, fps_start=fs, use_kdtree=True,
+                                            bn_stats_f64=bn_stats_f64)
     else:
-        cov, proba, _ = network.forward(s, cloud, d["xyz"], args, training=True, fps_start=(fs[0], fs[1]), use_kdtree=True)
+        cov, proba, _ = network.forward(s, cloud, d["xyz"], args, training=True, fps_start=(fs[0], fs[1]), use_kdtree=True,
+                                        bn_stats_f64=bn_stats_f64)
     pred = projection.project_to_plotwise_coverages(cov, d["cloud"], args)          # pixel ids from the fp32 cloud
     loss, _ = olosses.total_loss(pred, proba, d["coverages"], d["pdf_all"], args.m, args.e)
     loss.backward()
@@ -54,6 +56,11 @@ def test_metric_size_forward_loss_backward_vs_oracle(arch):
 
     s32, cov_r, proba_r, pred_r, loss_r = _oracle(arch, sd, d, args, fs, torch.float32)
     s64, cov_64, proba_64, pred_64, loss_64 = _oracle(arch, sd, d, args, fs, torch.float64)
+    # The contract's wording is "within 1e-4 fp32 of the reference CPU path".  The fp32 oracle with ONLY its BatchNorm batch
+    # statistics summed in fp64 (every product, ReLU, affine, max and interpolation still fp32) isolates the one thing
+    # DESIGN.md section 3 blames for the fp32 CPU path's own 1e-3 distance from the exact network: torch's fp32 sums over
+    # 4e5 rows.  If the attribution holds, the HIP outputs agree with THIS fp32 run to 1e-4 directly.
+    _, cov_s, proba_s, pred_s, loss_s = _oracle(arch, sd, d, args, fs, torch.float32, bn_stats_f64=True)
     # Forward 1e-4 (BASELINE.json north_star), gradients 1e-3 of each tensor's magnitude -- against the oracle evaluated
     # in fp64.  The fp32 oracle is printed beside it: at this size it sits up to 1e-3 (outputs) and 1e-1 (gradients) away
     # from the fp64 evaluation (oracle/check.py says why), so "within 1e-4 of the fp32 CPU path" is not a property any
@@ -66,6 +73,11 @@ def test_metric_size_forward_loss_backward_vs_oracle(arch):
         d_direct = np.abs(g - r32.double().numpy()).max()
         lines.append(f"{name:22s} |HIP - fp64 oracle| {e_hip:.2e}   |fp32 oracle - fp64 oracle| {e_ref:.2e}   |HIP - fp32 oracle| {d_direct:.2e}")
         if e_hip > TOL:
+            fails.append(lines[-1])
+    for name, got, rs in (("coverages_pointwise", cov, cov_s), ("proba_pointwise", proba, proba_s), ("pred_coverages", pred, pred_s)):
+        e = np.abs(got.detach().cpu().double().numpy() - rs.double().numpy()).max()
+        lines.append(f"{name:22s} |HIP - fp32 oracle with fp64 BatchNorm statistics| {e:.2e}  (tol {TOL:.0e})")
+        if e > TOL:
             fails.append(lines[-1])
     print(f"\n[{arch}-arch, {B} x {N}] forward:\n  " + "\n  ".join(lines))
     if abs(loss.item() - loss_64) > TOL:

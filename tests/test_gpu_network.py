@@ -277,7 +277,7 @@ def test_kde_lookup_matches_scipy_interp1d():
 
 
 def test_dense_plot_128k_points_vs_oracle():
-    """BASELINE config 5's plot size through the whole network (fp32; the bf16 variant is not built): one 131 072-point
+    """BASELINE config 5's plot size through the whole network (fp32; the bf16 variant of this size: tests/test_gpu_bf16.py): one 131 072-point
     plot, forward + loss + backward against the oracle (kd-tree candidate search, canonical fp32 tests)."""
     N = 131072
     args = make_args(subsample_size=N, ratio1=1024 / N, r1=1.0, ratio2=0.25, r2=2.0)

@@ -77,7 +77,7 @@ def test_pipeline_matches_plain_loop(use_graph, split, pair):
     # capture() warms each slot with feature passes that update the BN running statistics but not the weights; reset
     # the model/optimiser state so both loops start equal
     model2.load_state_dict(network.init_state_dict(5))
-    opt2.exp_avg.zero_(); opt2.exp_avg_sq.zero_(); opt2.step_dev.zero_()
+    opt2.reset()                                  # moments, step count and the Adam kernel's arrival ticket
     pipe.prime()
     got = []
     for i in range(steps):
@@ -91,6 +91,11 @@ def test_pipeline_matches_plain_loop(use_graph, split, pair):
     # parameters: a ReLU mask flip (see _assert_same_losses) lets the two trajectories drift: up to ~5e-4 on half of the
     # weights within nine steps; a missed or doubled update would show in the optimiser's step counter
     dp = np.abs(model2._flat_params.cpu().numpy() - ref_params.cpu().numpy())
+    drm = np.abs(model2.fp1_module.nn[0][2].running_mean.cpu().numpy() - ref_rm.cpu().numpy()).max()
+    # stated bounds = 4 x the largest value ever measured (parameters 5e-4, running mean 5.3e-4), far below what a real
+    # defect shows (a missed, doubled or misplaced update: 1e-2 and more); the measured values of this run are printed
+    print(f"\n[pipeline graph={use_graph} split={split} pair={pair}] max |d parameters| {dp.max():.2e} (bound 2e-3), "
+          f"max |d running mean| {drm:.2e} (bound 2e-3), max |d loss| {np.abs(np.array(got) - np.array(ref_losses)).max():.2e}")
     assert dp.max() < 2e-3, dp.max()
     assert int(opt2.step_dev.item()) == steps == int(opt.step_dev.item())
     np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(), ref_rm.cpu().numpy(), atol=2e-3)   # the same drift (seen: 5.3e-4); one update more or less: 1e-2
@@ -133,7 +138,7 @@ def test_pipeline_with_host_feeder_matches_plain_loop(pair):
         for k in ("cloud", "xyz", "gt", "pdf"):
             sl[k].zero_()
     model2.load_state_dict(network.init_state_dict(5))
-    opt2.exp_avg.zero_(); opt2.exp_avg_sq.zero_(); opt2.step_dev.zero_()
+    opt2.reset()                                  # moments, step count and the Adam kernel's arrival ticket
     pipe.issued = pipe.done = 0
     pipe.set_feeder(lambda i: host[i % n_host])
     issue = pipe.issue_geometry

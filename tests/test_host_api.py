@@ -71,24 +71,46 @@ def test_no_oracle_import_in_product():
             assert "import oracle" not in txt and "from oracle" not in txt, fn
 
 
+def _run_clean(cmd, env, timeout=120):
+    """Run a command and hand back (rc, stdout, stderr).  When this pytest process already holds the GPU (an unfiltered run
+    on a GPU box: the test_gpu_* modules come first) the child is started from the clean forkserver of conftest.py -- never a
+    fork + exec of a process that has initialised the GPU."""
+    import subprocess
+    import torch
+    if torch.cuda.is_initialized():
+        import multiprocessing as mp
+        from _dist_gpu_worker import run_command
+        ctx = mp.get_context("forkserver")
+        q = ctx.Queue()
+        p = ctx.Process(target=run_command, args=(cmd, env, q))
+        p.start()
+        rc, out, err = q.get(timeout=timeout)
+        p.join(30)
+        return rc, out, err
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env)
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout)
+    return r.returncode, r.stdout, r.stderr
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus N` without a launcher: N child processes, rank/world/rendezvous set as torch.distributed.run
     would; a failing rank makes the launcher exit non-zero.  (SN2_BENCH_LAUNCH_CHECK: the ranks only report and exit.)"""
     import json
-    import os
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env["SN2_BENCH_LAUNCH_CHECK"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2"], env=env,
-                       capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
-    got = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["RANK"])
+    rc, out, err = _run_clean([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2"],
+                              {"SN2_BENCH_LAUNCH_CHECK": "1"})
+    assert rc == 0, err
+    got = sorted((json.loads(l) for l in out.splitlines() if l.startswith("{")), key=lambda d: d["RANK"])
     assert [d["RANK"] for d in got] == ["0", "1", "2"] and all(d["WORLD_SIZE"] == "3" for d in got)
     assert all(d["LOCAL_RANK"] == d["RANK"] and d["MASTER_ADDR"] == "127.0.0.1" for d in got)
     assert len({d["MASTER_PORT"] for d in got}) == 1
-    env["SN2_BENCH_LAUNCH_CHECK"] = "fail"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
-                       text=True, timeout=120)
-    assert r.returncode == 3
+    # every rank gets its share of the host cores (SN2 launcher: OMP_NUM_THREADS and, where the cpuset allows, an affinity mask)
+    assert all(int(d["OMP_NUM_THREADS"]) >= 1 for d in got)
+    masks = [set(d["affinity"]) for d in got]
+    if all(d["affinity_pinned"] for d in got):
+        assert not (masks[0] & masks[1]) and not (masks[1] & masks[2])
+    rc, out, err = _run_clean([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                              {"SN2_BENCH_LAUNCH_CHECK": "fail"})
+    assert rc == 3
