@@ -587,7 +587,7 @@ def main():
         if fork is not None:
             model.geometry_fork = True
         try:
-            side = torch.cuda.Stream()
+            side = ops.shared_stream(dev, "capture")
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 step()                                   # allocator warm-up on the capture stream

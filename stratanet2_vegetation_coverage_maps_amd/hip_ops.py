@@ -68,6 +68,22 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_SHARED_STREAMS = {}      # (device index, name) -> stream
+
+
+def shared_stream(dev, name: str) -> torch.cuda.Stream:
+    """The process-wide side stream `name` of a device ("side0".."sideK": geometry passes of pipelined loops and prefetch
+    lanes; "fork_b", "fork_c", "pack": the branches of an unpipelined geometry pass; "capture").  Created ONCE: HIP deals
+    streams onto a few hardware queues round-robin as they are created, so a second pipeline (or model) that created its own
+    streams could find two of them -- or one and the main stream -- on one queue, where the passes it meant to overlap run
+    back to back (seen: +25 % per step for a pipeline built after another one in the same process)."""
+    dev = torch.device(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), name)
+    if key not in _SHARED_STREAMS:
+        _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SHARED_STREAMS[key]
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 

@@ -67,7 +67,7 @@ class TrainPipeline:
         # batches the geometry may run ahead of the feature passes (never into a slot whose feature pass is not launched yet)
         self.ahead = min(2 * depth, self.slots - 2) if self.pair else depth
         self.n_streams = n_streams or depth
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+        self.side = [ops.shared_stream(dev, f"side{j}") for j in range(self.n_streams)]     # one set per process: hip_ops.shared_stream
         self.geo_ready = [torch.cuda.Event() for _ in range(self.slots)]
         self.slot_done = [None] * self.slots
         self.graph_fb = [None] * self.slots       # zero_grad .. backward
@@ -160,7 +160,7 @@ class TrainPipeline:
         torch.cuda.synchronize(self.dev)
         if not self.use_graph:
             return
-        cap = torch.cuda.Stream(device=self.dev)
+        cap = ops.shared_stream(self.dev, "capture")
         cap.wait_stream(main)
         with torch.cuda.stream(cap):
             for k in range(self.slots):           # warm-up on the capture stream

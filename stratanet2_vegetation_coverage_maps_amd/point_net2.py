@@ -286,9 +286,7 @@ class PointNet2(nn.Module):
         ops.fps(xyz, M1, fps_start[0], out=(g.idx1, g.pos1_soa, g.pos1_aos, g.ws1),
                 waves=self.fps_waves_shared if shared else 0)
         if fork:
-            if getattr(self, "_fork_streams", None) is None or self._fork_streams[0].device != dev:
-                self._fork_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-            sb, sc = self._fork_streams
+            sb, sc = ops.shared_stream(dev, "fork_b"), ops.shared_stream(dev, "fork_c")
             sb.wait_stream(cur)
             sc.wait_stream(cur)
         else:
@@ -386,12 +384,8 @@ class PointNet2(nn.Module):
         if dev.type != "cuda":
             raise StrataHipError("prefetch_geometry needs a HIP device")
         with torch.cuda.device(dev):
-            if getattr(self, "_geo_streams", None) is None:
-                self._geo_streams = {}
-            if lane not in self._geo_streams:
-                self._geo_streams[lane] = torch.cuda.Stream(device=dev)
             xyz_d, fs = self._stage_positions(cloud_data, dev)
-            side = self._geo_streams[lane]
+            side = ops.shared_stream(dev, f"side{lane}")
             side.wait_stream(torch.cuda.current_stream())
             # staged on the current stream, read by kernels of the side stream long after this function has returned:
             # without this the allocator may hand the start indices' memory to the next forward while FPS level 2 still
@@ -432,13 +426,12 @@ class PointNet2(nn.Module):
             if self.geometry_fork:
                 # the row packing needs the inputs only: beside the level-1 FPS (16 workgroups) instead of behind it
                 rows0 = torch.empty(B * N, 12, dtype=F32, device=dev)
-                if getattr(self, "_pack_stream", None) is None or self._pack_stream.device != dev:
-                    self._pack_stream = torch.cuda.Stream(device=dev)
-                self._pack_stream.wait_stream(cur_stream)
-                with torch.cuda.stream(self._pack_stream):
+                pack_stream = ops.shared_stream(dev, "pack")
+                pack_stream.wait_stream(cur_stream)
+                with torch.cuda.stream(pack_stream):
                     ops.pack_rows(cloud, xyz, out=rows0)
                     packed = torch.cuda.Event()
-                    packed.record(self._pack_stream)
+                    packed.record(pack_stream)
             geo = self._geometry(xyz, fps_start, defer_join=True, inverted=training)
         elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
             raise ValueError("prefetched geometry does not match this batch")

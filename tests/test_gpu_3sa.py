@@ -117,7 +117,8 @@ def test_3sa_prefetched_geometry_and_parcel_loop():
     (cov2.sum() + proba2.sum()).backward()
     assert torch.equal(cov, cov2)
     for a, b in zip(g_pre, (p.grad for p in model.parameters())):
-        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+        # the backward adds its weight gradients with float atomics: two runs agree to ~1e-6 of a tensor's magnitude
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
     # the parcel loop with its default prefetch of 3 passes
     batches = []
     for s in range(3):

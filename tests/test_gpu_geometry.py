@@ -60,10 +60,11 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
         out = (torch.empty(B, M, dtype=torch.int32, device=DEV), torch.empty(B, 3, M, device=DEV), torch.empty(B * M, 4, device=DEV), w)
         ops.fps(dev, M, start.to(DEV, torch.int32), out=out, waves=waves)
         return w
-    wa, wb = _filled(0x01010101, 8), _filled(0x7E7E7E7E, 16)
-    assert int((wa == 0x01010101).sum()) == 0 and int((wb == 0x7E7E7E7E).sum()) == 0
-    assert torch.equal(wa[5 * B * N:], wb[5 * B * N:])                                  # cell starts, bounding boxes, pad words
-    assert torch.equal(wa[:B * N].view(B, N).sort(1).values, wb[:B * N].view(B, N).sort(1).values)    # a permutation of 0..N-1
+    if ops.fps_fills_ws(B, N, M):                     # (1 x 2049: no bucketed path, the workspace is not touched)
+        wa, wb = _filled(0x01010101, 8), _filled(0x7E7E7E7E, 16)
+        assert int((wa == 0x01010101).sum()) == 0 and int((wb == 0x7E7E7E7E).sum()) == 0
+        assert torch.equal(wa[5 * B * N:], wb[5 * B * N:])                                  # cell starts, bounding boxes, pad words
+        assert torch.equal(wa[:B * N].view(B, N).sort(1).values, wb[:B * N].view(B, N).sort(1).values)    # a permutation of 0..N-1
     nbr8, cnt8, _ = ops.ball_query(dev, cs_8, 1.0, 64, fps_ws=ws8)
     nbr_f, cnt_f, _ = ops.ball_query(dev, cs_f, 1.0, 64)
     assert torch.equal(cnt8, cnt_f)
