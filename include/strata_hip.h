@@ -71,16 +71,21 @@ int sn2_pack_rows(const float *cloud, const float *xyz, int B, int C, int N, flo
  * start (B) local start index per plot or NULL (= 0, i.e. random_start=False).
  * idx (B,M) local indices in selection order; cpos_soa (B,3,M) and cpos_aos (B*M,4) = the selected positions.
  * order_ws: workspace of SN2_FPS_WS_WORDS(B,N) int32 (16-byte aligned, no initialisation: B*N ints of spatial order,
- * B*N float4 of sorted points, B cell-grid headers) enabling the bucketed kernel (exact same result, several times
+ * B*N float4 of sorted points, B cell-grid headers of 4104 words, B exchange areas of 4096 words for the
+ * multi-workgroup kernel, 32 control words) enabling the bucketed kernel (exact same result, several times
  * faster at N = 32768), or NULL for the brute-force kernel.  After the call the workspace describes the sorted point
  * set and can be handed to sn2_ball_query over the same sources. */
-#define SN2_FPS_WS_WORDS(B, N) (5L * (B) * (N) + 4104L * (B))
+#define SN2_FPS_WS_WORDS(B, N) (5L * (B) * (N) + (4104L + 4096L) * (B) + 32L)
 int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
             float *cpos_aos, int *order_ws, void *stream);
-/* The same with a hint for the bucketed kernel: waves per plot, 16 (= 0, what sn2_fps uses: shortest pass when FPS runs
- * alone) or 8 (a 9 % longer pass that leaves half of each occupied CU to concurrent kernels: the setting of a pipelined
- * loop where the pass runs beside another batch's feature kernels); 1 = one sample per arg-max round (round 1's kernel,
- * kept for cross-checks and timing comparisons).  Same indices whichever runs. */
+/* The same with a choice of kernel for the bucketed path.  waves = 0 (what sn2_fps passes): the shortest pass -- the
+ * multi-workgroup kernel wherever the batch fits the chip (B * P workgroups resident at once), else one workgroup of 16 waves
+ * per plot.  16 / 8: one workgroup of 16 / 8 waves per plot (8: a 9 % longer pass that leaves half of each occupied CU to
+ * concurrent kernels: the setting of a pipelined loop where the pass runs beside another batch's feature kernels).
+ * 32 + P / 64 + P, P = 2, 4, 8: P workgroups of 16 / 8 waves per plot (each owns every P-th bucket of the plot's Morton order;
+ * one exchange of tagged 8-byte granules through L2 per super-round; falls back to 16 when B * P workgroups do not fit).
+ * 1: one sample per arg-max round (round 1's kernel, kept for cross-checks and timing comparisons).
+ * Same indices whichever runs. */
 int sn2_fps_waves(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
                   float *cpos_aos, int *order_ws, int waves, void *stream);
 

@@ -2,6 +2,7 @@
 import ctypes, subprocess, sys, os, time
 import torch
 sys.path.insert(0, ".")
+from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
 from stratanet2_vegetation_coverage_maps_amd.synthetic import make_batch
 csrc = "stratanet2_vegetation_coverage_maps_amd/csrc"
 so = "gpurun_out/libfps_dbg.so"
@@ -12,7 +13,7 @@ lib = ctypes.CDLL(so)
 B, N, M = 16, 32768, 1024
 xyz = make_batch(B, N)["xyz"].cuda()
 idx = torch.empty(B, M, dtype=torch.int32, device="cuda"); cs = torch.empty(B, 3, M, device="cuda"); ca = torch.empty(B * M, 4, device="cuda")
-ws = torch.empty(5 * B * N + 4104 * B, dtype=torch.int32, device="cuda")
+ws = torch.empty(ops.fps_ws_words(B, N), dtype=torch.int32, device="cuda")
 lib.sn2_fps_waves.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
 WAVES = 1 if os.environ.get("SN2_FPS_SPECULATE", "1") == "0" else 0
 def run():

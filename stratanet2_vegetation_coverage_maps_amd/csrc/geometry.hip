@@ -142,9 +142,14 @@ __device__ __forceinline__ unsigned morton_cell(unsigned cx, unsigned cy, unsign
 // grid header per plot (32-bit words): [0..4096] first sorted position of every Morton cell (+ end), then lo.xyz, scale.xyz
 constexpr int GRID_WORDS = ORDER_CELLS + 1 + 6 + 1;   // padded to an even count
 // NT threads per plot (1024: 0.10 ms at N = 32768; 256 threads measured 0.18 ms and changed nothing else).
+// exchange area of the multi-workgroup FPS (fps_cluster_kernel): per plot FPS_XCHG_WORDS words of tagged granules, then
+// FPS_CTL_WORDS control words per launch (ticket counter, timeout count).  Zeroed HERE, by the kernel in front of every FPS
+// launch (a kernel boundary: visible to every workgroup behind it; the tags count super-rounds from 1, so 0 = nothing yet).
+constexpr int FPS_XCHG_WORDS = 4096, FPS_CTL_WORDS = 32;
 template <int NT>
 __global__ __launch_bounds__(NT) void spatial_order_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
-                                                             float4* __restrict__ sorted, int* __restrict__ grid) {
+                                                             float4* __restrict__ sorted, int* __restrict__ grid,
+                                                             unsigned* __restrict__ xchg, unsigned* __restrict__ ctl) {
     __shared__ int s_hist[ORDER_CELLS];
     __shared__ float s_mm[6][NT / 64];
     __shared__ int s_wsum[NT / 64];
@@ -152,6 +157,10 @@ __global__ __launch_bounds__(NT) void spatial_order_kernel(const float* __restri
     const float* px = pos + (size_t)b * 3 * N;
     const float* py = px + N;
     const float* pz = py + N;
+    if (xchg) {
+        for (int i = tid; i < FPS_XCHG_WORDS; i += NT) xchg[(size_t)b * FPS_XCHG_WORDS + i] = 0u;
+        if (b == 0 && tid < FPS_CTL_WORDS) ctl[tid] = 0u;
+    }
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = tid; i < N; i += NT) {
         const float v[3] = {px[i], py[i], pz[i]};
@@ -871,7 +880,9 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
     float4* sorted = reinterpret_cast<float4*>(ws + (size_t)B * N);   // B*N float4 (16-byte aligned: B*N*4 bytes offset
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
     int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
-    hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid);
+    unsigned* xchg = reinterpret_cast<unsigned*>(grid + (size_t)B * GRID_WORDS);      // B*FPS_XCHG_WORDS + FPS_CTL_WORDS
+    hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg,
+                       xchg + (size_t)B * FPS_XCHG_WORDS);
     if (speculate) {
         constexpr int K = SN2_FPS_K;
         const size_t lds = fps_spec_lds_bytes<SPW, NW, K>();
@@ -886,13 +897,757 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
     SN2_RETURN_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Multi-workgroup speculative FPS (exact; round 3).  fps_spec_kernel keeps a whole plot in ONE workgroup: 16 plots use 16
+// of 256 CUs, and two thirds of a super-round are work that only scales with the buckets a workgroup owns -- the box tests
+// (A) and the dirty-bucket updates (B: VALU-issue bound on one CU's four SIMDs).  Here P workgroups share a plot:
+//   * bucket g (64 consecutive points of the Morton order) belongs to workgroup g % P -- interleaved, so the ~17 buckets a
+//     new sample dirties spread evenly over the P workgroups; each workgroup keeps (max, second max, arg-max point) of
+//     its NBL = ceil(buckets / P) buckets in LDS and runs phases (A) and (B) of fps_spec_kernel on them;
+//   * per super-round ONE exchange through L2: wave 0 of every workgroup publishes its TP = 8 largest bucket maxima (value,
+//     second max, point) and a bound on everything it did not publish as 8-byte {tag = super-round, value} granules
+//     (agent-scope relaxed stores = `global_store_dwordx2 sc1`, the data is its own flag: cdna_hip_programming.md
+//     Guideline 16, form R2), sweeps the granules of all P workgroups until every tag matches, and then runs the SAME
+//     selection on the SAME 8 P records as its peers: every workgroup derives the same accepted samples, no broadcast;
+//   * the local top-8 come from a THRESHOLD, not from reduction chains: tau = the value of the (accepted + 16)-th merged
+//     candidate of the previous super-round (running distances only ever shrink, so at most that many buckets of the whole
+//     plot can still reach tau); the buckets >= tau are compacted with two ballots and ranked among themselves (a dozen
+//     integer compares per lane).  Whatever tau is, the result is exact: a workgroup states `bound` = tau (all its other
+//     buckets are below) or its 8-th value (when more than 8 reach tau), a candidate is accepted only above every
+//     workgroup's bound, and a super-round that finds nothing above the bounds lowers tau and tries again (more than 64
+//     survivors: eight wave-max rounds instead of the ranking);
+//   * acceptance tests, exact-tie search (lowest ORIGINAL index, one more granule per workgroup) and emitted samples are
+//     those of fps_spec_kernel, bit for bit (tests/test_gpu_geometry.py holds all kernels to each other and to the oracle).
+// Residency: a workgroup waits only for the P-1 peers of its plot.  Plots are handed out by a ticket counter in arrival
+// order (not by blockIdx), so the peers of every resident workgroup are resident too or are the very next workgroups to
+// start -- no dispatch-order assumption; every spin is bounded (FC_SPIN_LIMIT sweeps, then the kernel gives up, counts the
+// timeout in the control words and exits: wrong samples, never a hang).
+// ------------------------------------------------------------------------------------------------------------
+typedef unsigned long long fc_u64;
+constexpr int FC_TP = 8;                     // records a workgroup publishes per super-round
+constexpr int FC_PARITY_U64 = 512;           // granules per parity (6 * 8P record fields + P bounds + P tie words <= 400)
+constexpr unsigned FC_SPIN_LIMIT = 1u << 21; // sweeps (~1 us each) before a wait gives up
+#ifndef SN2_FC_FLAG_SLEEP
+#define SN2_FC_FLAG_SLEEP 3
+#endif
+#ifndef SN2_FC_TAU_KEEP
+#define SN2_FC_TAU_KEEP 15                   // candidates beyond the accepted ones that stay above the next threshold
+#endif
+static_assert(2 * 2 * FC_PARITY_U64 * 2 == FPS_XCHG_WORDS, "exchange area: two copies x two parities");
+constexpr int FC_COPY_U64 = 2 * FC_PARITY_U64;      // copy 0: plain stores (same-XCD peers see them in their L2), copy 1: write-through
+
+#ifndef SN2_FC_DUAL
+#define SN2_FC_DUAL 0
+#endif
+constexpr bool FC_DUAL = SN2_FC_DUAL != 0;
+// (FC_DUAL, measured and switched off: see below) one granule goes out TWICE: a plain store into copy 0 (it stays in this XCD's L2, where a peer on the SAME XCD finds it with an
+// L1-bypassing load a few hundred clocks later) and a write-through `sc1` store into copy 1 (what a peer on ANOTHER XCD sees,
+// ~1000 clocks later).  A reader takes whichever copy carries the tag first: which one it is depends on placement, the value
+// does not -- both hold the same 8 bytes, each written by one store.
+__device__ __forceinline__ void fc_store(fc_u64* g, unsigned epoch, unsigned v) {
+    const fc_u64 x = ((fc_u64)epoch << 32) | (fc_u64)v;
+    if (FC_DUAL) __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(g + FC_COPY_U64, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// both copies of a granule -> the one that carries `epoch` (or one that does not: the caller checks the tag)
+__device__ __forceinline__ fc_u64 fc_pick(fc_u64 a, fc_u64 b, unsigned epoch) { return (FC_DUAL && (unsigned)(a >> 32) == epoch) ? a : b; }
+__device__ __forceinline__ fc_u64 fc_load(const fc_u64* g) {
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// max over lanes 0..7 (three DPP steps inside the first row), broadcast to the wave
+__device__ __forceinline__ float max_of_first8(float v) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+
+template <int SPW, int NW, int P, bool LP>
+__global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __restrict__ pos, int B, int N, int M,
+                                                           const int* __restrict__ start, const int* __restrict__ order,
+                                                           float4* sorted, int* __restrict__ idx_out,
+                                                           float* __restrict__ cpos_soa, float* __restrict__ cpos_aos,
+                                                           fc_u64* xchg_all, unsigned* ctl, int log_cap, int tau_keep) {
+    constexpr int NBL = SPW * NW;                      // buckets of this workgroup: local bucket lb = slot * NW + wave
+    constexpr int SL = (SPW + 63) / 64;                // bucket slots per lane of the owning wave
+    constexpr int VL = (NBL + 63) / 64;                // bucket values per lane of wave 0 in the selection
+    constexpr int K = 8, TP = FC_TP, NE = TP * P;      // accepted per super-round, records per workgroup, merged records
+    constexpr int SPWP = SPW < 64 ? SPW : 64;          // phase A: lane = (slot, sample): SPWP slots x KPL samples per pass
+    constexpr int KPL = 64 / SPWP < 8 ? 64 / SPWP : 8;
+    static_assert(NE <= 64 && P <= 8 && SPW <= 128 && NBL <= 2048 && NW <= 16 && 6 * NE + 2 * P <= FC_PARITY_U64, "limits");
+    static_assert((SPWP & (SPWP - 1)) == 0 && TP <= 15, "slots per wave: a power of two; the record count rides in 4 bits");
+    extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
+    float4* s_pt = reinterpret_cast<float4*>(fc_smem);             // [NBL] arg-max point of the bucket: x, y, z, sorted position
+    float4* s_acc = s_pt + NBL;                                    // [K] accepted samples of this super-round
+    float4* s_crA = s_acc + K;                                     // [NE + 16] merged records in order: (value, second max, position, -)
+    float4* s_crB = s_crA + NE + 16;                               // [NE + 16] ... (x, y, z, -)
+    float4* s_ownA = s_crB + NE + 16;                              // [TP] this workgroup's published records (not re-read from memory)
+    float4* s_ownB = s_ownA + TP;                                  // [TP]
+    float* s_box = reinterpret_cast<float*>(s_ownB + TP);          // [6][NBL] bucket boxes, [component][wave][slot]
+    float* s_val = s_box + 6 * NBL;                                // [NBL] largest running distance of the bucket (-1: empty)
+    float* s_max2 = s_val + NBL;                                   // [NBL] >= the second largest (== s_val: treated as a tie)
+    unsigned* s_q = reinterpret_cast<unsigned*>(s_max2 + NBL);     // [NBL] work queue: local bucket | samples << 11
+    int* s_keys = reinterpret_cast<int*>(s_q + NBL);               // [64 + 8] integer keys of a ranking (+ the pad of its last quad)
+    int* s_ctl = s_keys + 72;                                      // [0] accepted, [1] done, [2] tie value, [3] queue length,
+                                                                   // [4] mode (0 accept, 1 tie search, 2 lower tau, 3 gave up),
+                                                                   // [5] tie winner, [7] ticket
+    unsigned* s_win = reinterpret_cast<unsigned*>(s_ctl + 8);
+    float4* s_log = reinterpret_cast<float4*>(s_win + 4);          // [log_cap] every sample of the plot (x, y, z, -1 - position | index):
+                                                                   // written out once at the end (log_cap = 0: emitted as they come)
+    float4* s_pts = s_log + log_cap;                               // LP: [NBL * 64] this workgroup's points (x, y, z, running distance):
+                                                                   // the updates of phase B never leave the CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // which plot, which part: by XCD.  Plot c belongs to XCD c % 8; a workgroup takes the next free part of its XCD's plots (a
+    // per-XCD arrival counter), so the P workgroups of a plot share an L2 and exchange through it.  HIP promises nothing about
+    // placement: a workgroup whose XCD is full waits until all B * P have registered and takes the first hole left on another
+    // XCD (its exchange then runs through the write-through copy: slower, same result).  ctl: [0] overflow tickets,
+    // [1] timeouts, [16 + x] arrivals on XCD x.
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        const unsigned t = atomicAdd(&ctl[16 + xcc], 1u);
+        const unsigned mine = xcc < (unsigned)B ? ((unsigned)B - 1u - xcc) / 8u + 1u : 0u;     // plots of this XCD
+        int slot = -1;
+        if (t < mine * P) {
+            slot = (int)((xcc + 8u * (t / P)) * P + t % P);
+        } else {
+            unsigned o = atomicAdd(&ctl[0], 1u);
+            unsigned n[8];
+            for (unsigned spins = 0; spins < FC_SPIN_LIMIT; ++spins) {
+                unsigned sum = 0;
+                for (int x = 0; x < 8; ++x) {
+                    n[x] = __hip_atomic_load(&ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sum += n[x];
+                }
+                if (sum == (unsigned)(B * P)) {
+                    for (int c = 0; c < B && slot < 0; ++c) {
+                        const unsigned before = (unsigned)(c / 8) * P, nx = n[c & 7];
+                        const unsigned have = nx <= before ? 0u : (nx - before < (unsigned)P ? nx - before : (unsigned)P);
+                        if (o < (unsigned)P - have) slot = c * P + (int)(have + o);
+                        else o -= (unsigned)P - have;
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (slot < 0) atomicAdd(&ctl[1], 1u);
+        }
+        s_ctl[7] = slot;
+    }
+    __syncthreads();
+    const int ticket = s_ctl[7];
+    if (ticket < 0) return;
+    const int b = ticket / P, part = ticket - b * P;
+    const bool use_log = log_cap >= M;
+    const float* px = pos + (size_t)b * 3 * N;
+    const float* py = px + N;
+    const float* pz = py + N;
+    const int* ord = order + (size_t)b * N;
+    float4* pts = sorted + (size_t)b * N;              // (x, y, z, running distance = +inf from spatial_order_kernel)
+    fc_u64* xchg = xchg_all + (size_t)b * (2 * FC_COPY_U64);
+    float* my_box = s_box + wave * SPW;                // + component * NBL + slot
+    for (int k = 0; k < SPW; ++k) {
+        const int p = ((k * NW + wave) * P + part) * 64 + lane;       // sorted position: global bucket (k*NW + wave)*P + part
+        const bool v = p < N;
+        const float4 q = v ? pts[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (LP) s_pts[(k * NW + wave) * 64 + lane] = q;
+        const float lx = -wave_max_fused(v ? -q.x : -INFINITY), ly = -wave_max_fused(v ? -q.y : -INFINITY),
+                    lz = -wave_max_fused(v ? -q.z : -INFINITY);
+        const float hx = wave_max_fused(v ? q.x : -INFINITY), hy = wave_max_fused(v ? q.y : -INFINITY),
+                    hz = wave_max_fused(v ? q.z : -INFINITY);
+        if (lane == 0) {
+            my_box[0 * NBL + k] = lx; my_box[1 * NBL + k] = ly; my_box[2 * NBL + k] = lz;
+            my_box[3 * NBL + k] = hx; my_box[4 * NBL + k] = hy; my_box[5 * NBL + k] = hz;
+        }
+    }
+    for (int lb = tid; lb < NBL; lb += NW * 64) {
+        s_val[lb] = (lb * P + part) * 64 < N ? INFINITY : -1.f;     // every real bucket is dirty for the first sample
+        s_max2[lb] = -1.f;
+    }
+    int cur = start ? start[b] : 0;
+    cur = cur < 0 ? 0 : (cur >= N ? N - 1 : cur);
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    // the accepted samples of the current super-round: s_acc[0..j-1], and lanes 0..j-1 of (ax, ay, az) in EVERY wave
+    float ax = px[cur], ay = py[cur], az = pz[cur];
+    int j = 1, cnt = 1;
+    unsigned epoch = 0;
+    float tau = -1.f;                                  // wave 0's threshold for the next selection
+    int* out_idx = idx_out + (size_t)b * M;
+    // one sample of the plot: (x, y, z) and its code = -1 - sorted position (translated at the end) or the original index
+    auto emit = [&](int at, float x, float y, float z, int code) {
+        if (use_log) {
+            s_log[at] = make_float4(x, y, z, __int_as_float(code));
+        } else {
+            out_idx[at] = code;
+            cpos_soa[((size_t)b * 3 + 0) * M + at] = x;
+            cpos_soa[((size_t)b * 3 + 1) * M + at] = y;
+            cpos_soa[((size_t)b * 3 + 2) * M + at] = z;
+            reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M + at] = make_float4(x, y, z, 0.f);
+        }
+    };
+    if (tid == 0) {
+        if (part == 0) emit(0, ax, ay, az, cur);
+        s_acc[0] = make_float4(ax, ay, az, 0.f);
+        s_ctl[3] = 0;
+    }
+    if (M <= 1 && !use_log) return;
+    __syncthreads();
+    // phase A: lane = (slot asl, sample group akk), slot-major so that the hits of one slot are contiguous ballot bits
+    const int asl = lane / KPL, akk = lane & (KPL - 1);
+
+#ifdef SN2_FC_STAMPS
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned n_rounds = 0, n_acc = 0, n_fb = 0, n_m1 = 0, n_m2 = 0, n_surv = 0, n_spins = 0;
+#define FCSTAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define FCSTAMP(var)
+#endif
+    while (M > 1) {
+        ++epoch;
+        fc_u64* xg = xchg + (epoch & 1u) * FC_PARITY_U64;
+        FCSTAMP(t0);
+        // (A) which of this wave's buckets can change, and through which of the j samples?  lane = (slot, sample): every lane
+        // runs ONE box test per pass of KPL samples (a lane per slot ran j of them in sequence: 1100 clocks whatever SPW was)
+#pragma unroll
+        for (int h = 0; h < SL; ++h) {
+            const int sl = 64 * h + asl;
+            const bool slot_ok = asl < SPWP && sl < SPW;
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f, mx = -1.f;
+            if (slot_ok) {
+                b0 = my_box[0 * NBL + sl]; b1 = my_box[1 * NBL + sl]; b2 = my_box[2 * NBL + sl];
+                b3 = my_box[3 * NBL + sl]; b4 = my_box[4 * NBL + sl]; b5 = my_box[5 * NBL + sl];
+                mx = s_val[sl * NW + wave];
+            }
+            unsigned sm = 0u;
+            for (int k0 = 0; k0 < j; k0 += KPL) {
+                const int k = k0 + akk;
+                bool hit = false;
+                if (slot_ok && k < j) {
+                    const float4 sp = s_acc[k];
+                    hit = sn2_box_d2(b0, b1, b2, b3, b4, b5, sp.x, sp.y, sp.z) < mx;
+                }
+                const unsigned long long hb = __ballot(hit);
+                sm |= ((unsigned)(hb >> ((asl * KPL) & 63)) & ((1u << KPL) - 1u)) << k0;     // the KPL hits of this lane's slot
+            }
+            if (akk != 0 || !slot_ok) sm = 0u;           // one lane per slot pushes
+            const unsigned long long bal = __ballot(sm != 0u);
+            if (bal) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ctl[3], __popcll(bal));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (sm != 0u) s_q[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =
+                    (unsigned)(sl * NW + wave) | (sm << 11);
+            }
+        }
+        FCSTAMP(t1);
+        __syncthreads();
+        FCSTAMP(t2);
+        // (B) the queue, four entries per wave in flight (fps_spec_kernel's phase B on this workgroup's buckets)
+        const int qn = s_ctl[3];
+        constexpr int QD = 4;
+        for (int i0 = wave; i0 < qn; i0 += QD * NW) {
+            unsigned ent[QD];
+            int p[QD];
+            bool on[QD];
+            float4 q[QD];
+            float U[QD];
+#pragma unroll
+            for (int u = 0; u < QD; ++u) {
+                const int i = i0 + u * NW;
+                on[u] = i < qn;
+                ent[u] = s_q[on[u] ? i : 0];
+                const int lb = (int)(ent[u] & 2047u);
+                p[u] = (lb * P + part) * 64 + lane;
+                if constexpr (LP) q[u] = s_pts[lb * 64 + lane]; else q[u] = pts[p[u] < N ? p[u] : 0];
+                U[u] = s_val[lb];
+            }
+#pragma unroll
+            for (int u = 0; u < QD; ++u) {
+                if (!on[u]) continue;
+                const int lb = (int)(ent[u] & 2047u);
+                unsigned sm = ent[u] >> 11;
+                const float d0 = q[u].w;
+                float nd = d0;
+                while (sm) {
+                    const int k = __ffs(sm) - 1;
+                    sm &= sm - 1;
+                    const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax), k));
+                    const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay), k));
+                    const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az), k));
+                    nd = fminf(nd, sn2_d2(q[u].x, q[u].y, q[u].z, sx, sy, sz));
+                }
+                const bool real = p[u] < N;
+                const bool changed = real && nd < d0;
+                if (changed) {
+                    if constexpr (LP) reinterpret_cast<float*>(s_pts + lb * 64 + lane)[3] = nd; else fps_st_dist(pts, p[u], nd);
+                }
+                if (__ballot(changed) == 0ull) continue;
+                if (__ballot(changed && d0 == U[u]) == 0ull && U[u] != INFINITY) continue;
+                if (!real) nd = -1.f;                               // padding lanes of the last bucket never win
+                const float m1 = wave_max_fused(nd);
+                const unsigned long long bal = __ballot(nd == m1);
+                const int first = __ffsll((long long)bal) - 1;
+                float m2 = m1;
+                if (__popcll(bal) == 1) m2 = wave_max_fused(nd == m1 ? -1.f : nd);
+                const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[u].x), first));
+                const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[u].y), first));
+                const float fz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[u].z), first));
+                if (lane == 0) {
+                    s_val[lb] = m1;
+                    s_max2[lb] = m2;
+                    s_pt[lb] = make_float4(fx, fy, fz, __int_as_float((lb * P + part) * 64 + first));
+                }
+            }
+        }
+        FCSTAMP(t3);
+        __syncthreads();
+        FCSTAMP(t4);
+        // (C + D) wave 0: this workgroup's records, the exchange, the selection (identical in all P workgroups).  ONE wave issues
+        // an instruction every 4-5 clocks whatever its kind: this block is written for instruction count.
+        if (wave == 0) {
+            // one record leaves the workgroup: as granules for the peers and into LDS for ourselves
+            auto publish = [&](int r, float val, float m2, const float4& pt) {
+                fc_u64* rg = xg + part * TP + r;       // record (part, r), field f at xg[f * NE + part * TP + r]
+                fc_store(rg + 0 * NE, epoch, __float_as_uint(val));
+                fc_store(rg + 1 * NE, epoch, __float_as_uint(m2));
+                fc_store(rg + 2 * NE, epoch, __float_as_uint(pt.w));
+                fc_store(rg + 3 * NE, epoch, __float_as_uint(pt.x));
+                fc_store(rg + 4 * NE, epoch, __float_as_uint(pt.y));
+                fc_store(rg + 5 * NE, epoch, __float_as_uint(pt.z));
+                s_ownA[r] = make_float4(val, m2, pt.w, 0.f);
+                s_ownB[r] = make_float4(pt.x, pt.y, pt.z, 0.f);
+            };
+            float v[VL], m2v[VL];
+            float4 ptv[VL];
+            bool surv[VL];
+            unsigned long long bal[VL];
+            int n = 0;
+#pragma unroll
+            for (int h = 0; h < VL; ++h) {
+                const int lb = 64 * h + lane;
+                v[h] = lb < NBL ? s_val[lb] : -1.f;
+            }
+#pragma unroll
+            for (int h = 0; h < VL; ++h) {
+                surv[h] = v[h] >= tau && v[h] >= 0.f;
+                bal[h] = __ballot(surv[h]);
+                n += __popcll(bal[h]);
+                m2v[h] = -1.f;
+                ptv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (surv[h] && n <= 64) {              // what a published record carries (read now: off the ranking's path)
+                    m2v[h] = s_max2[64 * h + lane];
+                    ptv[h] = s_pt[64 * h + lane];
+                }
+            }
+            float bound = tau;                         // every bucket of this workgroup that is not published is below `bound`
+            int npub = n < TP ? n : TP;                // records this workgroup publishes (the peers ignore the rest of its area)
+            if (n <= 64) {
+                // the survivors ranked among themselves: integer keys = value bits with the low 6 bits replaced by the
+                // survivor's place (all keys differ), every survivor counts the keys above its own
+                int key[VL], rank[VL];
+                if (n > TP && lane < 4) s_keys[n + lane] = INT_MIN;
+                int base = 0;
+#pragma unroll
+                for (int h = 0; h < VL; ++h) {
+                    key[h] = INT_MAX;
+                    rank[h] = 0;
+                    if (surv[h]) {
+                        const int si = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal[h] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[h], 0u));
+                        key[h] = (__float_as_int(v[h]) & ~63) | (63 - si);
+                        rank[h] = si;                  // n <= TP: every survivor is published, in any order (the merge ranks them)
+                        if (n > TP) s_keys[si] = key[h];
+                    }
+                    base += __popcll(bal[h]);
+                }
+                if (n > TP) {
+#pragma unroll
+                    for (int h = 0; h < VL; ++h) rank[h] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                    for (int q4 = 0; q4 < (n + 3) / 4; ++q4) {
+                        const int4 k4 = reinterpret_cast<const int4*>(s_keys)[q4];
+#pragma unroll
+                        for (int h = 0; h < VL; ++h)
+                            rank[h] += (k4.x > key[h] ? 1 : 0) + (k4.y > key[h] ? 1 : 0) + (k4.z > key[h] ? 1 : 0) + (k4.w > key[h] ? 1 : 0);
+                    }
+                }
+                float b7 = -1.f;
+#pragma unroll
+                for (int h = 0; h < VL; ++h) {
+                    if (surv[h] && rank[h] < TP) publish(rank[h], v[h], m2v[h], ptv[h]);
+                    if (surv[h] && rank[h] == TP - 1) b7 = v[h];
+                }
+                if (n > TP) {                          // the unpublished survivors are <= the TP-th value
+                    const int l7 = __ffsll((long long)__ballot(b7 >= 0.f)) - 1;
+                    bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b7), l7));
+                }
+            } else {
+                // more than 64 buckets reach tau (the first super-rounds, or after tau was lowered): TP wave-max rounds
+                float pval = -1.f;
+                int plb = 0;
+                npub = 0;
+#pragma unroll 1
+                for (int t = 0; t < TP; ++t) {
+                    float lm = v[0];
+#pragma unroll
+                    for (int h = 1; h < VL; ++h) lm = fmaxf(lm, v[h]);
+                    const float m = wave_max_fused(lm);
+                    const int owner = __ffsll((long long)__ballot(lm == m)) - 1;
+                    int hh = VL - 1;
+#pragma unroll
+                    for (int h = VL - 2; h >= 0; --h) hh = v[h] == m ? h : hh;
+                    const int lbsel = __builtin_amdgcn_readlane(64 * hh + lane, owner);
+                    if (lane == owner) {
+#pragma unroll
+                        for (int h = 0; h < VL; ++h) if (h == hh) v[h] = -3.f;
+                    }
+                    if (lane == t) {
+                        pval = m;
+                        plb = lbsel;
+                    }
+                    if (m >= 0.f) {
+                        npub = t + 1;
+                        bound = m;
+                    }
+                }
+                if (lane < npub) publish(lane, pval, s_max2[plb], s_pt[plb]);
+            }
+            // the header: the bound (its low 4 bits give way to the record count: only bits 6 and up are ever compared)
+            if (lane == 0) fc_store(xg + 6 * NE + part, epoch, (__float_as_uint(bound) & ~15u) | (unsigned)npub);
+            // sweep: lane l < NE takes record l of the merged set and its workgroup's header, lane l < P also header l (for the
+            // bounds); our own records come from LDS.  A record counts once its header and -- if the header lists it -- its
+            // six fields carry this super-round's tag.
+            fc_u64 x[6] = {0, 0, 0, 0, 0, 0}, hw = 0, hb = 0;
+            const int rw = lane / TP, rr = lane - rw * TP;
+            const bool peer_rec = lane < NE && rw != part, peer_bnd = lane < P && lane != part;
+            bool failed = false;
+            FCSTAMP(t5);
+#ifdef SN2_FC_STAMPS
+            n_surv += n; n_fb += n > 64 ? 1 : 0;
+#endif
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (peer_rec) {
+                    const fc_u64 h0 = FC_DUAL ? fc_load(xg + 6 * NE + rw) : 0ull, h1 = fc_load(xg + FC_COPY_U64 + 6 * NE + rw);
+                    fc_u64 y[6];
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) {
+                        x[f] = FC_DUAL ? fc_load(xg + f * NE + lane) : 0ull;
+                        y[f] = fc_load(xg + FC_COPY_U64 + f * NE + lane);
+                    }
+                    hw = fc_pick(h0, h1, epoch);
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) x[f] = fc_pick(x[f], y[f], epoch);
+                    ok = (unsigned)(hw >> 32) == epoch;
+                    if (rr < (int)((unsigned)hw & 15u)) {
+#pragma unroll
+                        for (int f = 0; f < 6; ++f) ok &= (unsigned)(x[f] >> 32) == epoch;
+                    }
+                }
+                if (peer_bnd) {
+                    hb = fc_pick(FC_DUAL ? fc_load(xg + 6 * NE + lane) : 0ull, fc_load(xg + FC_COPY_U64 + 6 * NE + lane), epoch);
+                    ok &= (unsigned)(hb >> 32) == epoch;
+                }
+                if (__ballot(!ok) == 0ull) break;
+                if (++spins > FC_SPIN_LIMIT) {
+                    failed = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            FCSTAMP(t6);
+#ifdef SN2_FC_STAMPS
+            n_spins += spins;
+#endif
+            float4 rA = make_float4(__uint_as_float((unsigned)x[0]), __uint_as_float((unsigned)x[1]), __uint_as_float((unsigned)x[2]), 0.f);
+            float4 rB = make_float4(__uint_as_float((unsigned)x[3]), __uint_as_float((unsigned)x[4]), __uint_as_float((unsigned)x[5]), 0.f);
+            bool valid = peer_rec && rr < (int)((unsigned)hw & 15u);
+            if (lane < NE && !peer_rec && rr < npub) {
+                rA = s_ownA[rr];
+                rB = s_ownB[rr];
+                valid = true;
+            }
+            const float val = rA.x;
+            const unsigned long long vb = __ballot(valid);
+            const int nvalid = __popcll(vb);
+            // the valid records ranked by value (keys as above): rank = place in the merged order
+            const int key = (__float_as_int(val) & ~63) | (63 - lane);
+            if (lane < 4) s_keys[nvalid + lane] = INT_MIN;
+            if (valid) s_keys[__builtin_amdgcn_mbcnt_hi((unsigned)(vb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vb, 0u))] = key;
+            if (lane < 9) s_crA[nvalid + lane] = make_float4(-1.f, -1.f, 0.f, 0.f);       // sentinels behind the valid records
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const float Ub = max_of_first8(lane < P ? __uint_as_float((lane == part ? __float_as_uint(bound) : (unsigned)hb) & ~15u) : -1.f);
+            __builtin_amdgcn_wave_barrier();
+            int rank = 0;
+#pragma unroll 2
+            for (int q4 = 0; q4 < (nvalid + 3) / 4; ++q4) {
+                const int4 k4 = reinterpret_cast<const int4*>(s_keys)[q4];
+                rank += (k4.x > key ? 1 : 0) + (k4.y > key ? 1 : 0) + (k4.z > key ? 1 : 0) + (k4.w > key ? 1 : 0);
+            }
+            if (valid) {
+                s_crA[rank] = rA;
+                s_crB[rank] = rB;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // acceptance tests: lane 8 e + jj looks at the pair (candidate e, earlier candidate jj)
+            const int e = lane >> 3, jj = lane & 7;
+            const float4 Ae = s_crA[e], Be = s_crB[e], Aj = s_crA[jj], Bj = s_crB[jj], An = s_crA[e + 1];
+            const float me = Ae.x;
+            const float nxt = fmaxf(An.x, Ub);          // the next known maximum, or what an unpublished bucket may still hold
+            const bool self_ok = me > 0.f && (__float_as_int(me) >> 6) > (__float_as_int(nxt) >> 6) && Ae.y < me;
+            const bool pair_bad = jj < e && (sn2_d2(Be.x, Be.y, Be.z, Bj.x, Bj.y, Bj.z) < me || Aj.y >= me);
+            // candidate c stands iff bit 8c of okm is set and byte c of badm is empty; accepted = the leading run of those
+            const unsigned long long okm = __ballot(self_ok);
+            unsigned long long badm = __ballot(pair_bad);
+            badm |= badm >> 4;
+            badm |= badm >> 2;
+            badm |= badm >> 1;
+            const unsigned long long stand = okm & ~badm & 0x0101010101010101ull;
+            const unsigned long long fell = ~stand & 0x0101010101010101ull;
+            int nj = fell ? __builtin_ctzll(fell) >> 3 : K;
+            const int rem = M - cnt;
+            nj = nj > rem ? rem : nj;
+            if (jj == 0 && e < nj) {
+                s_acc[e] = make_float4(Be.x, Be.y, Be.z, 0.f);
+                if (part == 0) emit(cnt + e, Be.x, Be.y, Be.z, -1 - __float_as_int(Ae.z));
+            }
+            int mode = 0;
+            float vtop = 0.f;
+            if (nj == 0) {
+                // nothing accepted: either the maximum is not unique at the keys' resolution (exact-tie search for the TRUE
+                // maximum) or nothing reached the bounds (lower the threshold and select again)
+                if (nvalid > 0) {
+                    vtop = wave_max_fused(valid ? val : -1.f);
+                    mode = 1;
+                } else {
+                    mode = 2;
+                }
+            }
+            // the next threshold: the candidate SN2_FC_TAU_KEEP places behind the accepted ones stays above it.  Only buckets
+            // that reached THIS threshold are known, so a list that is too short is extended downwards by its own average
+            // spacing (any value is exact -- see the header comment --, a good one keeps a dozen survivors per super-round:
+            // few enough to rank in a few compares, enough that a super-round never runs out of candidates)
+            tau = -1.f;
+            if (mode != 2 && nvalid >= 2) {
+                const int want = nj + tau_keep;
+                if (want <= nvalid - 1) {
+                    tau = s_crA[want].x;
+                } else {
+                    const float v0 = s_crA[0].x, vl = s_crA[nvalid - 1].x;
+                    tau = vl - (v0 - vl) / (float)(nvalid - 1) * (float)(want - (nvalid - 1));
+                }
+            }
+            if (failed) mode = 3;
+            if (lane == 0) {
+                if (failed) atomicAdd(&ctl[1], 1u);
+                s_ctl[0] = nj;
+                s_ctl[1] = (mode == 3 || cnt + (mode == 0 ? nj : (mode == 1 ? 1 : 0)) >= M) ? 1 : 0;
+                s_ctl[2] = __float_as_int(vtop);
+                s_ctl[3] = 0;
+                s_ctl[4] = mode;
+                *s_win = 0xFFFFFFFFu;
+            }
+#ifdef SN2_FC_STAMPS
+            FCSTAMP(t7);
+            acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4; acc[5] += t6 - t5;
+            acc[6] += t7 - t6;
+            n_rounds += 1; n_acc += nj; n_m1 += mode == 1; n_m2 += mode == 2;
+#endif
+        }
+        FCSTAMP(t8);
+        __syncthreads();
+#ifdef SN2_FC_STAMPS
+        { FCSTAMP(t9); acc[7] += t9 - t8; }
+#endif
+        j = s_ctl[0];
+        int done = s_ctl[1];
+        const int mode = s_ctl[4];
+        if (mode == 3) break;
+        if (mode == 0) {
+            const float4 a = s_acc[lane < j ? lane : 0];
+            ax = a.x; ay = a.y; az = a.z;
+        } else if (mode == 1) {
+            // exact tie of the maximal distance: lowest ORIGINAL index among all points of the plot attaining it
+            const float V = __int_as_float(s_ctl[2]);
+#pragma unroll
+            for (int h = 0; h < SL; ++h) {
+                const int sl = 64 * h + lane;
+                unsigned long long cand = __ballot(sl < SPW && s_val[sl * NW + wave] == V);
+                while (cand) {
+                    const int kk = 64 * h + __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const int pp = ((kk * NW + wave) * P + part) * 64 + lane;
+                    float d = -1.f;
+                    if (pp < N) {
+                        if constexpr (LP) d = s_pts[(kk * NW + wave) * 64 + lane].w; else d = pts[pp].w;
+                    }
+                    unsigned oi = 0xFFFFFFFFu;
+                    if (d == V) oi = (unsigned)ord[pp];
+                    oi = wave_min_u32_dpp(oi);
+                    if (lane == 0) atomicMin(s_win, oi);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                fc_u64* tg = xg + 6 * NE + P;           // one tie word per workgroup
+                if (lane == 0) fc_store(tg + part, epoch, *s_win);
+                fc_u64 tw = 0;
+                bool failed = false;
+                for (unsigned spins = 0;;) {
+                    bool ok = true;
+                    if (lane < P) {
+                        tw = fc_pick(FC_DUAL ? fc_load(tg + lane) : 0ull, fc_load(tg + FC_COPY_U64 + lane), epoch);
+                        ok = (unsigned)(tw >> 32) == epoch;
+                    }
+                    if (__ballot(!ok) == 0ull) break;
+                    if (++spins > FC_SPIN_LIMIT) {
+                        failed = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned w = wave_min_u32_dpp(lane < P ? (unsigned)tw : 0xFFFFFFFFu);
+                if (lane == 0) {
+                    s_ctl[5] = (int)w;
+                    if (failed || w == 0xFFFFFFFFu) {
+                        atomicAdd(&ctl[1], 1u);
+                        s_ctl[4] = 3;
+                    } else {
+                        s_acc[0] = make_float4(px[w], py[w], pz[w], 0.f);
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_ctl[4] == 3) break;
+            cur = __builtin_amdgcn_readfirstlane(s_ctl[5]);
+            ax = px[cur]; ay = py[cur]; az = pz[cur];
+            if (tid == 0 && part == 0) emit(cnt, ax, ay, az, cur);
+            j = 1;
+        } else {
+            j = 0;                                      // mode 2: no sample this super-round, the threshold was lowered
+        }
+        cnt += j;
+        if (done) break;
+    }
+#ifdef SN2_FC_STAMPS
+    if (ticket == 0 && tid == 0) {
+        for (int i = 0; i < 8; ++i) ctl[2 + i] = (unsigned)(acc[i] >> 4);       // 16-clock units
+        ctl[10] = n_rounds; ctl[11] = n_acc; ctl[12] = n_fb; ctl[13] = n_m1 | (n_m2 << 16); ctl[14] = n_surv; ctl[15] = n_spins;
+    }
+#endif
+    // the samples leave: sorted positions -> original indices (kept out of the loop: the loads would sit on wave 0's critical path)
+    if (part != 0) return;
+    __syncthreads();
+    for (int i = tid; i < M; i += NW * 64) {
+        if (use_log) {
+            const float4 e = s_log[i];
+            const int code = __float_as_int(e.w);
+            out_idx[i] = code < 0 ? ord[-1 - code] : code;
+            cpos_soa[((size_t)b * 3 + 0) * M + i] = e.x;
+            cpos_soa[((size_t)b * 3 + 1) * M + i] = e.y;
+            cpos_soa[((size_t)b * 3 + 2) * M + i] = e.z;
+            reinterpret_cast<float4*>(cpos_aos)[(size_t)b * M + i] = make_float4(e.x, e.y, e.z, 0.f);
+        } else {
+            const int v = out_idx[i];
+            if (v < 0) out_idx[i] = ord[-1 - v];
+        }
+    }
+}
+
+static bool fps_cluster_lds_points = getenv("SN2_FC_NO_LDS_POINTS") == nullptr;     // (diagnostic switches)
+static int fps_cluster_tau_keep = getenv("SN2_FC_TAU_KEEP") ? atoi(getenv("SN2_FC_TAU_KEEP")) : SN2_FC_TAU_KEEP;
+template <int SPW, int NW, int P>
+static int launch_fps_cluster(const float* pos, int B, int N, int M, const int* start, int* ws, int* idx, float* cs,
+                              float* ca, hipStream_t st) {
+    constexpr int NBL = SPW * NW, NE = FC_TP * P;
+    int* order = ws;
+    float4* sorted = reinterpret_cast<float4*>(ws + (size_t)B * N);
+    int* grid = ws + (size_t)5 * B * N;
+    unsigned* xchg = reinterpret_cast<unsigned*>(grid + (size_t)B * GRID_WORDS);
+    unsigned* ctl = xchg + (size_t)B * FPS_XCHG_WORDS;
+    hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl);
+    const int log_cap = M <= 4096 ? M : 0;           // the samples of a plot stay in LDS until the end (16 B each) when they fit
+    const size_t lds0 = (size_t)NBL * 16 + 8 * 16 + 2 * (size_t)(NE + 16) * 16 + 2 * FC_TP * 16 + (size_t)NBL * 4 * 9 + 72 * 4 + 8 * 4 + 16 +
+                        (size_t)log_cap * 16;
+    // the workgroup's points in LDS (64 KB at 8 x 8 x 8) when they fit beside the rest: phase B then never waits for L2
+    constexpr bool can_lp = (size_t)NBL * 64 * 16 <= 96 * 1024;
+    if (can_lp && lds0 + (size_t)NBL * 64 * 16 <= 150 * 1024 && fps_cluster_lds_points) {
+        const size_t lds = lds0 + (size_t)NBL * 64 * 16;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_cluster_kernel<SPW, NW, P, can_lp>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((fps_cluster_kernel<SPW, NW, P, can_lp>), dim3(B * P), dim3(NW * 64), lds, st, pos, B, N, M, start,
+                           (const int*)order, sorted, idx, cs, ca, reinterpret_cast<fc_u64*>(xchg), ctl, log_cap, fps_cluster_tau_keep);
+        SN2_RETURN_LAUNCH();
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_cluster_kernel<SPW, NW, P, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+    hipLaunchKernelGGL((fps_cluster_kernel<SPW, NW, P, false>), dim3(B * P), dim3(NW * 64), lds0, st, pos, B, N, M, start,
+                       (const int*)order, sorted, idx, cs, ca, reinterpret_cast<fc_u64*>(xchg), ctl, log_cap, fps_cluster_tau_keep);
+    SN2_RETURN_LAUNCH();
+}
+
+// P workgroups of NW waves per plot; the slots per wave follow from the plot size
+template <int NW, int P>
+static int dispatch_fps_cluster(const float* pos, int B, int N, int M, const int* start, int* ws, int* idx, float* cs,
+                                float* ca, hipStream_t st) {
+    const int nbl = sn2_cdiv(sn2_cdiv(N, 64), P);          // buckets per workgroup
+    const int spw = sn2_cdiv(nbl, NW);
+    if (spw <= 2) return launch_fps_cluster<2, NW, P>(pos, B, N, M, start, ws, idx, cs, ca, st);
+    if (spw <= 4) return launch_fps_cluster<4, NW, P>(pos, B, N, M, start, ws, idx, cs, ca, st);
+    if (spw <= 8) return launch_fps_cluster<8, NW, P>(pos, B, N, M, start, ws, idx, cs, ca, st);
+    if (spw <= 16) return launch_fps_cluster<16, NW, P>(pos, B, N, M, start, ws, idx, cs, ca, st);
+    if (spw <= 32) return launch_fps_cluster<32, NW, P>(pos, B, N, M, start, ws, idx, cs, ca, st);
+    if constexpr (NW <= 8) {     // (64 slots x 16 waves = 16 bucket values per lane of the selecting wave: spills at 128 VGPRs)
+        if (spw <= 64) return launch_fps_cluster<64, NW, P>(pos, B, N, M, start, ws, idx, cs, ca, st);
+    }
+    return SN2_ELIMIT;
+}
+
 extern "C" int sn2_fps_waves(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
                              float* cpos_aos, int* order_ws, int waves, void* stream) {
     if (!pos_soa || !idx || !cpos_soa || !cpos_aos || B <= 0 || N <= 0 || M <= 0 || M > N) return SN2_EINVAL;
-    if (waves != 0 && waves != 16 && waves != 8 && waves != 1) return SN2_EINVAL;
+    bool cluster = waves == 34 || waves == 36 || waves == 40 || waves == 66 || waves == 68 || waves == 72;
+    if (waves != 0 && waves != 16 && waves != 8 && waves != 1 && !cluster) return SN2_EINVAL;
+    if (waves == 0) {
+        // the shortest pass: several workgroups per plot wherever that fits (measured at 16 x 32 768 -> 1024: 8 workgroups of 8
+        // waves 0.87 ms, 4 of 8 0.99, the single workgroup 1.24; scripts/time_fps_cluster.py)
+        const int nbk = sn2_cdiv(N, 64);
+        for (int Pc = 8; Pc >= 2 && !cluster; Pc >>= 1) {
+            if ((long)B * Pc <= sn2_cu_count() && nbk >= 2 * Pc * 8 && nbk <= 512 * Pc) {
+                waves = 64 + Pc;
+                cluster = true;
+            }
+        }
+    }
     const bool spec = waves != 1;      // 1: the one-sample-per-round kernel (round 1's; cross-checks and timing comparisons)
     hipStream_t st = (hipStream_t)stream;
     if (order_ws && N > 2048 && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
+        // 32 + P / 64 + P: P = 2, 4 or 8 workgroups of 16 / 8 waves per plot (fps_cluster_kernel); needs at least two buckets
+        // per wave and all B * P workgroups resident at once, else the single-workgroup kernel below runs
+        if (cluster) {
+            const int P = waves & 15, NWc = (waves & 64) ? 8 : 16;
+            const bool fits = (long)B * P <= sn2_cu_count() && sn2_cdiv(N, 64) >= 2 * P * NWc && sn2_cdiv(N, 64) <= 512 * P;
+            if (fits) {
+                if (waves == 34) return dispatch_fps_cluster<16, 2>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                if (waves == 36) return dispatch_fps_cluster<16, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                if (waves == 40) return dispatch_fps_cluster<16, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                if (waves == 66) return dispatch_fps_cluster<8, 2>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                if (waves == 68) return dispatch_fps_cluster<8, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                return dispatch_fps_cluster<8, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+            }
+            waves = 16;
+        }
         // bucketed path (exact, see above): up to 128 bucket slots per wave = 131 072 points per plot.
         // waves = 8: half the waves per plot.  Alone the pass is 9 % slower (1.37 vs 1.26 ms at 32 x 32 768: fewer loads in
         // flight), but it leaves half of its CU's wave slots to whatever else runs: beside the feature pass of a pipelined

@@ -135,7 +135,7 @@ def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor, out: Optional[torch.Tensor
 
 def fps_ws_words(B: int, N: int) -> int:
     """SN2_FPS_WS_WORDS of include/strata_hip.h."""
-    return 5 * B * N + 4104 * B
+    return 5 * B * N + (4104 + 4096) * B + 32
 
 
 def fps_fills_ws(B: int, N: int, m: int) -> bool:
@@ -148,8 +148,10 @@ def fps_fills_ws(B: int, N: int, m: int) -> bool:
 def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True,
         return_ws: bool = False, out=None, waves: int = 0):
     """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
-    waves: 0/16 or 8 waves per plot in the bucketed kernel (include/strata_hip.h: sn2_fps_waves; 8 = the pass that shares its
-    CUs with concurrent kernels, what the pipelined training loop asks for; 1 = the one-sample-per-round kernel); same indices.
+    waves: which bucketed kernel (include/strata_hip.h: sn2_fps_waves): 0 = the shortest pass (several workgroups per plot
+    where the batch fits the chip), 16 / 8 = one workgroup of 16 / 8 waves per plot (8 = the pass that shares its CUs with
+    concurrent kernels, what the pipelined training loop asks for), 32 + P / 64 + P = P workgroups of 16 / 8 waves per plot,
+    1 = the one-sample-per-round kernel; same indices whichever runs.
     bucketed=False forces the brute-force kernel (same result; kept for cross-checks).  return_ws=True also returns
     the spatial-order workspace (or None), which `ball_query` over the same points can reuse.
     out = (idx, cpos_soa, cpos_aos, workspace-or-None): caller-owned result buffers (persistent pipelines)."""
@@ -204,7 +206,7 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
     else:
         _chk(total, I64, (1,), "total")
     if fps_ws is not None:
-        _chk(fps_ws, I32, (5 * B * N + 4104 * B,), "fps_ws")
+        _chk(fps_ws, I32, (fps_ws_words(B, N),), "fps_ws")
     _call("sn2_ball_query", _ptr(src_soa), B, N, _ptr(cpos_soa), M, r2_threshold(r), cap, _ptr(nbr), _ptr(cnt), _ptr(total),
           _ptr(fps_ws), _stream(), tag=f"N={N}")
     return nbr, cnt, total

@@ -161,7 +161,8 @@ class PointNet2(nn.Module):
     # are VALU streaming kernels bound by HBM, not by arithmetic: they stay fp32.
     BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn", "sa3_module.nn", "fp3_module.nn", "fp2_module.nn")
     mma_dtype = "fp32"
-    fps_waves_shared = 8       # waves per plot of the level-1 FPS when its pass shares the chip with feature kernels
+    # the level-1 FPS kernel when its pass shares the chip with feature kernels (sn2_fps_waves: 8 = one workgroup of 8 waves per plot)
+    fps_waves_shared = int(os.environ.get("SN2_FPS_WAVES_SHARED", "8"))
     geometry_fork = True       # `_geometry`: the three independent chains behind the level-1 FPS on three streams
 
     def set_mma_dtype(self, dtype: str):
