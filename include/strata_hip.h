@@ -200,6 +200,10 @@ typedef struct sn2_fp {
                                        gathers rows of T = W_A (sa*src+sc) kept here; backward keeps G[s] = sum of
                                        w * d pre-activation over the rows interpolating s here (dsrc += G W_A,
                                        dW_A += G^T (sa*src+sc)).  NULL: every row rebuilds its interpolated input.     */
+    int act_bf16;                   /* non-zero (only with src_ws, i.e. on the per-point layer, and with bn_sums_done): the rows
+                                       of h, dy and du_scratch are bfloat16 (same ELEMENT strides: 72-byte rows at cout = 34)
+                                       -- BASELINE.json configs[4]: the three per-point activation buffers are what the step
+                                       streams; statistics, every sum and the weight gradients stay fp32               */
 } sn2_fp;
 #define SN2_FP_SRC_WS_WORDS(B, S, cout) ((size_t)(B) * (S) * ((((cout) + 3) / 4) * 4))
 /* The transpose of knn_interpolate (its backward) is done as a gather through an inverted index of the 3-NN table:
@@ -235,6 +239,7 @@ typedef struct sn2_head {
     const int *drop_mask;           /* F.dropout between lin1 and lin2 (model/point_net2.py:142) in training: (R) words,
                                        bit j set = hidden channel j of the row is KEPT; NULL = no dropout (eval, p = 0) */
     float drop_scale;               /* 1/(1-p) applied to the kept channels (0 when p = 1)                         */
+    int act_bf16;                   /* non-zero: the rows of f and dy are bfloat16 (as sn2_fp.act_bf16 of the block that wrote f) */
 } sn2_head;
 int sn2_head_forward(const sn2_head *p, void *stream);
 int sn2_head_backward(const sn2_head *p, void *stream);

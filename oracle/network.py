@@ -82,6 +82,55 @@ class _LinearBF16(torch.autograd.Function):
         return dyr @ Wr, dyr.t() @ xr, dy.sum(0)
 
 
+class _RoundSTE(torch.autograd.Function):
+    """A tensor that is STORED in bfloat16 on its way forward (rounded to nearest even; the gradient passes unchanged)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GradRound(torch.autograd.Function):
+    """A tensor whose GRADIENT is stored in bfloat16 on its way back (the forward value passes unchanged)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+def _fp1_block(f, x0, sd, training, new_stats, act_bf16):
+    """FP1's (Linear, ReLU, BatchNorm) block on cat[interpolated, skip] (`model/point_net2.py:62-67,90,93`).  act_bf16: the
+    checker of the build's bfloat16 ACTIVATION STORAGE on the per-point layer (sn2_fp.act_bf16; BASELINE.json configs[4];
+    not in the reference): the block's output rows (after the ReLU, before the BatchNorm, whose batch statistics describe
+    the stored rows), the gradient of the BatchNorm's output, and the gradient of the pre-activation on its way to the
+    interpolation's sources are each rounded to bfloat16 once; sums, statistics and weight gradients stay wide."""
+    if not act_bf16:
+        return _mlp(torch.cat([f, x0], dim=1), sd, "fp1_module.nn", 1, training, new_stats)
+    prefix = "fp1_module.nn"
+    W, b = sd[f"{prefix}.0.0.weight"], sd[f"{prefix}.0.0.bias"]
+    ca = f.shape[1]
+    tA = _GradRound.apply(F.linear(f, W[:, :ca]))                 # d pre-activation -> sources through bfloat16 rows
+    a = _RoundSTE.apply(F.relu(tA + F.linear(x0, W[:, ca:]) + b))  # h1 as stored
+    rm = sd[f"{prefix}.0.2.running_mean"].clone()
+    rv = sd[f"{prefix}.0.2.running_var"].clone()
+    if BN_STATS_F64 and training:
+        y = _batch_norm_f64_stats(a, rm, rv, sd[f"{prefix}.0.2.weight"], sd[f"{prefix}.0.2.bias"])
+    else:
+        y = F.batch_norm(a, rm, rv, sd[f"{prefix}.0.2.weight"], sd[f"{prefix}.0.2.bias"], training=training, momentum=0.1, eps=1e-5)
+    if new_stats is not None:
+        new_stats[f"{prefix}.0.2.running_mean"] = rm
+        new_stats[f"{prefix}.0.2.running_var"] = rv
+    return _GradRound.apply(y)                                     # dy1 as stored
+
+
 BF16_LAYERS = ()      # prefixes of the blocks evaluated with bf16 operands (set through `forward(..., bf16_layers=)`)
 BN_STATS_F64 = False  # training-mode BatchNorm: batch mean / variance summed in fp64, everything else in the input's dtype
                       # (set through `forward(..., bn_stats_f64=True)`; isolates torch's fp32 batch-statistics error)
@@ -131,12 +180,14 @@ def _fps_regular(pos_long, B, n, ratio, start):
 
 def forward(sd: Dict[str, torch.Tensor], cloud: torch.Tensor, xyz: torch.Tensor, args, training: bool,
             fps_start: Optional[Sequence[torch.Tensor]] = None, use_kdtree: bool = False, details: bool = False,
-            dropout_mask: Optional[torch.Tensor] = None, bf16_layers: Sequence[str] = (), bn_stats_f64: bool = False):
+            dropout_mask: Optional[torch.Tensor] = None, bf16_layers: Sequence[str] = (), bn_stats_f64: bool = False,
+            act_bf16: bool = False):
     """cloud (B,10,N), xyz (B,3,N) fp32 CPU tensors (the DataLoader collate of `loader.py:73-87`).
     fps_start = (start1 (B,), start2 (B,)) LOCAL start indices of the two FPS calls (None -> 0).
     dropout_mask (B*N,16), non-zero = keep: the mask F.dropout (point_net2.py:142) would have drawn (None: torch draws).
     bf16_layers: prefixes of the (Linear, ReLU, BN) stacks whose Linear layers take bfloat16 operands (`_LinearBF16`).
     bn_stats_f64: training-mode BatchNorm statistics summed in fp64, everything else in `cloud`'s dtype (`BN_STATS_F64`).
+    act_bf16: the per-point activation buffers pass through bfloat16 storage (`_fp1_block`).
     Returns (coverages_pointwise (B*N,4), proba_pointwise (B*N,4), extras) where extras holds the new BN
     running statistics (training) and, with details=True, the intermediate tensors."""
     global BF16_LAYERS, BN_STATS_F64
@@ -183,7 +234,7 @@ def forward(sd: Dict[str, torch.Tensor], cloud: torch.Tensor, xyz: torch.Tensor,
     f = P.knn_interpolate(f3, pos2, pos1, batch2, batch1, k=3, use_kdtree=use_kdtree)
     f2 = _mlp(torch.cat([f, x1], dim=1), sd, "fp2_module.nn", 1, training, new_stats)
     f = P.knn_interpolate(f2, pos1, pos0, batch1, batch0, k=3, use_kdtree=use_kdtree)
-    f1 = _mlp(torch.cat([f, x0], dim=1), sd, "fp1_module.nn", 1, training, new_stats)
+    f1 = _fp1_block(f, x0, sd, training, new_stats, act_bf16)
 
     # ---- head (:141-151)
     h = F.relu(F.linear(f1, sd["lin1.weight"], sd["lin1.bias"]))
@@ -238,7 +289,8 @@ def init_state_dict_3sa(seed: int = 0):
     return sd
 
 
-def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False, bf16_layers=(), bn_stats_f64=False):
+def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False, bf16_layers=(), bn_stats_f64=False,
+                act_bf16=False):
     global BF16_LAYERS, BN_STATS_F64
     BF16_LAYERS, BN_STATS_F64 = tuple(bf16_layers), bool(bn_stats_f64)
     B, _, N = cloud.shape
@@ -268,7 +320,7 @@ def forward_3sa(sd, cloud, xyz, args, training, fps_start=None, use_kdtree=False
     f = P.knn_interpolate(f3, pos2, pos1, batch2, batch1, k=3, use_kdtree=use_kdtree)
     f2 = _mlp(torch.cat([f, x1], dim=1), sd, "fp2_module.nn", 1, training, new_stats)
     f = P.knn_interpolate(f2, pos1, pos0, batch1, batch0, k=3, use_kdtree=use_kdtree)
-    f1 = _mlp(torch.cat([f, x0], dim=1), sd, "fp1_module.nn", 1, training, new_stats)
+    f1 = _fp1_block(f, x0, sd, training, new_stats, act_bf16)
     h = F.relu(F.linear(f1, sd["lin1.weight"], sd["lin1.bias"]))
     scores = F.linear(h, sd["lin2.weight"], sd["lin2.bias"])
     proba = torch.softmax(scores[:, :4], dim=1)

@@ -35,7 +35,8 @@ class FP(Structure):  # sn2_fp
                 ("knn_idx", c_void_p), ("knn_w", c_void_p), ("skip", c_void_p), ("skip_stride", c_int),
                 ("blk", Block), ("h", c_void_p), ("h_stride", c_int), ("dy", c_void_p), ("dsrc", c_void_p),
                 ("dsrc_stride", c_int), ("dskip", c_void_p), ("dskip_stride", c_int), ("du_scratch", c_void_p),
-                ("scatter_ws", c_void_p), ("scatter_ready", c_int), ("bn_sums_done", c_void_p), ("src_ws", c_void_p)]
+                ("scatter_ws", c_void_p), ("scatter_ready", c_int), ("bn_sums_done", c_void_p), ("src_ws", c_void_p),
+                ("act_bf16", c_int)]
 
 
 class Head(Structure):  # sn2_head
@@ -43,7 +44,8 @@ class Head(Structure):  # sn2_head
                 ("fc", c_void_p), ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
                 ("coverages", c_void_p), ("proba", c_void_p), ("dcoverages", c_void_p), ("dproba", c_void_p),
                 ("dy", c_void_p), ("dW1", c_void_p), ("db1", c_void_p), ("dW2", c_void_p), ("db2", c_void_p),
-                ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("drop_mask", c_void_p), ("drop_scale", c_float)]
+                ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("drop_mask", c_void_p), ("drop_scale", c_float),
+                ("act_bf16", c_int)]
 
 
 # name -> argtypes; every entry point returns int (0 ok, >0 hipError_t, <0 argument error)

@@ -588,6 +588,32 @@ __global__ __launch_bounds__(WAVES * 64) void interp_gather_long_kernel(int n_sr
 // The row kernels use QH = ceil(CO/4) consecutive lanes per row, one float4 quad each: a load or store instruction covers
 // 64/QH whole rows = ~1 KB of consecutive bytes, and nothing but the lane's own quad constants lives in registers.
 // Results differ from the row-per-lane form by fp32 re-association only.
+// ---- rows of per-point activations in either storage precision (sn2_fp.act_bf16 / sn2_head.act_bf16).  A row has `stride`
+// ELEMENTS either way; quad q = elements 4q .. 4q+3: one 16-byte (fp32) or one 8-byte (bfloat16) access.  bfloat16 rows are
+// written with v_cvt_pk_bf16_f32 (round to nearest even) and read back exactly (a bfloat16 IS the upper half of an fp32).
+template <bool BF>
+__device__ __forceinline__ float4 row_quad_ld(const float* __restrict__ base, size_t row, int stride, int q) {
+    if constexpr (BF) {
+        const uint2 u = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + row * stride)[q];
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xFFFF0000u));
+    } else {
+        return reinterpret_cast<const float4*>(base + row * stride)[q];
+    }
+}
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+    bf16x4 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+    return __builtin_bit_cast(uint2, v);
+}
+template <bool BF>
+__device__ __forceinline__ void row_quad_st(float* __restrict__ base, size_t row, int stride, int q, float a, float b, float c, float d) {
+    if constexpr (BF) reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + row * stride)[q] = pack_bf16x4(a, b, c, d);
+    else reinterpret_cast<float4*>(base + row * stride)[q] = make_float4(a, b, c, d);
+}
+// the value a bfloat16 store keeps (for sums that must describe the STORED rows)
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+
 template <int CA, int CB, int CO>
 __global__ __launch_bounds__(256) void fp_src_table_kernel(int n_src, int src_stride, const float* __restrict__ src,
                                                            const float* __restrict__ src_a, const float* __restrict__ src_c,
@@ -648,7 +674,7 @@ __device__ __forceinline__ FpRowIn<QB> fp_row_in(long row, bool on, int R, const
     return in;
 }
 
-template <int CA, int CB, int CO>
+template <int CA, int CB, int CO, bool BF>
 __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot, int S_per_plot, int skip_stride,
                                                           const float* __restrict__ T, const int* __restrict__ knn_idx,
                                                           const float* __restrict__ knn_w, const float* __restrict__ skip,
@@ -708,11 +734,12 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
                     acc = fmaf(wB[t][4 * b2 + 3], in[u].sk[b2].w, acc);
                 }
                 acc = (in[u].valid && 4 * q + t < CO) ? fmaxf(acc, 0.f) : 0.f;
+                if constexpr (BF) acc = bf16_round(acc);     // the batch statistics describe the rows as they are stored
                 ssum[t] += acc;
                 ssq[t] = fmaf(acc, acc, ssq[t]);
                 v[t] = acc;
             }
-            if (in[u].valid) reinterpret_cast<float4*>(h + (size_t)in[u].rr * HS)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            if (in[u].valid) row_quad_st<BF>(h, in[u].rr, HS, q, v[0], v[1], v[2], v[3]);
         }
     }
     if (!slots) return;
@@ -733,7 +760,7 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
 }
 
 // rows: dp = relu'/BN backward of dy (stored, row stride HS, pad channels 0), dW_B | db
-template <int CA, int CB, int CO, int NT>
+template <int CA, int CB, int CO, int NT, bool BF>
 __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride, float invR, const float* __restrict__ skip,
                                                           const float* __restrict__ gammag, const float* __restrict__ meang,
                                                           const float* __restrict__ invstdg, const float* __restrict__ dgammag,
@@ -778,8 +805,8 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
             const long row = (grp0 + u) * G + g;
             valid[u] = on && row < R;
             rr[u] = valid[u] ? (unsigned)row : 0u;
-            hv[u] = reinterpret_cast<const float4*>(h + (size_t)rr[u] * HS)[q];
-            dv[u] = reinterpret_cast<const float4*>(dy + (size_t)rr[u] * HS)[q];
+            hv[u] = row_quad_ld<BF>(h, rr[u], HS, q);
+            dv[u] = row_quad_ld<BF>(dy, rr[u], HS, q);
 #pragma unroll
             for (int b = 0; b < QB; ++b)
                 sk[u][b] = reinterpret_cast<const float4*>(skip + (size_t)rr[u] * skip_stride)[b];
@@ -802,7 +829,7 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
                     aW[t][4 * b + 3] = fmaf(d4[t], sk[u][b].w, aW[t][4 * b + 3]);
                 }
             }
-            if (valid[u]) reinterpret_cast<float4*>(dp_out + (size_t)rr[u] * HS)[q] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+            if (valid[u]) row_quad_st<BF>(dp_out, rr[u], HS, q, d4[0], d4[1], d4[2], d4[3]);
         }
     }
     // per-lane partials -> LDS (plain stores) -> one sum per element and workgroup -> global atomics
@@ -826,7 +853,7 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
 
 // sources: G[s] = sum over the inverted list of w * dp[row] (QH lanes per entry, 64/QH entries per load instruction),
 // stored for the dW_A pass; dsrc[s] += G[s] W_A
-template <int CA, int CB, int CO>
+template <int CA, int CB, int CO, bool BF>
 __global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_plot, int S, int dsrc_stride,
                                                          const int4* __restrict__ items, const int* __restrict__ inv_row,
                                                          const float* __restrict__ inv_w, const float* __restrict__ dp,
@@ -859,7 +886,8 @@ __global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_pl
                   n = __builtin_amdgcn_readfirstlane(item.z);
         const int b = s / S;
         const float d_old = (lane < CA && active) ? dsrc[(size_t)s * dsrc_stride + lane] : 0.f;   // early: off the chain
-        const float* dpb = dp + (size_t)b * R_per_plot * HS;
+        const float* dpb = BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(dp) + (size_t)b * R_per_plot * HS)
+                              : dp + (size_t)b * R_per_plot * HS;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int base = 0; base < n; base += CH) {
             const int m = (n - base) < CH ? (n - base) : CH;
@@ -874,7 +902,7 @@ __global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_pl
                 const float w = __shfl(wj, e);
                 wv[j] = on ? w : 0.f;
                 v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (G * j < m) v[j] = reinterpret_cast<const float4*>(dpb + (size_t)r * HS)[q];
+                if (G * j < m) v[j] = row_quad_ld<BF>(dpb, (size_t)r, HS, q);
             }
 #pragma unroll
             for (int j = 0; j < STEPS; ++j) {
@@ -1401,6 +1429,7 @@ template <int CA, int CB, int CO, bool KNN>
 int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     const int R = p->B * p->R_per_plot;
     if (sn2_cdiv(R, 64) <= SN2_STAT_SLOTS) {   // small layer: 64 rows x 4 channel groups per workgroup
+        if (p->act_bf16) return SN2_ELIMIT;
         const int grid = sn2_cdiv(R, 64);
         constexpr size_t lf = (size_t)(64 * OuterAcc<16, CA + CB + 1>::QS + 2 * 16 * ((CO + 15) / 16)) * sizeof(float);
         static_assert(lf <= 48 * 1024, "fp_fwd_split_kernel staging");
@@ -1424,7 +1453,8 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
             // third of a second one (0.057 ms; 768: 0.056; 512: 0.052; 384: 0.058)
             const int cap_fwd_rows = 2 * sn2_cu_count() < SN2_STAT_SLOTS ? 2 * sn2_cu_count() : SN2_STAT_SLOTS;
             if (grid > cap_fwd_rows) grid = cap_fwd_rows;
-            hipLaunchKernelGGL((fp_fwd_rows_kernel<CA, CB, CO>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
+            auto kr = p->act_bf16 ? &fp_fwd_rows_kernel<CA, CB, CO, true> : &fp_fwd_rows_kernel<CA, CB, CO, false>;
+            hipLaunchKernelGGL(kr, dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
                                p->skip_stride, (const float*)p->src_ws, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.b, p->h,
                                training ? p->blk.stat_slots : (float*)nullptr);
             hipError_t e1 = hipGetLastError();
@@ -1432,6 +1462,7 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
             return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
         }
     }
+    if (p->act_bf16) return SN2_ELIMIT;       // bfloat16 rows: the source-side form of the per-point layer only
     int grid = pick_grid(R, 256, 4);
     if (grid > SN2_STAT_SLOTS) grid = SN2_STAT_SLOTS;
     hipLaunchKernelGGL((fp_fwd_kernel<CA, CB, CO, KNN>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot,
@@ -1481,6 +1512,9 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     // waves per workgroup (one workgroup per CU): as many as the staging regions and 256 VGPRs per lane allow
     constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 8 <= 150 * 1024) ? 8 : ((Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : 2);
     const int R = p->B * p->R_per_plot;
+    if (p->act_bf16 && !(p->bn_sums_done && p->src_ws && p->du_scratch && p->scatter_ws && p->dsrc && !p->dskip &&
+                         sn2_cdiv(R, 64) > SN2_STAT_SLOTS))
+        return SN2_ELIMIT;                    // bfloat16 rows: the source-side form of the per-point layer only
     // bn_sums_done (non-NULL): dgamma / dbeta of this block's BatchNorm already came from sn2_head_bn_sums / sn2_fp_bn_sums
     if (p->bn_sums_done) {
         // sn2_head_bn_sums / sn2_fp_bn_sums already completed dgamma / dbeta of this block (by the identity or by their
@@ -1522,7 +1556,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             if (S > 8192) return SN2_ELIMIT;
             constexpr int NT = 512;                       // 2 workgroups x 8 waves per CU; [4 (CB + 1)][NT] floats of LDS each
             constexpr size_t lb1 = (size_t)4 * (CB + 1) * NT * sizeof(float);
-            auto k1 = &fp_bwd_rows_kernel<CA, CB, CO, NT>;
+            auto k1 = p->act_bf16 ? &fp_bwd_rows_kernel<CA, CB, CO, NT, true> : &fp_bwd_rows_kernel<CA, CB, CO, NT, false>;
             if (lb1 > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb1);
             hipLaunchKernelGGL(k1, dim3(2 * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
@@ -1535,7 +1569,8 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             int gs = sn2_cdiv(n_src, 4);
             if (gs > 65536) gs = 65536;
             gs = (gs + 7) & ~7;                           // the same number of workgroups on each of the 8 XCDs
-            hipLaunchKernelGGL((fp_bwd_src_kernel<CA, CB, CO>), dim3(gs), dim3(256), 0, st, n_src, Rp, S, p->dsrc_stride,
+            auto k2 = p->act_bf16 ? &fp_bwd_src_kernel<CA, CB, CO, true> : &fp_bwd_src_kernel<CA, CB, CO, false>;
+            hipLaunchKernelGGL(k2, dim3(gs), dim3(256), 0, st, n_src, Rp, S, p->dsrc_stride,
                                (const int4*)x.items, (const int*)x.inv_row, (const float*)x.inv_w,
                                (const float*)p->du_scratch, p->blk.W, p->src_ws, p->dsrc);
             using AccD = OuterAcc<CO, CA, 32>;
@@ -1549,6 +1584,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             SN2_RETURN_LAUNCH();
         }
     }
+    if (p->act_bf16) return SN2_ELIMIT;
     constexpr size_t lds_bytes = (size_t)Acc::LDS_FLOATS * 4 * WAVES;
     auto kern = &fp_bwd_main_kernel<CA, CB, CO, KNN, WAVES>;
     if (lds_bytes > 48 * 1024)
@@ -1694,13 +1730,13 @@ __device__ __forceinline__ void head_row_v(const float4 (&fv)[9], cfp fa, cfp fc
     o.dens = 1.0f / (1.0f + expf(-s[4]));
 }
 
+template <bool BF = false>
 __device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, cfp fa, cfp fc, cfp W1, cfp b1, cfp W2,
                                          cfp b2, size_t r, HeadOut& o, const int* __restrict__ drop_mask = nullptr,
                                          float drop_scale = 1.f) {
-    const float4* fr = reinterpret_cast<const float4*>(f + r * f_stride);
     float4 fv[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) fv[q] = fr[q];
+    for (int q = 0; q < 9; ++q) fv[q] = row_quad_ld<BF>(f, r, f_stride, q);
     head_row_v(fv, fa, fc, W1, b1, W2, b2, r, o, drop_mask, drop_scale);
 }
 
@@ -1718,6 +1754,7 @@ constexpr int HEAD_T_QUADS = 64 * 9;   // a wave's 64 consecutive rows of 36 flo
 // form (24-28 us for 92 MB either way: the kernel streams at 3.3-3.8 TB/s and fp32 MFMA has the packed-VALU rate, 2 x the
 // scalar-operand FMA rate); it frees the VALU and scalar cache for whatever runs beside it.  The backward keeps its
 // row-per-lane form: 188 padded MFMAs per 64 rows would take as long as its 1250 FMAs per row do now.
+template <bool BF>
 __global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
                                                             const float* __restrict__ fc, const float* __restrict__ W1,
                                                             const float* __restrict__ b1, const float* __restrict__ W2,
@@ -1744,13 +1781,13 @@ __global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const floa
     const float bias1 = b1[n], bias2 = n < 5 ? b2[n] : 0.f;
     for (long r0 = ((long)blockIdx.x * 4 + wave) * 64; r0 < R; r0 += (long)gridDim.x * 256) {
         {
-            const float4* chunk = reinterpret_cast<const float4*>(f) + r0 * 9;
             const long lim = (R - r0) * 9;
             float4 t[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int e = lane + 64 * k;
-                t[k] = e < lim ? chunk[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+                // quad e of the wave's 64 consecutive rows: 16 bytes of fp32 or 8 bytes of bfloat16, contiguous either way
+                t[k] = e < lim ? row_quad_ld<BF>(f, (size_t)r0, 36, e) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) st4[lane + 64 * k] = t[k];
@@ -1823,6 +1860,7 @@ __global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const floa
 
 constexpr int HEAD_BWD_THREADS = 256;
 constexpr int HEAD_BWD_LDS_FLOATS = OuterAcc<16, 35, 32>::LDS_FLOATS;   // >= OuterAcc<16, 17, 32>::LDS_FLOATS
+template <bool BF>
 __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f_stride, const float* __restrict__ f,
                                                        const float* __restrict__ fa, const float* __restrict__ fc,
                                                        const float* __restrict__ W1g, const float* __restrict__ b1,
@@ -1852,8 +1890,8 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
         const size_t rr = valid ? (size_t)r : 0;
         const cfp W1 = opaque(as_const(W1g)), W2 = opaque(as_const(W2g));
         HeadOut o;
-        head_row(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), W1, opaque(as_const(b1)), W2,
-                 opaque(as_const(b2)), rr, o, drop_mask, drop_scale);
+        head_row<BF>(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), W1, opaque(as_const(b1)), W2,
+                     opaque(as_const(b2)), rr, o, drop_mask, drop_scale);
         float gc[4] = {0.f, 0.f, 0.f, 0.f}, gp[4] = {0.f, 0.f, 0.f, 0.f};
         if (dcov) {
             const float4 v = reinterpret_cast<const float4*>(dcov)[rr];
@@ -1888,7 +1926,6 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
         }
         acc1.add(lds1, dpre, o.y);
         if (valid) {
-            float* dr = dy + rr * f_stride;
 #pragma unroll
             for (int k4 = 0; k4 < 36; k4 += 4) {
                 float v[4];
@@ -1901,7 +1938,7 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f
                     }
                     v[t] = a;
                 }
-                *reinterpret_cast<float4*>(dr + k4) = make_float4(v[0], v[1], v[2], v[3]);
+                row_quad_st<BF>(dy, rr, f_stride, k4 / 4, v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -1947,7 +1984,7 @@ __global__ __launch_bounds__(256) void bn_sums_from_consumer_kernel(
     const float* __restrict__ db, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int* __restrict__ ok, int rep_k, int rep_stride,
     const float* __restrict__ h, int h_stride, const float* __restrict__ dyv, int dy_stride, long R,
-    const float* __restrict__ mean, const float* __restrict__ invstd) {
+    const float* __restrict__ mean, const float* __restrict__ invstd, int rows_bf16) {
     // one workgroup per channel o of the BatchNorm; its threads share the (consumer row j, gradient image r) pairs
     __shared__ int s_ok;
     __shared__ double s_red[2][4];
@@ -1962,7 +1999,13 @@ __global__ __launch_bounds__(256) void bn_sums_from_consumer_kernel(
         const float mu = mean[o], is = invstd[o];
         double sb = 0.0, sg = 0.0;
         for (long r = threadIdx.x; r < R; r += 256) {
-            const float dd = dyv[(size_t)r * dy_stride + o], hh = h[(size_t)r * h_stride + o];
+            float dd, hh;
+            if (rows_bf16) {
+                dd = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(dyv)[(size_t)r * dy_stride + o] << 16);
+                hh = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(h)[(size_t)r * h_stride + o] << 16);
+            } else {
+                dd = dyv[(size_t)r * dy_stride + o], hh = h[(size_t)r * h_stride + o];
+            }
             sb += (double)dd;
             sg += (double)(dd * ((hh - mu) * is));
         }
@@ -2017,7 +2060,8 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     SN2_TRY(check_head(p));
     if (!p->coverages || !p->proba) return SN2_EINVAL;
     // check_head: rows of exactly 36 floats (34 channels)
-    hipLaunchKernelGGL(head_fwd_mfma_kernel, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
+    auto kf = p->act_bf16 ? &head_fwd_mfma_kernel<true> : &head_fwd_mfma_kernel<false>;
+    hipLaunchKernelGGL(kf, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
                        p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba, p->drop_mask,
                        p->drop_mask ? p->drop_scale : 1.f);
     SN2_RETURN_LAUNCH();
@@ -2029,7 +2073,8 @@ extern "C" int sn2_head_bn_sums(const sn2_head* p, const float* gamma, const flo
     if (!p->dW1 || !p->db1 || !p->dy || !gamma || !beta || !mean || !invstd || !dgamma || !dbeta || !ok) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(p->cin), dim3(256), 0, (hipStream_t)stream, p->cin, 16, p->cin, 0, p->W1,
                        (const float*)p->dW1, (const float*)p->db1, gamma, beta, dgamma, dbeta, ok, p->grad_replicas,
-                       p->grad_replica_stride, p->f, p->f_stride, (const float*)p->dy, p->f_stride, (long)p->R, mean, invstd);
+                       p->grad_replica_stride, p->f, p->f_stride, (const float*)p->dy, p->f_stride, (long)p->R, mean, invstd,
+                       p->act_bf16);
     SN2_RETURN_LAUNCH();
 }
 
@@ -2042,7 +2087,7 @@ extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* 
     hipLaunchKernelGGL(bn_sums_from_consumer_kernel, dim3(p->ca), dim3(256), 0, (hipStream_t)stream, p->ca, p->blk.cout, p->blk.cin, 0,
                        (const float*)p->blk.W, (const float*)p->blk.dW, (const float*)p->blk.db, gamma, beta, dgamma, dbeta, ok,
                        p->blk.grad_replicas, p->blk.grad_replica_stride, p->src, p->src_stride, (const float*)p->dsrc,
-                       p->dsrc_stride, (long)p->B * p->S_per_plot, mean, invstd);
+                       p->dsrc_stride, (long)p->B * p->S_per_plot, mean, invstd, 0);
     SN2_RETURN_LAUNCH();
 }
 
@@ -2051,11 +2096,11 @@ extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     if (!p->dy || !p->dW1 || !p->db1 || !p->dW2 || !p->db2) return SN2_EINVAL;
     static_assert(OuterAcc<16, 17, 32>::LDS_FLOATS <= HEAD_BWD_LDS_FLOATS, "shared staging region");
     constexpr size_t lds_bytes = (size_t)HEAD_BWD_LDS_FLOATS * 4 * (HEAD_BWD_THREADS / 64);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
+    auto kb = p->act_bf16 ? &head_bwd_kernel<true> : &head_bwd_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     int grid = pick_grid(p->R, HEAD_BWD_THREADS, 1);
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
+    hipLaunchKernelGGL(kb, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
                        p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
                        p->db2, p->grad_replicas, p->grad_replica_stride, p->drop_mask, p->drop_mask ? p->drop_scale : 1.f);
     SN2_RETURN_LAUNCH();

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import FP, SA, Block, Head, check
 
-I32, F32, F64, I64 = torch.int32, torch.float32, torch.float64, torch.int64
+I32, F32, F64, I64, BF16 = torch.int32, torch.float32, torch.float64, torch.int64, torch.bfloat16
 
 
 # ---- optional per-entry-point timing with HIP events on torch's current stream (the stream every kernel is launched
@@ -461,14 +461,18 @@ SOURCE_SIDE = True     # False: never hand out src_ws, i.e. every row rebuilds i
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
             dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False, interp_index=None,
             bn_sums_done=None) -> FP:
-    """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view."""
+    """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view.
+    h of dtype bfloat16 (then dy and du_scratch too): the per-point layer stores its three activation buffers in bfloat16
+    (include/strata_hip.h: sn2_fp.act_bf16; BASELINE config 5) -- only the source-side form of a layer of more than
+    64 * SN2_STAT_SLOTS rows has those kernels."""
     R = B * R_per_plot
     hs = (block.cout + 3) // 4 * 4
+    AT = BF16 if h.dtype == BF16 else F32         # the storage type of h / dy / du_scratch
     n_src_rows = R if knn is None else B * S_per_plot
     src_stride = _chk_rows(src, F32, n_src_rows, ca, "src")
     if src.shape[1] < (ca + 3) // 4 * 4 and src_stride < (ca + 3) // 4 * 4:
         raise ValueError("fp: src rows must be padded to a multiple of 4 floats")
-    _chk(h, F32, (R, hs), "h")
+    _chk(h, AT, (R, hs), "h")
     d = FP()
     d.B, d.R_per_plot, d.S_per_plot, d.ca, d.cb = B, R_per_plot, S_per_plot, ca, cb
     d.src, d.src_stride = _ptr(src), src_stride
@@ -496,7 +500,7 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
         d.blk.mma_bf16 = 0
     d.h, d.h_stride = _ptr(h), hs
     if dy is not None:
-        _chk(dy, F32, (R, hs), "dy")
+        _chk(dy, AT, (R, hs), "dy")
     d.dsrc_stride = d.dskip_stride = 0
     if dsrc is not None:
         d.dsrc_stride = _chk_rows(dsrc, F32, n_src_rows, ca, "dsrc", align=1)
@@ -511,8 +515,11 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     if SOURCE_SIDE and knn is not None and 0 < cb <= 16 and cb % 4 == 0 and R > 64 * _lib.STAT_SLOTS:
         d._src_ws = torch.empty(B * S_per_plot * hs, dtype=F32, device=src.device)
     d.src_ws = _ptr(d._src_ws)
+    d.act_bf16 = int(AT == BF16)
+    if d.act_bf16 and d._src_ws is None:
+        raise ValueError("fp: bfloat16 activation rows need the source-side form (a k-NN layer of more than 65 536 rows)")
     if du_scratch is not None:
-        _chk(du_scratch, F32, (R, max(ca, hs)), "du_scratch")
+        _chk(du_scratch, AT, (R, max(ca, hs)), "du_scratch")
         if knn is not None and dsrc is not None:
             # inverted index of the 3-NN table: prebuilt by interp_index (geometry pass) or built by the backward call
             words = interp_ws_words(B, R_per_plot, S_per_plot)
@@ -574,7 +581,8 @@ def dropout_mask_words(keep: torch.Tensor) -> torch.Tensor:
 def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dproba=None, dy=None, grads=None,
               grad_images=(1, 0), drop_mask=None, drop_p: float = 0.0) -> Head:
     R = f.shape[0]
-    _chk(f, F32, (R, 36), "f")
+    AT = BF16 if f.dtype == BF16 else F32         # bfloat16 rows of f (and dy): sn2_head.act_bf16
+    _chk(f, AT, (R, 36), "f")
     _chk(fa, F32, (34,), "fa")
     _chk(fc, F32, (34,), "fc")
     _chk(lin1.weight, F32, (16, 34), "lin1.weight")
@@ -590,8 +598,9 @@ def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dpro
             _chk(t, F32, (R, 4), n)
     d.coverages, d.proba, d.dcoverages, d.dproba = _ptr(coverages), _ptr(proba), _ptr(dcov), _ptr(dproba)
     if dy is not None:
-        _chk(dy, F32, (R, 36), "dy")
+        _chk(dy, AT, (R, 36), "dy")
     d.dy = _ptr(dy)
+    d.act_bf16 = int(AT == BF16)
     if grads is not None:
         for t, ref in zip(grads, (lin1.weight, lin1.bias, lin2.weight, lin2.bias)):
             _chk(t, F32, ref.shape, "head grad view")

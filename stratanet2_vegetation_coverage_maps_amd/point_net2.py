@@ -226,6 +226,12 @@ class PointNet2(nn.Module):
                 raise ValueError(f"dropout_mask must have shape ({R},16)")
         return ops.dropout_mask_words(keep)
 
+    def _act_dtype(self, rows):
+        """Storage type of the three per-point activation buffers (FP1's output h1, the head's gradient dy1, FP1's
+        d pre-activation): bfloat16 under `mma_dtype = "bf16"` where the per-point layer takes its source-side form (more
+        than 64 * SN2_STAT_SLOTS rows), else fp32.  These 75 MB buffers are what the per-point kernels stream."""
+        return torch.bfloat16 if (self.mma_dtype == "bf16" and ops.SOURCE_SIDE and rows > 64 * STAT_SLOTS) else F32
+
     def _sizes(self, N):
         M1 = ops.fps_num_samples(N, self.sa1_module.ratio)
         M2 = ops.fps_num_samples(M1, self.sa2_module.ratio)
@@ -492,7 +498,7 @@ class PointNet2(nn.Module):
         ops.fp_forward(self._fp3_desc(s), training)
         s.h2 = torch.empty(B * M1, 36, dtype=F32, device=dev)
         ops.fp_forward(self._fp2_desc(s), training)
-        s.h1 = torch.empty(B * N, 36, dtype=F32, device=dev)
+        s.h1 = torch.empty(B * N, 36, dtype=self._act_dtype(B * N), device=dev)
         if join is not None:
             cur_stream.wait_stream(join[1])      # chain c: the per-point 3-NN table and its inverted index
         ops.fp_forward(self._fp1_desc(s), training)
@@ -546,7 +552,7 @@ class PointNet2(nn.Module):
         dcov = None if dcov is None else dcov.contiguous()
         dproba = None if dproba is None else dproba.contiguous()
         # head
-        dy1 = torch.empty(B * N, 36, dtype=F32, device=dev)
+        dy1 = torch.empty(B * N, 36, dtype=s.h1.dtype, device=dev)
         hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
         hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg,
                            grad_images=images, drop_mask=getattr(s, "drop_keep", None), drop_p=self.drop)
@@ -558,7 +564,7 @@ class PointNet2(nn.Module):
                          views[id(bn1.bias)], bn_ok[0:1])
         # FP1 -> d(fp2 output)
         dy2 = buf["dy2"].view(B * M1, 36)
-        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 36, dtype=F32, device=dev), with_grads=True,
+        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 36, dtype=s.h1.dtype, device=dev), with_grads=True,
                             interp_index=s.inv1, bn_sums_done=bn_ok[0:1])
         ops.fp_backward(d1)
         bn2 = self.fp2_module.nn[0][2]      # FP2's BatchNorm feeds FP1's interpolation: its gradients from FP1's dW, db

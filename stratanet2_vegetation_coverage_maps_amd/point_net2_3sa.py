@@ -259,7 +259,7 @@ class PointNet2ThreeSA(PointNet2):
         ops.fp_forward(self._fp3_desc(s), training)
         s.h2 = e(B * M1, 36)
         ops.fp_forward(self._fp2_desc(s), training)
-        s.h1 = e(B * N, 36)
+        s.h1 = torch.empty(B * N, 36, dtype=self._act_dtype(B * N), device=dev)
         ops.fp_forward(self._fp1_desc(s), training)
         cov, proba = e(B * N, 4), e(B * N, 4)
         s.drop_keep = drop_keep
@@ -295,7 +295,7 @@ class PointNet2ThreeSA(PointNet2):
         dcov = None if dcov is None else dcov.contiguous()
         dproba = None if dproba is None else dproba.contiguous()
         e = lambda *shape: torch.empty(*shape, dtype=F32, device=dev)                  # noqa: E731
-        dy1 = e(B * N, 36)
+        dy1 = torch.empty(B * N, 36, dtype=s.h1.dtype, device=dev)
         hg = (views[id(self.lin1.weight)], views[id(self.lin1.bias)], views[id(self.lin2.weight)], views[id(self.lin2.bias)])
         hd = ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, dcov=dcov, dproba=dproba, dy=dy1, grads=hg,
                            grad_images=images, drop_mask=getattr(s, "drop_keep", None), drop_p=self.drop)
@@ -313,7 +313,7 @@ class PointNet2ThreeSA(PointNet2):
         dy2, dy3, dy4 = buf["dy2"].view(B * M1, 36), buf["dy3"].view(B * M2, 64), buf["dy4"].view(B * M3, 64)
         dx1, dx2, dx3 = buf["dx1"].view(B * M1, 16), buf["dx2"].view(B * M2, 32), buf["dx3"].view(B * M3, 64)
         dxg, dy_sa4 = buf["dxg"].view(B, 64), buf["dy_sa4"].view(B * M3, 64)
-        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=e(B * N, 36), with_grads=True, interp_index=s.inv1,
+        d1 = self._fp1_desc(s, dy=dy1, dsrc=dy2, du_scratch=torch.empty(B * N, 36, dtype=s.h1.dtype, device=dev), with_grads=True, interp_index=s.inv1,
                             bn_sums_done=bn_ok[0:1])
         ops.fp_backward(d1)
         sums(ops.fp_bn_sums, d1, bn_of(self.fp2_module), s.b_fp2, 1)
