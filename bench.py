@@ -484,6 +484,15 @@ def dropin_eager_leg(dev, B, n_points, steps=10, warmup=3):
                     "torch.optim.Adam, plain torch loss ops, eager launches, geometry and features back to back"}
 
 
+def secondary_legs(dev):
+    """name -> thunk: the other configurations BASELINE.json names, as compact legs of the same process."""
+    return {"config2_3sa_arch": lambda: secondary_train_leg(dev, "3sa", 16, 32768, "f32", 100, 10),
+            "config5_128k_f32": lambda: secondary_train_leg(dev, "ref", 8, 131072, "f32", 50, 6),
+            "config5_128k_bf16": lambda: secondary_train_leg(dev, "ref", 8, 131072, "bf16", 50, 6),
+            "config4_parcel_inference": lambda: inference_leg(dev),
+            "dropin_eager": lambda: dropin_eager_leg(dev, 16, 32768)}
+
+
 def main():
     global N_POINTS
     ap = argparse.ArgumentParser()
@@ -514,6 +523,9 @@ def main():
                          "matrix cores (SA levels and the dense layers over centroids), fp32 accumulate, fp32 everywhere else")
     ap.add_argument("--split-exchange", action="store_true",
                     help="one GPU: use the multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
+    ap.add_argument("--only-leg", default=None,
+                    help="run ONE secondary leg by name and print its JSON (no headline): config2_3sa_arch, config5_128k_f32, "
+                         "config5_128k_bf16, config4_parcel_inference, dropin_eager -- for profiling and experiments")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (BASELINE configs 2 (3sa-arch), 4, 5 and the eager drop-in loop) that a default "
                          "single-GPU run of the metric's workload attaches under \"secondary\"")
@@ -538,6 +550,12 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
 
+    if a.only_leg:
+        legs = secondary_legs(dev)
+        if a.only_leg not in legs:
+            raise SystemExit(f"--only-leg: one of {sorted(legs)}")
+        print(json.dumps({a.only_leg: legs[a.only_leg]()}), flush=True)
+        return
     B, N_POINTS = a.plots, a.points
     # depth+1 resident batches (the pipeline's slots)
     n_slots = 1 if a.serial else (a.depth + 1 if a.no_pair else 2 * a.depth + 2)
@@ -773,12 +791,7 @@ def main():
             slots.clear()
             torch.cuda.empty_cache()
             sec = {}
-            legs = (("config2_3sa_arch", lambda: secondary_train_leg(dev, "3sa", 16, 32768, "f32", 100, 10)),
-                    ("config5_128k_f32", lambda: secondary_train_leg(dev, "ref", 8, 131072, "f32", 50, 6)),
-                    ("config5_128k_bf16", lambda: secondary_train_leg(dev, "ref", 8, 131072, "bf16", 50, 6)),
-                    ("config4_parcel_inference", lambda: inference_leg(dev)),
-                    ("dropin_eager", lambda: dropin_eager_leg(dev, 16, 32768)))
-            for name, fn in legs:
+            for name, fn in secondary_legs(dev).items():
                 log(f"secondary leg: {name}")
                 try:
                     sec[name] = fn()

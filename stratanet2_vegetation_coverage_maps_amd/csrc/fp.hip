@@ -1428,7 +1428,13 @@ bool fp_source_side_ok(const sn2_fp* p) {
 template <int CA, int CB, int CO, bool KNN>
 int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     const int R = p->B * p->R_per_plot;
-    if (sn2_cdiv(R, 64) <= SN2_STAT_SLOTS) {   // small layer: 64 rows x 4 channel groups per workgroup
+    // the matrix-core kernel (64 rows x 4 channel groups per workgroup): its per-workgroup statistic slots bound the rows of a
+    // TRAINING pass; an eval pass writes no statistics, so any row count takes it (parcel inference: FP3 on 80 000 rows ran
+    // the scalar-weight fallback below at 0.31 ms, 15 x what the contraction needs)
+    const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS;
+    bool src_side = false;                      // (the per-point layer keeps its source-side form in both modes)
+    if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) src_side = !small && fp_source_side_ok<CA, CO>(p);
+    if (small || (!training && !src_side)) {
         if (p->act_bf16) return SN2_ELIMIT;
         const int grid = sn2_cdiv(R, 64);
         constexpr size_t lf = (size_t)(64 * OuterAcc<16, CA + CB + 1>::QS + 2 * 16 * ((CO + 15) / 16)) * sizeof(float);
@@ -1439,7 +1445,7 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
                            p->knn_w, p->skip, p->blk.W, p->blk.b, p->h, training ? p->blk.stat_slots : (float*)nullptr);
         hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return (int)e0;
-        return sn2_bn_finalize(&p->blk, grid, nullptr, R, training, st);
+        return sn2_bn_finalize(&p->blk, training ? grid : 0, nullptr, R, training, st);
     }
     if (p->blk.mma_bf16) return SN2_ELIMIT;   // bf16 operands exist on the matrix-core kernel of the small layers only
     if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) {

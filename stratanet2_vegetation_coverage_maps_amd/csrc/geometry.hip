@@ -247,6 +247,132 @@ __global__ __launch_bounds__(NT) void spatial_order_kernel(const float* __restri
     }
 }
 
+// The same sort with U loads per coordinate in flight: the kernel above walks the points three times (bounding box, histogram,
+// scatter), N / 1024 trips each with three DEPENDENT loads per trip -- 71 us of load latency at N = 32 768, on the critical
+// path of every sn2_fps call.  Here a trip fetches U = 16 points per thread before it touches the first (two trips per pass at
+// N = 32 768); same arithmetic, same tables.  (All 32 points of a thread in registers at once spill at 1024 threads.)
+template <int U>
+__global__ __launch_bounds__(1024) void spatial_order_chunk_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
+                                                                   float4* __restrict__ sorted, int* __restrict__ grid,
+                                                                   unsigned* __restrict__ xchg, unsigned* __restrict__ ctl) {
+    constexpr int NT = 1024;
+    __shared__ int s_hist[ORDER_CELLS];
+    __shared__ float s_mm[6][NT / 64];
+    __shared__ int s_wsum[NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* px = pos + (size_t)b * 3 * N;
+    const float* py = px + N;
+    const float* pz = py + N;
+    // fn(i, x, y, z) for every point i of the plot, U points per thread and trip
+    auto for_points = [&](auto fn) {
+        for (int i0 = 0; i0 < N; i0 += NT * U) {
+            float vx[U], vy[U], vz[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT + tid;
+                const int ii = i < N ? i : N - 1;
+                vx[u] = px[ii]; vy[u] = py[ii]; vz[u] = pz[ii];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT + tid;
+                if (i < N) fn(i, vx[u], vy[u], vz[u]);
+            }
+        }
+    };
+    if (xchg) {
+        for (int i = tid; i < FPS_XCHG_WORDS; i += NT) xchg[(size_t)b * FPS_XCHG_WORDS + i] = 0u;
+        if (b == 0 && tid < FPS_CTL_WORDS) ctl[tid] = 0u;
+    }
+    for (int i = tid; i < ORDER_CELLS; i += NT) s_hist[i] = 0;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for_points([&](int, float vx, float vy, float vz) {
+        mn[0] = fminf(mn[0], vx); mx[0] = fmaxf(mx[0], vx);
+        mn[1] = fminf(mn[1], vy); mx[1] = fmaxf(mx[1], vy);
+        mn[2] = fminf(mn[2], vz); mx[2] = fmaxf(mx[2], vz);
+    });
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_min(mn[a]);
+        mx[a] = wave_max(mx[a]);
+        if (lane == 0) {
+            s_mm[a][wave] = mn[a];
+            s_mm[3 + a][wave] = mx[a];
+        }
+    }
+    __syncthreads();
+    float lo[3], sc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = s_mm[a][0], h = s_mm[3 + a][0];
+        for (int k = 1; k < NT / 64; ++k) {
+            l = fminf(l, s_mm[a][k]);
+            h = fmaxf(h, s_mm[3 + a][k]);
+        }
+        lo[a] = l;
+        const float ext = fmaxf(h - l, 1e-6f);
+        sc[a] = (a < 2 ? (float)ORDER_GX : (float)ORDER_GZ) / ext;
+    }
+    auto cell_of = [&](float vx, float vy, float vz) -> unsigned {     // the arithmetic of spatial_order_kernel, bit for bit
+        int cx = (int)((vx - lo[0]) * sc[0]), cy = (int)((vy - lo[1]) * sc[1]), cz = (int)((vz - lo[2]) * sc[2]);
+        cx = cx < 0 ? 0 : (cx > ORDER_GX - 1 ? ORDER_GX - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > ORDER_GX - 1 ? ORDER_GX - 1 : cy);
+        cz = cz < 0 ? 0 : (cz > ORDER_GZ - 1 ? ORDER_GZ - 1 : cz);
+        return morton_cell((unsigned)cx, (unsigned)cy, (unsigned)cz);
+    };
+    for_points([&](int, float vx, float vy, float vz) { atomicAdd(&s_hist[cell_of(vx, vy, vz)], 1); });
+    __syncthreads();
+    // exclusive scan over the cells: PER consecutive cells per thread, wave scan, 16 wave totals
+    constexpr int PER = ORDER_CELLS / NT;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        loc[k] = s_hist[tid * PER + k];
+        sum += loc[k];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += s_wsum[k];
+    int run = base + incl - sum;
+    int* gb = grid + (size_t)b * GRID_WORDS;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        s_hist[tid * PER + k] = run;
+        gb[tid * PER + k] = run;                        // cell -> first sorted position (the ball query walks these cell lists)
+        run += loc[k];
+    }
+    if (tid == 0) {
+        gb[ORDER_CELLS] = N;
+        float* gf = reinterpret_cast<float*>(gb + ORDER_CELLS + 1);
+        gf[0] = lo[0]; gf[1] = lo[1]; gf[2] = lo[2]; gf[3] = sc[0]; gf[4] = sc[1]; gf[5] = sc[2];
+        gb[GRID_WORDS - 1] = 0;
+    }
+    __syncthreads();
+    int* ob = order + (size_t)b * N;
+    float4* sb = sorted + (size_t)b * N;
+    for_points([&](int i, float vx, float vy, float vz) {
+        const int p = atomicAdd(&s_hist[cell_of(vx, vy, vz)], 1);
+        ob[p] = i;
+        sb[p] = make_float4(vx, vy, vz, INFINITY);      // .w = running FPS distance
+    });
+}
+
+// the plot's Morton order, sorted table and cell starts (+ the zeroed exchange area)
+static void launch_spatial_order(const float* pos, int B, int N, int* order, float4* sorted, int* grid, unsigned* xchg,
+                                 unsigned* ctl, hipStream_t st) {
+    if (N <= 8 * 1024)
+        hipLaunchKernelGGL(spatial_order_chunk_kernel<8>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl);
+    else
+        hipLaunchKernelGGL(spatial_order_chunk_kernel<16>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl);
+}
+
 // canonical, monotone lower bound of sn2_d2(p, c) over all p inside the box [lo, hi]
 __device__ __forceinline__ float sn2_box_d2(float lx, float ly, float lz, float hx, float hy, float hz, float cx, float cy,
                                             float cz) {
@@ -881,8 +1007,7 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
     int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
     unsigned* xchg = reinterpret_cast<unsigned*>(grid + (size_t)B * GRID_WORDS);      // B*FPS_XCHG_WORDS + FPS_CTL_WORDS
-    hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg,
-                       xchg + (size_t)B * FPS_XCHG_WORDS);
+    launch_spatial_order(pos, B, N, order, sorted, grid, xchg, xchg + (size_t)B * FPS_XCHG_WORDS, st);
     if (speculate) {
         constexpr int K = SN2_FPS_K;
         const size_t lds = fps_spec_lds_bytes<SPW, NW, K>();
@@ -1576,7 +1701,7 @@ static int launch_fps_cluster(const float* pos, int B, int N, int M, const int* 
     int* grid = ws + (size_t)5 * B * N;
     unsigned* xchg = reinterpret_cast<unsigned*>(grid + (size_t)B * GRID_WORDS);
     unsigned* ctl = xchg + (size_t)B * FPS_XCHG_WORDS;
-    hipLaunchKernelGGL(spatial_order_kernel<1024>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl);
+    launch_spatial_order(pos, B, N, order, sorted, grid, xchg, ctl, st);
     const int log_cap = M <= 4096 ? M : 0;           // the samples of a plot stay in LDS until the end (16 B each) when they fit
     const size_t lds0 = (size_t)NBL * 16 + 8 * 16 + 2 * (size_t)(NE + 16) * 16 + 2 * FC_TP * 16 + (size_t)NBL * 4 * 9 + 72 * 4 + 8 * 4 + 16 +
                         (size_t)log_cap * 16;
@@ -2334,6 +2459,79 @@ __global__ __launch_bounds__(1024) void nn_target_sort_kernel(const float* __res
     }
 }
 
+// nn_target_sort_kernel with U loads per coordinate in flight (the loop form spends a trip of dependent loads per point and
+// pass: 54 us at T = 32 768); same keys, same tables
+template <int U>
+__global__ __launch_bounds__(1024) void nn_target_sort_chunk_kernel(const float* __restrict__ dst, int T, const int* __restrict__ hdr,
+                                                                    int* __restrict__ order, float4* __restrict__ sorted) {
+    __shared__ int s_hist[NN_GMAX * NN_GMAX + 1];
+    __shared__ int s_wsum[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* dx = dst + (size_t)b * 3 * T;
+    const float* dy = dx + T;
+    const float* dz = dy + T;
+    const int* hb = hdr + (size_t)b * NN_HDR;
+    const int G = hb[NN_GMAX * NN_GMAX + 1 + 5];
+    const float* hf = reinterpret_cast<const float*>(hb + NN_GMAX * NN_GMAX + 1);
+    const float x0 = hf[0], y0 = hf[1], ix = hf[2], iy = hf[3];
+    auto key_of = [&](float px_, float py_) {                       // nn_target_sort_kernel's key, bit for bit
+        const float vx = px_ - x0, vy = py_ - y0;
+        int cx = (int)(vx * ix), cy = (int)(vy * iy);
+        cx = (vx < 0.f || cx < 0) ? 0 : (cx > G - 1 ? G - 1 : cx);
+        cy = (vy < 0.f || cy < 0) ? 0 : (cy > G - 1 ? G - 1 : cy);
+        return cy * G + ((cy & 1) ? G - 1 - cx : cx);
+    };
+    for (int i = tid; i <= G * G; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < T; i0 += 1024 * U) {
+        float vx[U], vy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 1024 + tid, ii = i < T ? i : T - 1;
+            vx[u] = dx[ii]; vy[u] = dy[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * 1024 + tid < T) atomicAdd(&s_hist[key_of(vx[u], vy[u])], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan over the <= 1024 cells: one cell per thread, wave scan, 16 wave totals
+        const int v = tid < G * G ? s_hist[tid] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - v;
+        for (int k = 0; k < wave; ++k) run += s_wsum[k];
+        __syncthreads();
+        if (tid < G * G) s_hist[tid] = run;
+    }
+    __syncthreads();
+    int* ob = order + (size_t)b * T;
+    float4* sb = sorted + (size_t)b * T;
+    for (int i0 = 0; i0 < T; i0 += 1024 * U) {
+        float vx[U], vy[U], vz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 1024 + tid, ii = i < T ? i : T - 1;
+            vx[u] = dx[ii]; vy[u] = dy[ii]; vz[u] = dz[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 1024 + tid;
+            if (i < T) {
+                const int p = atomicAdd(&s_hist[key_of(vx[u], vy[u])], 1);
+                ob[p] = i;
+                sb[p] = make_float4(vx[u], vy[u], vz[u], 0.f);
+            }
+        }
+    }
+}
+
 extern "C" int sn2_three_nn_xy(const float* src_soa, int B, int S, const float* dst_soa, int T, int k, int* idx, float* w,
                                void* ws, void* stream) {
     if (!src_soa || !dst_soa || !idx || !w || !ws || B <= 0 || S <= 0 || T <= 0 || k < 1 || k > 3) return SN2_EINVAL;
@@ -2346,7 +2544,10 @@ extern "C" int sn2_three_nn_xy(const float* src_soa, int B, int S, const float* 
     int* hdr = reinterpret_cast<int*>(sorted + (size_t)B * T);
     int* order = hdr + (size_t)B * NN_HDR;
     hipLaunchKernelGGL(nn_grid_build_kernel, dim3(B), dim3(256), 0, st, src_soa, S, G, tbl, hdr);
-    hipLaunchKernelGGL(nn_target_sort_kernel, dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
+    if (T <= 8 * 1024)
+        hipLaunchKernelGGL(nn_target_sort_chunk_kernel<8>, dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
+    else
+        hipLaunchKernelGGL(nn_target_sort_chunk_kernel<16>, dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
     const size_t lds = (size_t)S * 16 + (size_t)(G * G + 1) * 4;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&three_nn_grid_kernel),
