@@ -374,13 +374,15 @@ def secondary_train_leg(dev, arch, B, n_points, dtype, steps, warmup, depth=3):
     return out
 
 
-def inference_leg(dev, plots=2048, points=10000, batch=128, repeat=3, prefetch=3, cpu_sample_plots=8):
+def inference_leg(dev, plots=2048, points=10000, batch=256, repeat=3, prefetch=4, cpu_sample_plots=8, dtype="f32"):
     """BASELINE configs[3] (SURVEY.md 8d "C4"): parcel inference -- 2048 overlapping 10 m plots x 10 000 points tiling one
     parcel, eval forward + fixed-grid max rasters + the ordered weighted mosaic merge (predict.py:96-141), inputs resident.
+    256 plots per launch, four geometry passes in flight (measured: 128 / 3 gives 43.6k plots/s, 256 / 4 47.8k).
     Median of `repeat` whole-parcel runs; roofline on SURVEY 8d's 368 B/point forward figure; the oracle's eval forward +
     rasters on a bounded sample of the same plots as the CPU baseline."""
     from stratanet2_vegetation_coverage_maps_amd import inference
     args = make_args(cuda=dev.index or 0, subsample_size=points)           # reference defaults: ratios .25/.25, r sqrt2/sqrt8
+    args.mma_dtype = "bf16" if dtype == "bf16" else "fp32"
     torch.manual_seed(0)
     model = PointNet2(args).eval()
     cols, stride = 64, 5.0                                                 # plot centres every 5 m: each pixel sees ~12 plots
@@ -417,10 +419,15 @@ def inference_leg(dev, plots=2048, points=10000, batch=128, repeat=3, prefetch=3
     out = {"workload": f"C4: {plots} plots x {points} pts, B={batch} per launch, reference defaults (ratios .25/.25, r sqrt2/sqrt8), "
                        f"eval forward + rasters + ordered mosaic merge, geometry prefetch {prefetch}, inputs resident",
            "seconds_per_parcel": round(med, 5), "plots_per_s": round(n / med, 1), "runs_s": [round(t, 5) for t in times],
-           "statistic": f"median of {repeat}", "parcel_pix": [H, W], "covered_frac": round(cover, 3), "dtype": "f32",
+           "statistic": f"median of {repeat}", "parcel_pix": [H, W], "covered_frac": round(cover, 3), "dtype": dtype,
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(by / med / 1e9, 2),
                         "frac": round(by / med / (HBM_PEAK_GBS * 1e9), 5), "compulsory_bytes": int(by),
                         "what": "whole parcel: 368 B/point (SURVEY.md 8d forward figure) x points x plots over seconds_per_parcel"}}
+    if dtype != "f32":
+        out["workload"] += "; bfloat16 operands on the matrix cores (SA levels, SA3/FP3/FP2) and bfloat16 per-point rows -- NOT the reference's precision"
+        del batches, model
+        torch.cuda.empty_cache()
+        return out
     # CPU baseline: the oracle's eval forward + fixed-grid rasters on the first plots of the same parcel
     from oracle import network, projection
     ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
@@ -490,6 +497,7 @@ def secondary_legs(dev):
             "config5_128k_f32": lambda: secondary_train_leg(dev, "ref", 8, 131072, "f32", 50, 6),
             "config5_128k_bf16": lambda: secondary_train_leg(dev, "ref", 8, 131072, "bf16", 50, 6),
             "config4_parcel_inference": lambda: inference_leg(dev),
+            "config4_parcel_inference_bf16": lambda: inference_leg(dev, dtype="bf16"),
             "dropin_eager": lambda: dropin_eager_leg(dev, 16, 32768)}
 
 
@@ -525,7 +533,7 @@ def main():
                     help="one GPU: use the multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
     ap.add_argument("--only-leg", default=None,
                     help="run ONE secondary leg by name and print its JSON (no headline): config2_3sa_arch, config5_128k_f32, "
-                         "config5_128k_bf16, config4_parcel_inference, dropin_eager -- for profiling and experiments")
+                         "config5_128k_bf16, config4_parcel_inference, config4_parcel_inference_bf16, dropin_eager -- for profiling and experiments")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (BASELINE configs 2 (3sa-arch), 4, 5 and the eager drop-in loop) that a default "
                          "single-GPU run of the metric's workload attaches under \"secondary\"")

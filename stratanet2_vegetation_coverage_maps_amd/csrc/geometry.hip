@@ -44,6 +44,10 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ pos, i
                                                 const int* __restrict__ start, int* __restrict__ idx_out,
                                                 float* __restrict__ cpos_soa, float* __restrict__ cpos_aos) {
     constexpr int NW = T / 64;
+    // PLDS: a copy of the positions in LDS (16 B per point) where it is small: the winner's coordinates are then one LDS read
+    // per round instead of three dependent global loads (~500 clocks of the ~1250 a round of the 1024 -> 256 level took)
+    constexpr bool PLDS = !ZLDS && PPT * T * 16 <= 32 * 1024;
+    __shared__ float4 s_pos[PLDS ? PPT * T : 1];
     __shared__ unsigned long long s_key[2][NW];
     // ZLDS (PPT = 32): x, y and the running distance fill the 128-VGPR budget of a 1024-lane workgroup, so the z
     // row lives in LDS (128 KiB, each lane re-reads only its own slots: conflict-free ds_read_b32).
@@ -60,13 +64,21 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ pos, i
         x[k] = v ? px[j] : 0.f;
         y[k] = v ? py[j] : 0.f;
         if constexpr (ZLDS) s_z[j] = v ? pz[j] : 0.f; else z[k] = v ? pz[j] : 0.f;
+        if constexpr (PLDS) s_pos[j] = make_float4(x[k], y[k], z[k], 0.f);
         d[k] = v ? INFINITY : 0.f;  // padding lanes: distance 0 and an index above every real point -> never win
     }
     int cur = start ? start[b] : 0;
     cur = cur < 0 ? 0 : (cur >= N ? N - 1 : cur);
+    if constexpr (PLDS) __syncthreads();
     for (int i = 0; i < M; ++i) {
         cur = __builtin_amdgcn_readfirstlane(cur);
-        const float lx = px[cur], ly = py[cur], lz = pz[cur];
+        float lx, ly, lz;
+        if constexpr (PLDS) {
+            const float4 c = s_pos[cur];
+            lx = c.x; ly = c.y; lz = c.z;
+        } else {
+            lx = px[cur]; ly = py[cur]; lz = pz[cur];
+        }
         if (tid == 0) {
             idx_out[(size_t)b * M + i] = cur;
             cpos_soa[((size_t)b * 3 + 0) * M + i] = lx;
