@@ -33,6 +33,9 @@ extern "C" {
 #define SN2_STAT_SLOTS 1024    /* workgroups (= partial-sum slots) of a kernel that produces BatchNorm statistics */
 
 int sn2_version(void);
+/* diagnostic (tests/test_gpu_bf16.py): D (16,16) = A (16,48) B (48,16) with bfloat16 operands through a K = 32 and a K = 16 MFMA
+ * chained on one accumulator -- modes 0..4: csrc/misc.hip, debug_mfma_chain_kernel */
+int sn2_debug_mfma_chain(const float *a, const float *b, float *d, int mode, void *stream);
 
 /* ---- one (Linear -> ReLU -> BatchNorm1d) block, model/point_net2.py:45-53 -------------------------------- */
 typedef struct sn2_block {

@@ -51,6 +51,7 @@ class Head(Structure):  # sn2_head
 # name -> argtypes; every entry point returns int (0 ok, >0 hipError_t, <0 argument error)
 SIGNATURES = {
     "sn2_version": [],
+    "sn2_debug_mfma_chain": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "sn2_pack_rows": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_fps": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_fps_waves": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],

@@ -284,6 +284,82 @@ extern "C" int sn2_prepare_plots(const float* raw, long T, const int* offsets, c
     SN2_RETURN_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Regression guard for mlp.h's rule "one MFMA shape per accumulation chain".  D (16 x 16) = A (16 x 48) B (48 x 16) with
+// bfloat16 operands, K = 32 through v_mfma_f32_16x16x32_bf16 and the tail K = 16 through v_mfma_f32_16x16x16_bf16, the second
+// instruction taking the first one's result as its accumulator:
+//   mode 0  the two builtins as the compiler schedules them HERE (it happens to put seven wait states between them: right);
+//   mode 1  the same with 16 wait states forced between them: right;
+//   mode 2  contract<true, 12> (mlp.h: K = 48 as two K = 32 instructions, the tail padded with zeros): what the library does;
+//   mode 3  the distance the compiler chose inside sa_mfma_bwd_kernel (below): three vector instructions, no s_nop, the K = 16
+//           instruction reading the K = 32 result as SrcC into another vDst.  The 8-pass K = 32 form (new on gfx950) has not
+//           written all four result registers by then: rows 4q, 4q+1 of the tile lack the first product;
+//   mode 4  mode 3 with 16 wait states: right.
+// tests/test_gpu_bf16.py holds modes 0, 1, 2 and 4 to the product of the rounded operands and reports mode 3.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void debug_mfma_chain_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ d, int mode) {
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (mode == 2) {
+        acc = contract<true, 12>(acc, [&](int kb) { return a[r * 48 + 4 * kb + q]; }, [&](int kb) { return b[(4 * kb + q) * 16 + r]; });
+    } else {
+        bf16x8 av, bv;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            av[t] = (__bf16)a[r * 48 + q * 8 + t];
+            bv[t] = (__bf16)b[(q * 8 + t) * 16 + r];
+        }
+        bf16x4 at, bt;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            at[t] = (__bf16)a[r * 48 + 32 + q * 4 + t];
+            bt[t] = (__bf16)b[(32 + q * 4 + t) * 16 + r];
+        }
+        if (mode >= 3) {
+            // the sequence hipcc emitted inside sa_mfma_bwd_kernel when contract<> still mixed the shapes (ROCm 7.2, -O3):
+            //     v_mfma_f32_16x16x32_bf16 a[32:35], v[246:249], v[238:241], a[0:3]
+            //     v_and_b32_e32 v38, 0xffff, v55 ; v_ashrrev_i32_e32 v57, 31, v56 ; v_lshl_add_u64 v[56:57], s[94:95], 0, v[56:57]
+            //     v_mfma_f32_16x16x16_bf16 a[36:39], v[40:41], v[38:39], a[32:35]
+            // i.e. the K = 16 instruction reads the K = 32 result as SrcC (another vDst) THREE vector instructions later and
+            // no s_nop.  Mode 3 replays exactly that distance, mode 4 the same with 16 wait states in between.
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x4 a8 = __builtin_bit_cast(u32x4, av), b8 = __builtin_bit_cast(u32x4, bv);
+            const u32x2 a4 = __builtin_bit_cast(u32x2, at), b4 = __builtin_bit_cast(u32x2, bt);
+            f32x4 t, o;
+            unsigned dummy = lane;
+            if (mode == 3)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, 0\n\t"
+                             "v_and_b32 %2, 0xffff, %2\n\tv_ashrrev_i32 %2, 1, %2\n\tv_add_u32 %2, 1, %2\n\t"
+                             "v_mfma_f32_16x16x16_bf16 %1, %5, %6, %0\n\t"
+                             "s_nop 7\n\ts_nop 7"
+                             : "=&v"(t), "=&v"(o), "+v"(dummy) : "v"(a8), "v"(b8), "v"(a4), "v"(b4));
+            else
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %3, %4, 0\n\t"
+                             "v_and_b32 %2, 0xffff, %2\n\tv_ashrrev_i32 %2, 1, %2\n\tv_add_u32 %2, 1, %2\n\t"
+                             "s_nop 7\n\ts_nop 7\n\t"
+                             "v_mfma_f32_16x16x16_bf16 %1, %5, %6, %0\n\t"
+                             "s_nop 7\n\ts_nop 7"
+                             : "=&v"(t), "=&v"(o), "+v"(dummy) : "v"(a8), "v"(b8), "v"(a4), "v"(b4));
+            acc = o;
+            if (dummy == 0xFFFFFFFFu) acc[0] = 0.f;    // (keeps the filler instructions' register alive)
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+            if (mode == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, at), __builtin_bit_cast(s16x4, bt), acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[(4 * q + j) * 16 + r] = acc[j];
+}
+
+extern "C" int sn2_debug_mfma_chain(const float* a, const float* b, float* d, int mode, void* stream) {
+    if (!a || !b || !d || mode < 0 || mode > 4) return SN2_EINVAL;
+    hipLaunchKernelGGL(debug_mfma_chain_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, d, mode);
+    SN2_RETURN_LAUNCH();
+}
+
 extern "C" int sn2_version(void) { return SN2_VERSION; }
 
 

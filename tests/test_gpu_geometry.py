@@ -253,3 +253,32 @@ def test_fps_workspace_is_only_handed_out_when_filled():
         assert torch.equal(cnt, cnt_f)
         ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, torch.zeros(B, dtype=torch.long))
         assert torch.equal(idx.cpu().long(), ref)
+
+
+@pytest.mark.parametrize("B,M", [(3, 1024), (2, 2500), (4, 256), (1, 10000), (2, 77)])
+def test_sa_work_items_order(B, M):
+    """sn2_sa_order (the work items of the set-abstraction passes, ranked per plot by neighbour count descending, index
+    ascending -- a bitonic sort in LDS) against the rule evaluated on the host: solo centroids (more than SOLO_MIN neighbours)
+    first, one per position in four copies with the flag; the others four per position; -1 behind the last."""
+    g = torch.Generator().manual_seed(B * 1000 + M)
+    cnt = torch.randint(0, 40, (B * M,), generator=g, dtype=torch.int32)         # many ties
+    heavy = torch.rand(B * M, generator=g) < 0.1
+    cnt[heavy] = torch.randint(40, 2001, (int(heavy.sum()),), generator=g, dtype=torch.int32)
+    got = ops.sa_order(cnt.to(DEV), B, M).cpu()
+    SOLO_MIN, FLAG = 64, 1 << 30
+    want = torch.full((4 * B * M + 4,), -1, dtype=torch.int32)
+    positions = 0
+    for b in range(B):
+        c = cnt[b * M:(b + 1) * M]
+        order = sorted(range(M), key=lambda i: (-int(c[i]), i))
+        nsolo = int((c > SOLO_MIN).sum())
+        for r, i in enumerate(order):
+            idv = b * M + i
+            if r < nsolo:
+                want[4 * (r * B + b):4 * (r * B + b) + 4] = idv | FLAG
+            else:
+                rl = r - nsolo
+                want[4 * ((nsolo + (rl >> 2)) * B + b) + (rl & 3)] = idv
+        positions = max(positions, nsolo + (M - nsolo + 3) // 4)
+    want[4 * B * M] = positions
+    assert torch.equal(got[:4 * B * M + 1], want[:4 * B * M + 1])
