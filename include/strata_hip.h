@@ -75,10 +75,11 @@ int sn2_pack_rows(const float *cloud, const float *xyz, int B, int C, int N, flo
  * idx (B,M) local indices in selection order; cpos_soa (B,3,M) and cpos_aos (B*M,4) = the selected positions.
  * order_ws: workspace of SN2_FPS_WS_WORDS(B,N) int32 (16-byte aligned, no initialisation: B*N ints of spatial order,
  * B*N float4 of sorted points, B cell-grid headers of 4104 words, B exchange areas of 4096 words for the
- * multi-workgroup kernel, 32 control words) enabling the bucketed kernel (exact same result, several times
+ * multi-workgroup kernel, 32 control words, B*N ints = every point's position in the spatial order [the inverse of the
+ * first B*N words: what sn2_fp.row_perm takes]) enabling the bucketed kernel (exact same result, several times
  * faster at N = 32768), or NULL for the brute-force kernel.  After the call the workspace describes the sorted point
  * set and can be handed to sn2_ball_query over the same sources. */
-#define SN2_FPS_WS_WORDS(B, N) (5L * (B) * (N) + (4104L + 4096L) * (B) + 32L)
+#define SN2_FPS_WS_WORDS(B, N) (6L * (B) * (N) + (4104L + 4096L) * (B) + 32L)
 int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
             float *cpos_aos, int *order_ws, void *stream);
 /* The same with a choice of kernel for the bucketed path.  waves = 0 (what sn2_fps passes): the shortest pass -- the
@@ -207,6 +208,12 @@ typedef struct sn2_fp {
                                        of h, dy and du_scratch are bfloat16 (same ELEMENT strides: 72-byte rows at cout = 34)
                                        -- BASELINE.json configs[4]: the three per-point activation buffers are what the step
                                        streams; statistics, every sum and the weight gradients stay fp32               */
+    const int *row_perm;            /* NULL, or (B*R) ints, a permutation of 0..R-1 per plot (with src_ws only): the backward
+                                       pass keeps the d pre-activation row of target row r of plot b at row b*R + row_perm[b*R + r]
+                                       of du_scratch, and the inverted index (sn2_interp_index_perm) lists those positions.
+                                       With row_perm = the targets' positions along a space-filling curve (the last B*N words
+                                       of sn2_fps's workspace) the rows a source gathers lie close together: the gather of the
+                                       source-side backward runs out of L2 instead of fetching every row three times          */
 } sn2_fp;
 #define SN2_FP_SRC_WS_WORDS(B, S, cout) ((size_t)(B) * (S) * ((((cout) + 3) / 4) * 4))
 /* The transpose of knn_interpolate (its backward) is done as a gather through an inverted index of the 3-NN table:
@@ -218,6 +225,9 @@ typedef struct sn2_fp {
  * target rows shared by neighbouring sources stay in that XCD's L2. */
 int sn2_interp_index(const int *knn_idx, const float *knn_w, const float *src_pos, int B, int R_per_plot,
                      int S_per_plot, float *ws, void *stream);
+/* the same index over PERMUTED target rows: list entries name row_perm[b*R + r] instead of r (sn2_fp.row_perm; NULL = identity) */
+int sn2_interp_index_perm(const int *knn_idx, const float *knn_w, const float *src_pos, const int *row_perm, int B,
+                          int R_per_plot, int S_per_plot, float *ws, void *stream);
 int sn2_fp_forward(const sn2_fp *p, int training, void *stream);
 int sn2_fp_backward(const sn2_fp *p, void *stream);
 

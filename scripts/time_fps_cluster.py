@@ -27,7 +27,7 @@ for w in VARIANTS:
     ops.fps(xyz, M, start, out=out, waves=w)
     torch.cuda.synchronize()
     ok = bool(torch.equal(out[0], ref))
-    ctl = out[3][-32:].tolist()
+    ctl = ops.fps_ws_ctl(out[3], B, N).tolist()
     msg = f"waves={w:3d}: equal={ok} per-XCD arrivals={ctl[16:24]} overflow={ctl[0]} timeouts={ctl[1]}"
     if not ok:
         bad = (out[0] != ref).nonzero()

@@ -36,7 +36,7 @@ class FP(Structure):  # sn2_fp
                 ("blk", Block), ("h", c_void_p), ("h_stride", c_int), ("dy", c_void_p), ("dsrc", c_void_p),
                 ("dsrc_stride", c_int), ("dskip", c_void_p), ("dskip_stride", c_int), ("du_scratch", c_void_p),
                 ("scatter_ws", c_void_p), ("scatter_ready", c_int), ("bn_sums_done", c_void_p), ("src_ws", c_void_p),
-                ("act_bf16", c_int)]
+                ("act_bf16", c_int), ("row_perm", c_void_p)]
 
 
 class Head(Structure):  # sn2_head
@@ -69,6 +69,7 @@ SIGNATURES = {
     "sn2_sa_backward": [POINTER(SA), c_void_p],
     "sn2_grad_reduce": [c_void_p, c_int, c_int, c_int, c_void_p],
     "sn2_interp_index": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sn2_interp_index_perm": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_fp_forward": [POINTER(FP), c_int, c_void_p],
     "sn2_fp_backward": [POINTER(FP), c_void_p],
     "sn2_plot_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],

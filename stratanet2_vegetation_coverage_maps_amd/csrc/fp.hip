@@ -391,7 +391,7 @@ __global__ __launch_bounds__(1024) void inv_scan_kernel(int R_per_plot, int S, i
 __global__ __launch_bounds__(1024) void inv_fill_kernel(int R_per_plot, int S, const int* __restrict__ knn_idx,
                                                         const float* __restrict__ knn_w, const int* __restrict__ H,
                                                         const int* __restrict__ off, int* __restrict__ inv_row,
-                                                        float* __restrict__ inv_w) {
+                                                        float* __restrict__ inv_w, const int* __restrict__ row_perm) {
     extern __shared__ int s_cur[];
     const int b = blockIdx.y, sl = blockIdx.x, SL = gridDim.x;
     const int* hp = H + ((size_t)b * SL + sl) * S;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(1024) void inv_fill_kernel(int R_per_plot, int S, c
         for (int j = 0; j < 3; ++j)
             if (j == 0 || w[j] != 0.f) {
                 const int p = atomicAdd(&s_cur[knn_idx[r * 3 + j]], 1);
-                inv_row[p] = rl;
+                inv_row[p] = row_perm ? row_perm[r] : rl;          // where the row's d pre-activation is kept (sn2_fp.row_perm)
                 inv_w[p] = w[j] * inv;
             }
     }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
                                                           const float* __restrict__ dbetag, const float* __restrict__ h,
                                                           const float* __restrict__ dy, float* __restrict__ dp_out,
                                                           float* __restrict__ dW, float* __restrict__ db, int rep_k,
-                                                          int rep_stride) {
+                                                          int rep_stride, const int* __restrict__ row_perm, int R_per_plot) {
     constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 2, NV = 4 * (CB + 1);
     static_assert(CB > 0 && CB % 4 == 0, "skip quads");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [NV][NT]
@@ -799,12 +799,15 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
     for (long grp0 = ((long)blockIdx.x * (NT / 64) + wave) * U; grp0 < n_grp; grp0 += n_waves * U) {
         float4 hv[U], dv[U], sk[U][QB];
         bool valid[U];
-        unsigned rr[U];
+        unsigned rr[U], ro[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long row = (grp0 + u) * G + g;
             valid[u] = on && row < R;
             rr[u] = valid[u] ? (unsigned)row : 0u;
+            // where the row's d pre-activation goes: its own place, or its plot's row_perm[] place (the source pass gathers
+            // rows that are neighbours in space: along a space-filling curve they are neighbours in memory too)
+            ro[u] = row_perm ? (rr[u] / (unsigned)R_per_plot) * (unsigned)R_per_plot + (unsigned)row_perm[rr[u]] : rr[u];
             hv[u] = row_quad_ld<BF>(h, rr[u], HS, q);
             dv[u] = row_quad_ld<BF>(dy, rr[u], HS, q);
 #pragma unroll
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
                     aW[t][4 * b + 3] = fmaf(d4[t], sk[u][b].w, aW[t][4 * b + 3]);
                 }
             }
-            if (valid[u]) row_quad_st<BF>(dp_out, rr[u], HS, q, d4[0], d4[1], d4[2], d4[3]);
+            if (valid[u]) row_quad_st<BF>(dp_out, ro[u], HS, q, d4[0], d4[1], d4[2], d4[3]);
         }
     }
     // per-lane partials -> LDS (plain stores) -> one sum per element and workgroup -> global atomics
@@ -1498,14 +1501,14 @@ InterpIndex carve_interp_index(float* ws, int B, int Rp, int S) {
     return x;
 }
 int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_pos, int B, int Rp, int S, float* ws,
-                       hipStream_t st) {
+                       hipStream_t st, const int* row_perm = nullptr) {
     if (S > 8192) return SN2_ELIMIT;
     const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
     const InterpIndex x = carve_interp_index(ws, B, Rp, S);
     hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, x.H);
     hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, x.H, x.off, x.cnt);
     hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, (const int*)x.H,
-                       (const int*)x.off, x.inv_row, x.inv_w);
+                       (const int*)x.off, x.inv_row, x.inv_w, row_perm);
     hipLaunchKernelGGL(inv_order_kernel, dim3(B), dim3(1024), (size_t)((S + 3) & ~3) * 4, st,
                        reinterpret_cast<const float4*>(src_pos), S, (const int*)x.off, (const int*)x.cnt, x.items);
     SN2_RETURN_LAUNCH();
@@ -1568,8 +1571,9 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             hipLaunchKernelGGL(k1, dim3(2 * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
                                p->blk.gamma, (const float*)p->blk.mean, (const float*)p->blk.invstd,
                                (const float*)p->blk.dgamma, (const float*)p->blk.dbeta, (const float*)p->h, p->dy,
-                               p->du_scratch, p->blk.dW, p->blk.db, p->blk.grad_replicas, p->blk.grad_replica_stride);
-            if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, nullptr, B, Rp, S, p->scatter_ws, st));
+                               p->du_scratch, p->blk.dW, p->blk.db, p->blk.grad_replicas, p->blk.grad_replica_stride,
+                               p->row_perm, Rp);
+            if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, nullptr, B, Rp, S, p->scatter_ws, st, p->row_perm));
             const InterpIndex x = carve_interp_index(p->scatter_ws, B, Rp, S);
             // one source per wave (two per wave in half as many workgroups ran 30 % longer: the lists differ in length)
             int gs = sn2_cdiv(n_src, 4);
@@ -1590,7 +1594,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             SN2_RETURN_LAUNCH();
         }
     }
-    if (p->act_bf16) return SN2_ELIMIT;
+    if (p->act_bf16 || p->row_perm) return SN2_ELIMIT;    // (both belong to the source-side form above)
     constexpr size_t lds_bytes = (size_t)Acc::LDS_FLOATS * 4 * WAVES;
     auto kern = &fp_bwd_main_kernel<CA, CB, CO, KNN, WAVES>;
     if (lds_bytes > 48 * 1024)
@@ -1666,6 +1670,12 @@ extern "C" int sn2_interp_index(const int* knn_idx, const float* knn_w, const fl
                                 int S_per_plot, float* ws, void* stream) {
     if (!knn_idx || !knn_w || !ws || B <= 0 || R_per_plot <= 0 || S_per_plot <= 0) return SN2_EINVAL;
     return build_interp_index(knn_idx, knn_w, src_pos, B, R_per_plot, S_per_plot, ws, (hipStream_t)stream);
+}
+
+extern "C" int sn2_interp_index_perm(const int* knn_idx, const float* knn_w, const float* src_pos, const int* row_perm, int B,
+                                     int R_per_plot, int S_per_plot, float* ws, void* stream) {
+    if (!knn_idx || !knn_w || !ws || B <= 0 || R_per_plot <= 0 || S_per_plot <= 0) return SN2_EINVAL;
+    return build_interp_index(knn_idx, knn_w, src_pos, B, R_per_plot, S_per_plot, ws, (hipStream_t)stream, row_perm);
 }
 
 extern "C" int sn2_fp_forward(const sn2_fp* p, int training, void* stream) {

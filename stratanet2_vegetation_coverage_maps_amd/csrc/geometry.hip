@@ -153,120 +153,20 @@ __device__ __forceinline__ unsigned morton_cell(unsigned cx, unsigned cy, unsign
 
 // grid header per plot (32-bit words): [0..4096] first sorted position of every Morton cell (+ end), then lo.xyz, scale.xyz
 constexpr int GRID_WORDS = ORDER_CELLS + 1 + 6 + 1;   // padded to an even count
-// NT threads per plot (1024: 0.10 ms at N = 32768; 256 threads measured 0.18 ms and changed nothing else).
 // exchange area of the multi-workgroup FPS (fps_cluster_kernel): per plot FPS_XCHG_WORDS words of tagged granules, then
 // FPS_CTL_WORDS control words per launch (ticket counter, timeout count).  Zeroed HERE, by the kernel in front of every FPS
 // launch (a kernel boundary: visible to every workgroup behind it; the tags count super-rounds from 1, so 0 = nothing yet).
 constexpr int FPS_XCHG_WORDS = 4096, FPS_CTL_WORDS = 32;
-template <int NT>
-__global__ __launch_bounds__(NT) void spatial_order_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
-                                                             float4* __restrict__ sorted, int* __restrict__ grid,
-                                                             unsigned* __restrict__ xchg, unsigned* __restrict__ ctl) {
-    __shared__ int s_hist[ORDER_CELLS];
-    __shared__ float s_mm[6][NT / 64];
-    __shared__ int s_wsum[NT / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* px = pos + (size_t)b * 3 * N;
-    const float* py = px + N;
-    const float* pz = py + N;
-    if (xchg) {
-        for (int i = tid; i < FPS_XCHG_WORDS; i += NT) xchg[(size_t)b * FPS_XCHG_WORDS + i] = 0u;
-        if (b == 0 && tid < FPS_CTL_WORDS) ctl[tid] = 0u;
-    }
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += NT) {
-        const float v[3] = {px[i], py[i], pz[i]};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            mn[a] = fminf(mn[a], v[a]);
-            mx[a] = fmaxf(mx[a], v[a]);
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        mn[a] = wave_min(mn[a]);
-        mx[a] = wave_max(mx[a]);
-        if (lane == 0) {
-            s_mm[a][wave] = mn[a];
-            s_mm[3 + a][wave] = mx[a];
-        }
-    }
-    for (int i = tid; i < ORDER_CELLS; i += NT) s_hist[i] = 0;
-    __syncthreads();
-    float lo[3], sc[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float l = s_mm[a][0], h = s_mm[3 + a][0];
-        for (int k = 1; k < NT / 64; ++k) {
-            l = fminf(l, s_mm[a][k]);
-            h = fmaxf(h, s_mm[3 + a][k]);
-        }
-        lo[a] = l;
-        const float ext = fmaxf(h - l, 1e-6f);
-        sc[a] = (a < 2 ? (float)ORDER_GX : (float)ORDER_GZ) / ext;
-    }
-    auto cell_of = [&](int i) -> unsigned {
-        int cx = (int)((px[i] - lo[0]) * sc[0]), cy = (int)((py[i] - lo[1]) * sc[1]), cz = (int)((pz[i] - lo[2]) * sc[2]);
-        cx = cx < 0 ? 0 : (cx > ORDER_GX - 1 ? ORDER_GX - 1 : cx);
-        cy = cy < 0 ? 0 : (cy > ORDER_GX - 1 ? ORDER_GX - 1 : cy);
-        cz = cz < 0 ? 0 : (cz > ORDER_GZ - 1 ? ORDER_GZ - 1 : cz);
-        return morton_cell((unsigned)cx, (unsigned)cy, (unsigned)cz);
-    };
-    for (int i = tid; i < N; i += NT) atomicAdd(&s_hist[cell_of(i)], 1);
-    __syncthreads();
-    // exclusive scan over the cells: PER consecutive cells per thread, wave scan, 16 wave totals
-    constexpr int PER = ORDER_CELLS / NT;
-    int loc[PER], sum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        loc[k] = s_hist[tid * PER + k];
-        sum += loc[k];
-    }
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int k = 0; k < wave; ++k) base += s_wsum[k];
-    int run = base + incl - sum;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        s_hist[tid * PER + k] = run;
-        run += loc[k];
-    }
-    __syncthreads();
-    if (grid) {   // cell -> first sorted position (the ball query walks these cell lists)
-        int* gb = grid + (size_t)b * GRID_WORDS;
-        for (int i = tid; i < ORDER_CELLS; i += NT) gb[i] = s_hist[i];
-        if (tid == 0) {
-            gb[ORDER_CELLS] = N;
-            float* gf = reinterpret_cast<float*>(gb + ORDER_CELLS + 1);
-            gf[0] = lo[0]; gf[1] = lo[1]; gf[2] = lo[2]; gf[3] = sc[0]; gf[4] = sc[1]; gf[5] = sc[2];
-            gb[GRID_WORDS - 1] = 0;   // the pad word: nobody reads it, but a workspace handed on is defined in every word
-        }
-    }
-    __syncthreads();
-    int* ob = order + (size_t)b * N;
-    float4* sb = sorted + (size_t)b * N;
-    for (int i = tid; i < N; i += NT) {
-        const int p = atomicAdd(&s_hist[cell_of(i)], 1);
-        ob[p] = i;
-        sb[p] = make_float4(px[i], py[i], pz[i], INFINITY);   // .w = running FPS distance (fps_bucket_kernel)
-    }
-}
-
-// The same sort with U loads per coordinate in flight: the kernel above walks the points three times (bounding box, histogram,
-// scatter), N / 1024 trips each with three DEPENDENT loads per trip -- 71 us of load latency at N = 32 768, on the critical
-// path of every sn2_fps call.  Here a trip fetches U = 16 points per thread before it touches the first (two trips per pass at
-// N = 32 768); same arithmetic, same tables.  (All 32 points of a thread in registers at once spill at 1024 threads.)
+// One workgroup of 1024 threads per plot walks the points three times (bounding box, histogram, scatter); a trip fetches U = 16
+// points per thread before it touches the first (two trips per pass at N = 32 768; one DEPENDENT load per trip took 71 us,
+// all 32 points of a thread in registers at once spill at 1024 threads).  What is left (61 us) are the LDS atomics: 55 % of a
+// plot's points are ground points in a few cell layers, and a wave's adds onto one counter serialise.
+// rank (or NULL): rank[plot * N + i] = sorted position of point i -- the inverse of `order` (sn2_fp.row_perm)
 template <int U>
 __global__ __launch_bounds__(1024) void spatial_order_chunk_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
                                                                    float4* __restrict__ sorted, int* __restrict__ grid,
-                                                                   unsigned* __restrict__ xchg, unsigned* __restrict__ ctl) {
+                                                                   unsigned* __restrict__ xchg, unsigned* __restrict__ ctl,
+                                                                   int* __restrict__ rank) {
     constexpr int NT = 1024;
     __shared__ int s_hist[ORDER_CELLS];
     __shared__ float s_mm[6][NT / 64];
@@ -373,16 +273,18 @@ __global__ __launch_bounds__(1024) void spatial_order_chunk_kernel(const float* 
         const int p = atomicAdd(&s_hist[cell_of(vx, vy, vz)], 1);
         ob[p] = i;
         sb[p] = make_float4(vx, vy, vz, INFINITY);      // .w = running FPS distance
+        if (rank) rank[(size_t)b * N + i] = p;
     });
 }
 
 // the plot's Morton order, sorted table and cell starts (+ the zeroed exchange area)
 static void launch_spatial_order(const float* pos, int B, int N, int* order, float4* sorted, int* grid, unsigned* xchg,
                                  unsigned* ctl, hipStream_t st) {
+    int* rank = reinterpret_cast<int*>(ctl + FPS_CTL_WORDS);          // the last B*N words of the workspace
     if (N <= 8 * 1024)
-        hipLaunchKernelGGL(spatial_order_chunk_kernel<8>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl);
+        hipLaunchKernelGGL(spatial_order_chunk_kernel<8>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl, rank);
     else
-        hipLaunchKernelGGL(spatial_order_chunk_kernel<16>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl);
+        hipLaunchKernelGGL(spatial_order_chunk_kernel<16>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl, rank);
 }
 
 // canonical, monotone lower bound of sn2_d2(p, c) over all p inside the box [lo, hi]

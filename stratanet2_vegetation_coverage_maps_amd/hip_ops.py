@@ -135,7 +135,18 @@ def pack_rows(cloud: torch.Tensor, xyz: torch.Tensor, out: Optional[torch.Tensor
 
 def fps_ws_words(B: int, N: int) -> int:
     """SN2_FPS_WS_WORDS of include/strata_hip.h."""
-    return 5 * B * N + (4104 + 4096) * B + 32
+    return 6 * B * N + (4104 + 4096) * B + 32
+
+
+def fps_ws_ctl(ws: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    """The 32 control words of a filled FPS workspace ([1] = exchange waits of the multi-workgroup kernel that gave up: 0)."""
+    o = 5 * B * N + (4104 + 4096) * B
+    return ws[o:o + 32]
+
+
+def fps_ws_rank(ws: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    """The (B*N) int32 view of a filled FPS workspace that holds every point's position in the plot's spatial (Morton) order."""
+    return ws[5 * B * N + (4104 + 4096) * B + 32:]
 
 
 def fps_fills_ws(B: int, N: int, m: int) -> bool:
@@ -436,13 +447,16 @@ def interp_ws_words(B: int, R_per_plot: int, S_per_plot: int) -> int:
 
 
 def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[torch.Tensor] = None,
-                 src_pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 src_pos: Optional[torch.Tensor] = None, row_perm: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Inverted index of a 3-NN table (source -> list of (target row, normalised weight)): what the backward of the
     interpolation gathers through.  Position-only, so it can be built in the geometry pass.  src_pos (B*S,4): the
     source positions; given, the index also orders every plot's sources along a Morton curve (L2 locality of the
-    source-side backward)."""
+    source-side backward).  row_perm (B*R_per_plot) int32, a permutation of 0..R-1 per plot: the lists name row_perm[row]
+    instead of row -- where `fp_desc(..., row_perm=)` keeps the row's d pre-activation (include/strata_hip.h: sn2_fp.row_perm)."""
     if src_pos is not None:
         _chk(src_pos, F32, (B * S_per_plot, 4), "src_pos")
+    if row_perm is not None:
+        _chk(row_perm, I32, (B * R_per_plot,), "row_perm")
     R = B * R_per_plot
     _chk(knn[0], I32, (R, 3), "knn_idx")
     _chk(knn[1], F32, (R, 3), "knn_w")
@@ -451,7 +465,8 @@ def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[to
         out = torch.empty(n, dtype=F32, device=knn[0].device)
     else:
         _chk(out, F32, (n,), "out index")
-    _call("sn2_interp_index", _ptr(knn[0]), _ptr(knn[1]), _ptr(src_pos), B, R_per_plot, S_per_plot, _ptr(out), _stream())
+    _call("sn2_interp_index_perm", _ptr(knn[0]), _ptr(knn[1]), _ptr(src_pos), _ptr(row_perm), B, R_per_plot, S_per_plot, _ptr(out),
+          _stream(), key="sn2_interp_index")
     return out
 
 
@@ -460,7 +475,7 @@ SOURCE_SIDE = True     # False: never hand out src_ws, i.e. every row rebuilds i
 
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
             dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False, interp_index=None,
-            bn_sums_done=None) -> FP:
+            bn_sums_done=None, row_perm=None) -> FP:
     """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view.
     h of dtype bfloat16 (then dy and du_scratch too): the per-point layer stores its three activation buffers in bfloat16
     (include/strata_hip.h: sn2_fp.act_bf16; BASELINE config 5) -- only the source-side form of a layer of more than
@@ -515,6 +530,12 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     if SOURCE_SIDE and knn is not None and 0 < cb <= 16 and cb % 4 == 0 and R > 64 * _lib.STAT_SLOTS:
         d._src_ws = torch.empty(B * S_per_plot * hs, dtype=F32, device=src.device)
     d.src_ws = _ptr(d._src_ws)
+    d.row_perm = None
+    if row_perm is not None and d._src_ws is not None and du_scratch is not None:
+        # the backward pass keeps its d pre-activation rows in this order; the interp_index handed in must have been built
+        # with the same permutation
+        _chk(row_perm, I32, (R,), "row_perm")
+        d.row_perm = _ptr(row_perm)
     d.act_bf16 = int(AT == BF16)
     if d.act_bf16 and d._src_ws is None:
         raise ValueError("fp: bfloat16 activation rows need the source-side form (a k-NN layer of more than 65 536 rows)")

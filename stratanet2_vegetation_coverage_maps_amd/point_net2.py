@@ -226,11 +226,23 @@ class PointNet2(nn.Module):
                 raise ValueError(f"dropout_mask must have shape ({R},16)")
         return ops.dropout_mask_words(keep)
 
+    # Keep FP1's d pre-activation rows in the plots' Morton order (sn2_fp.row_perm).  OFF: measured at 16 x 32 768, the source
+    # pass's gather did not get faster (45.2 against 46.8 us: neighbouring sources already share an XCD's L2, and the pass is
+    # bound by the number of cache lines its gather instructions touch, not by where they come from), while the row pass's
+    # permuted stores cost 7.8 us (57.9 against 50.1).  The path stays tested (tests/test_gpu_network.py).
+    fp1_morton_rows = False
+
+    @staticmethod
+    def _fp1_source_side(rows):
+        """Whether the per-point layer FP1 runs in its source-side form (hip_ops.fp_desc hands out `src_ws`): only that form
+        keeps bfloat16 rows (`_act_dtype`) and a permuted d pre-activation buffer (`rank1`)."""
+        return bool(ops.SOURCE_SIDE) and rows > 64 * STAT_SLOTS
+
     def _act_dtype(self, rows):
         """Storage type of the three per-point activation buffers (FP1's output h1, the head's gradient dy1, FP1's
         d pre-activation): bfloat16 under `mma_dtype = "bf16"` where the per-point layer takes its source-side form (more
         than 64 * SN2_STAT_SLOTS rows), else fp32.  These 75 MB buffers are what the per-point kernels stream."""
-        return torch.bfloat16 if (self.mma_dtype == "bf16" and ops.SOURCE_SIDE and rows > 64 * STAT_SLOTS) else F32
+        return torch.bfloat16 if (self.mma_dtype == "bf16" and self._fp1_source_side(rows)) else F32
 
     def _sizes(self, N):
         M1 = ops.fps_num_samples(N, self.sa1_module.ratio)
@@ -248,6 +260,9 @@ class PointNet2(nn.Module):
         g.B, g.N, g.M1, g.M2 = B, N, M1, M2
         g.idx1, g.pos1_soa, g.pos1_aos = e(B, M1, dt=I32), e(B, 3, M1), e(B * M1, 4)
         g.ws1 = e(ops.fps_ws_words(B, N), dt=I32) if ops.fps_fills_ws(B, N, M1) else None
+        # every point's position along the plot's Morton curve (the level-1 FPS leaves it in its workspace): the order FP1's
+        # backward keeps its d pre-activation rows in (hip_ops.fp_desc: row_perm)
+        g.rank1 = ops.fps_ws_rank(g.ws1, B, N) if (self.fp1_morton_rows and g.ws1 is not None and self._fp1_source_side(B * N)) else None
         g.nbr1, g.cnt1 = e(B * M1, min(MAX_NEIGHBORS, N), dt=I32), e(B * M1, dt=I32)
         g.idx2, g.pos2_soa, g.pos2_aos = e(B, M2, dt=I32), e(B, 3, M2), e(B * M2, 4)
         g.ws2 = e(ops.fps_ws_words(B, M1), dt=I32) if ops.fps_fills_ws(B, M1, M2) else None
@@ -312,7 +327,7 @@ class PointNet2(nn.Module):
         with torch.cuda.stream(sc):                                        # (c) the per-point table
             ops.three_nn(g.pos1_soa, xyz, 3, out=g.knn1, ws=g.nn_ws[1])
             if inverted:
-                ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+                ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos, row_perm=g.rank1)
         g.has_inverted = bool(inverted)
         # (a)
         ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
@@ -349,6 +364,7 @@ class PointNet2(nn.Module):
             g.ord1, g.ord2 = e(ops.sa_order_len(B, M1), dt=I32), e(ops.sa_order_len(B, M2), dt=I32)
             g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1)))
             g.ws1 = g.ws2 = g.nn_ws = None
+            g.rank1 = gp.rank1[rn] if (gp.rank1 is not None and self._fp1_source_side(B * N)) else None
             g.ready = None
             halves.append(g)
         return gp, tuple(halves)
@@ -379,7 +395,7 @@ class PointNet2(nn.Module):
             ops.sa_order(g.cnt2, B, M2, out=g.ord2)
             ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
             ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
-            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos, row_perm=g.rank1)
         return halves
 
     def prefetch_geometry(self, cloud_data, lane: int = 0):
@@ -448,7 +464,7 @@ class PointNet2(nn.Module):
             # tables prefetched in eval mode, forward in training mode: the backward pass needs the inverted indices
             ops.interp_index(geo.knn3, B, M2, 1, out=geo.inv3)
             ops.interp_index(geo.knn2, B, M1, M2, out=geo.inv2)
-            ops.interp_index(geo.knn1, B, N, M1, out=geo.inv1, src_pos=geo.pos1_aos)
+            ops.interp_index(geo.knn1, B, N, M1, out=geo.inv1, src_pos=geo.pos1_aos, row_perm=getattr(geo, "rank1", None))
             geo.has_inverted = True
         s = _Saved()
         s.__dict__.update({k: v for k, v in geo.__dict__.items()
@@ -531,7 +547,7 @@ class PointNet2(nn.Module):
 
     def _fp1_desc(self, s, **kw):
         return ops.fp_desc(s.b_fp1, s.B, s.N, s.M1, 34, 8, s.h2, s.h1, src_affine=(s.b_fp2.a, s.b_fp2.c), knn=s.knn1,
-                           skip=s.rows0[:, 0:8], **kw)
+                           skip=s.rows0[:, 0:8], row_perm=getattr(s, "rank1", None), **kw)
 
     # ------------------------------------------------------------------------------------------ backward
     def _backward_impl(self, s, dcov, dproba):

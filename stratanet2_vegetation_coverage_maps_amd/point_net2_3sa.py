@@ -94,6 +94,7 @@ class PointNet2ThreeSA(PointNet2):
             g.tot1, g.tot2, g.tot3 = g.totals[0:1], g.totals[1:2], g.totals[2:3]
             g.inv4, g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M3, 1), (M2, M3), (M1, M2), (N, M1)))
             g.nn_ws = None
+            g.rank1 = gp.rank1[h * B * N:(h + 1) * B * N] if (gp.rank1 is not None and self._fp1_source_side(B * N)) else None
             g.ready = None
             halves.append(g)
         return gp, tuple(halves)
@@ -127,7 +128,7 @@ class PointNet2ThreeSA(PointNet2):
             ops.interp_index(g.knn4, B, M3, 1, out=g.inv4)
             ops.interp_index(g.knn3, B, M2, M3, out=g.inv3)
             ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
-            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos, row_perm=g.rank1)
         return halves
 
     def alloc_geometry(self, B, N, device=None):
@@ -153,6 +154,7 @@ class PointNet2ThreeSA(PointNet2):
         g.inv4, g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M3, 1), (M2, M3), (M1, M2), (N, M1)))
         g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S, T), dt=I32) if ops.three_nn_uses_grid(S, T) else None
                         for S, T in ((M3, M2), (M2, M1), (M1, N)))
+        g.rank1 = ops.fps_ws_rank(g.ws1, B, N) if (self.fp1_morton_rows and g.ws1 is not None and self._fp1_source_side(B * N)) else None       # as PointNet2.alloc_geometry
         g.ready = None
         return g
 
@@ -195,7 +197,7 @@ class PointNet2ThreeSA(PointNet2):
         ops.interp_index(g.knn4, B, M3, 1, out=g.inv4)
         ops.interp_index(g.knn3, B, M2, M3, out=g.inv3)
         ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
-        ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos)
+        ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos, row_perm=getattr(g, "rank1", None))
 
     def _stage_positions(self, cloud_data, dev):
         xyz_d = cloud_data["xyz"].to(device=dev, dtype=F32, non_blocking=True).contiguous()

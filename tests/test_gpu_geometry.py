@@ -58,7 +58,7 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
         i_c, cs_c, ca_c, ws_c = ops.fps(dev, M, start.to(DEV, torch.int32), waves=w, return_ws=True)
         assert torch.equal(i_c, i_f) and torch.equal(cs_c, cs_f), f"waves={w}"
         assert torch.equal(ca_c.view(B, M, 4)[..., :3], cs_f.permute(0, 2, 1)), f"waves={w}"
-        assert ws_c is None or int(ws_c[-31]) == 0, f"waves={w}: {int(ws_c[-31])} exchange waits timed out"
+        assert ws_c is None or int(ops.fps_ws_ctl(ws_c, B, N)[1]) == 0, f"waves={w}: exchange waits timed out"
     # the workspace is written in EVERY word (round 2 saw the pad word of the last plot's cell table keep the allocation's
     # old contents: no kernel reads it, but a buffer handed to other kernels should not hold undefined words): pre-fill two
     # buffers with different patterns -- whatever the kernel leaves untouched differs between them.  The order of duplicated
@@ -74,6 +74,8 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
         assert int((wa == 0x01010101).sum()) == 0 and int((wb == 0x7E7E7E7E).sum()) == 0
         assert torch.equal(wa[5 * B * N:5 * B * N + 4104 * B], wb[5 * B * N:5 * B * N + 4104 * B])    # cell starts, bounding boxes, pad words
         assert torch.equal(wa[:B * N].view(B, N).sort(1).values, wb[:B * N].view(B, N).sort(1).values)    # a permutation of 0..N-1
+        order, rank = wa[:B * N].view(B, N).long(), ops.fps_ws_rank(wa, B, N).view(B, N).long()               # and its inverse
+        assert torch.equal(torch.gather(rank, 1, order), torch.arange(N, device=DEV).expand(B, N))
     nbr8, cnt8, _ = ops.ball_query(dev, cs_8, 1.0, 64, fps_ws=ws8)
     nbr_f, cnt_f, _ = ops.ball_query(dev, cs_f, 1.0, 64)
     assert torch.equal(cnt8, cnt_f)
@@ -95,7 +97,7 @@ def test_bucketed_fps_on_dense_plots(B, N, M):
     assert torch.equal(i_b.cpu().long(), ref)
     for w in (16, 36, 72):                       # one workgroup per plot; 4 x 16 and 8 x 8 waves per plot
         i_w, cs_w, _, ws_w = ops.fps(xyz.to(DEV), M, start.to(DEV, torch.int32), waves=w, return_ws=True)
-        assert torch.equal(i_w, i_b) and torch.equal(cs_w, cs_b) and int(ws_w[-31]) == 0, f"waves={w}"
+        assert torch.equal(i_w, i_b) and torch.equal(cs_w, cs_b) and int(ops.fps_ws_ctl(ws_w, B, N)[1]) == 0, f"waves={w}"
     # the ball query and the 3-NN table over the same workspace, against their full scans
     nbr_g, cnt_g, _ = ops.ball_query(xyz.to(DEV), cs_b, 1.0, 2000, fps_ws=ws)
     nbr_f, cnt_f, _ = ops.ball_query(xyz.to(DEV), cs_b, 1.0, 2000)

@@ -297,11 +297,14 @@ def test_dense_plot_128k_points_vs_oracle():
     assert not fails, "\n".join(fails)
 
 
-def test_per_point_layer_source_side_form():
+@pytest.mark.parametrize("N", [24001, 24004])
+def test_per_point_layer_source_side_form(N):
     """FP1 above 65 536 rows runs in the source-side form (include/strata_hip.h: sn2_fp.src_ws): several plots, a plot
     size that is no multiple of the 7 rows a load instruction covers.  Checked against the oracle and against the
-    row-per-lane form of the same library on the same inputs (fp32 re-association only: 2e-5)."""
-    B, N = 3, 24001
+    row-per-lane form of the same library on the same inputs (fp32 re-association only: 2e-5).
+    N = 24004 (3 N a multiple of 4: the bucketed FPS fills its workspace): the backward pass also keeps its d pre-activation
+    rows in the plots' Morton order (sn2_fp.row_perm, the inverted index built over the permuted rows); N = 24001: it does not."""
+    B = 3
     args = make_args(subsample_size=N, ratio1=1024 / N, r1=1.0, ratio2=0.25, r2=2.0)
     d = make_batch(B, N, first_plot=31)
     sd = network.init_state_dict(5)
@@ -313,7 +316,9 @@ def test_per_point_layer_source_side_form():
         ops.SOURCE_SIDE = source_side
         try:
             m = _model(args, sd).train()
+            m.fp1_morton_rows = True               # (off by default: slower at the metric's size, point_net2.py)
             cov, proba = m(d)
+            assert (getattr(cov.grad_fn.saved, "rank1", None) is not None) == (source_side and N % 4 == 0)
             pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
             loss, _ = dev_losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
             loss.backward()
