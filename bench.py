@@ -206,20 +206,20 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
 
 # entry point -> the kernel that dominates it (names as rocprofv3 prints them, see profiles/*_pmc_traffic.json)
 DOMINANT_KERNEL = {
-    "sn2_fps:N=32768": "fps_spec_kernel<32, 16, 8>", "sn2_ball_query:N=32768": "ball_query_grid_kernel",
+    "sn2_fps:N=32768": "fps_cluster_kernel<8, 8, 8, true>", "sn2_ball_query:N=32768": "ball_query_grid_kernel",
     "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>",
-    "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34>",
-    "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512>",
-    "sn2_head_forward": "head_fwd_mfma_kernel", "sn2_head_backward": "head_bwd_kernel",
+    "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34, false>",
+    "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512, false>",
+    "sn2_head_forward": "head_fwd_mfma_kernel<false>", "sn2_head_backward": "head_bwd_kernel<false>",
     "sn2_three_nn:T=32768": "three_nn_grid_kernel", "sn2_pack_rows": "pack_rows_kernel",
 }
 
 
 # entry point -> all device kernels it launches (for the PMC traffic of the whole entry point, where it has several)
 ENTRY_KERNELS = {
-    "sn2_fp_backward:34+8->34": ["fp_bwd_rows_kernel<34, 8, 34, 512>", "fp_bwd_src_kernel<34, 8, 34>",
+    "sn2_fp_backward:34+8->34": ["fp_bwd_rows_kernel<34, 8, 34, 512, false>", "fp_bwd_src_kernel<34, 8, 34, false>",
                                  "fp_bwd_src_dw_kernel<34, 8, 34>", "fp_bwd_bn_kernel<34>"],
-    "sn2_fp_forward:34+8->34": ["fp_src_table_kernel<34, 8, 34>", "fp_fwd_rows_kernel<34, 8, 34>"],
+    "sn2_fp_forward:34+8->34": ["fp_src_table_kernel<34, 8, 34>", "fp_fwd_rows_kernel<34, 8, 34, false>"],
 }
 
 
@@ -784,7 +784,7 @@ def main():
                 # farthest point sampling: M strictly sequential arg-max rounds per plot -- what describes it is the time per
                 # sample and how little of the chip it occupies, not a bandwidth
                 roof_geo["us_per_sample"] = round(roof_geo["avg_ms"] * 1e3 / max(1, m1 - 1), 4)
-                roof_geo["workgroups"] = B * (2 if (pipe is not None and pipe.pair) else 1)
+                roof_geo["workgroups"] = B * 8           # the timed (unpipelined) form: eight workgroups per plot
                 roof_geo["compute_units"] = 256
                 roof_geo["bound"] = "latency"
             out["roofline_off_critical_path"] = roof_geo
