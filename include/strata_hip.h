@@ -36,6 +36,8 @@ int sn2_version(void);
 /* diagnostic (tests/test_gpu_bf16.py): D (16,16) = A (16,48) B (48,16) with bfloat16 operands through a K = 32 and a K = 16 MFMA
  * chained on one accumulator -- modes 0..4: csrc/misc.hip, debug_mfma_chain_kernel */
 int sn2_debug_mfma_chain(const float *a, const float *b, float *d, int mode, void *stream);
+/* diagnostic: `blocks` one-wave workgroups idle for `clocks` shader clocks each (s_sleep loop, bounded); out: NULL or one int */
+int sn2_debug_spin(int blocks, long long clocks, int *out, void *stream);
 
 /* ---- one (Linear -> ReLU -> BatchNorm1d) block, model/point_net2.py:45-53 -------------------------------- */
 typedef struct sn2_block {
@@ -198,12 +200,12 @@ typedef struct sn2_fp {
     const int *bn_sums_done;        /* non-NULL (the `ok` word of sn2_head_bn_sums / sn2_fp_bn_sums): blk.dgamma /
                                        blk.dbeta already hold this BatchNorm's gradients, sn2_fp_backward launches no
                                        pass over the rows for them.  NULL: it does                                  */
-    float *src_ws;                  /* workspace SN2_FP_SRC_WS_WORDS(B,S,cout) floats or NULL.  Given with knn_idx on a
+    float *src_ws;                  /* workspace SN2_FP_SRC_WS_WORDS(B,R,S,cout) floats or NULL.  Given with knn_idx on a
                                        layer of more than 64*SN2_STAT_SLOTS rows with cb % 4 == 0 (the per-point layer),
                                        everything linear in the interpolation is done once per SOURCE row: forward
-                                       gathers rows of T = W_A (sa*src+sc) kept here; backward keeps G[s] = sum of
-                                       w * d pre-activation over the rows interpolating s here (dsrc += G W_A,
-                                       dW_A += G^T (sa*src+sc)).  NULL: every row rebuilds its interpolated input.     */
+                                       gathers rows of T = W_A (sa*src+sc) kept here; backward keeps the partial sums of G[s] = sum of
+                                       w * d pre-activation over the rows interpolating s here, one row per 63 list
+                                       entries (dsrc += G W_A, dW_A += G^T (sa*src+sc)).  NULL: every row rebuilds its interpolated input.     */
     int act_bf16;                   /* non-zero (only with src_ws, i.e. on the per-point layer, and with bn_sums_done): the rows
                                        of h, dy and du_scratch are bfloat16 (same ELEMENT strides: 72-byte rows at cout = 34)
                                        -- BASELINE.json configs[4]: the three per-point activation buffers are what the step
@@ -215,11 +217,15 @@ typedef struct sn2_fp {
                                        of sn2_fps's workspace) the rows a source gathers lie close together: the gather of the
                                        source-side backward runs out of L2 instead of fetching every row three times          */
 } sn2_fp;
-#define SN2_FP_SRC_WS_WORDS(B, S, cout) ((size_t)(B) * (S) * ((((cout) + 3) / 4) * 4))
+/* chunks of at most 63 list entries an inverted 3-NN index of R rows over S sources can have, per plot (+ one slot per
+ * source: every list's last chunk may be short) */
+#define SN2_INTERP_CHUNKS(R, S) ((3 * (size_t)(R) + 62) / 63 + (size_t)(S))
+#define SN2_FP_SRC_WS_WORDS(B, R, S, cout) ((size_t)(B) * SN2_INTERP_CHUNKS(R, S) * ((((cout) + 3) / 4) * 4))
 /* The transpose of knn_interpolate (its backward) is done as a gather through an inverted index of the 3-NN table:
  * source -> list of (target row, normalised weight).  The index depends on positions only, so it can be built ahead of
  * the backward pass (in the geometry pass) with sn2_interp_index; otherwise sn2_fp_backward builds it itself. */
-#define SN2_INTERP_WS_WORDS(B, R, S) ((size_t)(B) * (S) * (((R) + 2047) / 2048 + 6) + 6 * (size_t)(B) * (R) + 64)
+#define SN2_INTERP_WS_WORDS(B, R, S) \
+    ((size_t)(B) * (S) * (((R) + 2047) / 2048 + 6) + 6 * (size_t)(B) * (R) + 64 + 4 * (size_t)(B) * SN2_INTERP_CHUNKS(R, S))
 /* src_pos: (B*S,4) x,y,z,- rows of the SOURCE positions or NULL.  Given, the index also holds the sources of every plot
  * in Morton order, and the source-side backward (sn2_fp.src_ws) walks them in that order, one stretch per XCD, so that
  * target rows shared by neighbouring sources stay in that XCD's L2. */

@@ -19,10 +19,18 @@ inp = {"cloud": h["cloud"].to(dev), "xyz": h["xyz"].to(dev), "fps_start": torch.
        "gt": h["coverages"].to(dev), "pdf": h["pdf_all"].to(dev)}
 geo = model.alloc_geometry(B, N, dev)
 model._geometry(inp["xyz"], inp["fps_start"], out=geo, fork=False)
-xyz2 = torch.cat([inp["xyz"], inp["xyz"]]).contiguous()
-fs2 = torch.zeros(2 * B, dtype=torch.int32, device=dev)
-gp = model.alloc_geometry(2 * B, N, dev)
+# the load: FPS passes over LOAD_PLOTS plots (one 8-wave workgroup = one CU each; default 32 = the pipelined loop's pair pass)
+LP = int(os.environ.get("LOAD_PLOTS", "32"))
+xyz2 = torch.cat([inp["xyz"], inp["xyz"]])[:LP].contiguous()
+fs2 = torch.zeros(LP, dtype=torch.int32, device=dev)
+gp = model.alloc_geometry(LP, N, dev)
+# DUMMY_STREAMS streams created (and used once) before the load's stream: moves it to another hardware queue
+_dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("DUMMY_STREAMS", "0")))]
+for _s in _dummies:
+    with torch.cuda.stream(_s):
+        torch.zeros(1, device=dev)
 side = torch.cuda.Stream()
+SPIN = int(os.environ.get("SPIN", "0"))
 
 
 def fstep():
@@ -40,8 +48,13 @@ def timed(n, load):
     torch.cuda.synchronize()
     if load:
         with torch.cuda.stream(side):
-            for _ in range(load):
-                ops.fps(xyz2, 1024, fs2, out=(gp.idx1, gp.pos1_soa, gp.pos1_aos, gp.ws1))
+            if SPIN:
+                # SPIN = "blocks": idle one-wave workgroups for the whole timed stretch (60 ms) instead of FPS passes
+                from stratanet2_vegetation_coverage_maps_amd import _lib
+                _lib.check(_lib.load().sn2_debug_spin(SPIN, int(60e-3 * 2.4e9), None, torch.cuda.current_stream().cuda_stream), "spin")
+            else:
+                for _ in range(load):
+                    ops.fps(xyz2, 1024, fs2, out=(gp.idx1, gp.pos1_soa, gp.pos1_aos, gp.ws1), waves=8)
     with ops.timing() as t:
         for _ in range(n):
             fstep()

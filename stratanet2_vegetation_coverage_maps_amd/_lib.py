@@ -2,7 +2,7 @@
 is missing the product path raises."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_double, c_float, c_int, c_long, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_long, c_longlong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libstrata_hip.so")
@@ -52,6 +52,7 @@ class Head(Structure):  # sn2_head
 SIGNATURES = {
     "sn2_version": [],
     "sn2_debug_mfma_chain": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "sn2_debug_spin": [c_int, c_longlong, c_void_p, c_void_p],
     "sn2_pack_rows": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_fps": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_fps_waves": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],

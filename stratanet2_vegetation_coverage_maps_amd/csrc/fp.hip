@@ -426,68 +426,107 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-__global__ __launch_bounds__(1024) void inv_order_kernel(const float4* __restrict__ pos, int S, const int* __restrict__ off,
-                                                         const int* __restrict__ cnt, int4* __restrict__ items) {
-    extern __shared__ __attribute__((aligned(16))) unsigned s_key[];   // [S rounded up to 4] + 6 floats of bounding box
+//    F  the lists cut into CHUNKS of at most INV_CHUNK entries, in the same order: chunks[plot*CM + j] = {source id, offset of
+//    the chunk's first entry, its length, plot}, CM = inv_chunks_per_plot (unused slots: length 0), and items[].w = the plot-local
+//    number of the source's first chunk.  The lists are anything but even (C2: median 25 entries, a tenth of the sources
+//    500-800: the synthetic stands are clumped like real ones), and a wave per SOURCE left the source pass waiting for a few
+//    waves that walk 13 chunks one after the other; a wave per CHUNK has one short chain for everybody.
+constexpr int INV_CHUNK = 63;
+__host__ __device__ constexpr int inv_chunks_per_plot(int Rp, int S) { return (3 * Rp + INV_CHUNK - 1) / INV_CHUNK + S; }
+
+__global__ __launch_bounds__(1024) void inv_order_kernel(const float4* __restrict__ pos, int S, int CM, const int* __restrict__ off,
+                                                         const int* __restrict__ cnt, int4* __restrict__ items,
+                                                         int4* __restrict__ chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned s_key[];   // [S rounded up to 4] keys | [S] source of every rank
     __shared__ float s_lo[3][16], s_hi[3][16];
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* pb = pos + (size_t)b * S;
-    if (!pos) {                                                        // no positions: identity
-        for (int i = threadIdx.x; i < S; i += 1024) {
-            const int id = b * S + i;
-            items[id] = make_int4(id, off[id], cnt[id], 0);
-        }
-        return;
-    }
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int i = threadIdx.x; i < S; i += 1024) {
-        const float4 p = pb[i];
-        lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
-        hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
-            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
-        }
-        if (lane == 0) s_lo[a][wave] = lo[a], s_hi[a][wave] = hi[a];
-    }
-    __syncthreads();
-    float sc[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float l = s_lo[a][0], h = s_hi[a][0];
-        for (int w = 1; w < 16; ++w) l = fminf(l, s_lo[a][w]), h = fmaxf(h, s_hi[a][w]);
-        lo[a] = l;
-        sc[a] = h > l ? 1023.999f / (h - l) : 0.f;
-    }
     const int S4 = (S + 3) & ~3;
-    for (int i = threadIdx.x; i < S4; i += 1024) {
-        unsigned key = 0xFFFFFFFFu;                                    // padding sorts last
-        if (i < S) {
+    int* s_ord = reinterpret_cast<int*>(s_key + S4);
+    if (pos) {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int i = threadIdx.x; i < S; i += 1024) {
             const float4 p = pb[i];
-            const unsigned qx = (unsigned)((p.x - lo[0]) * sc[0]), qy = (unsigned)((p.y - lo[1]) * sc[1]),
-                           qz = (unsigned)((p.z - lo[2]) * sc[2]);
-            key = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+            lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
+            hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
         }
-        s_key[i] = key;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+            }
+            if (lane == 0) s_lo[a][wave] = lo[a], s_hi[a][wave] = hi[a];
+        }
+        __syncthreads();
+        float sc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float l = s_lo[a][0], h = s_hi[a][0];
+            for (int w = 1; w < 16; ++w) l = fminf(l, s_lo[a][w]), h = fmaxf(h, s_hi[a][w]);
+            lo[a] = l;
+            sc[a] = h > l ? 1023.999f / (h - l) : 0.f;
+        }
+        for (int i = threadIdx.x; i < S4; i += 1024) {
+            unsigned key = 0xFFFFFFFFu;                                    // padding sorts last
+            if (i < S) {
+                const float4 p = pb[i];
+                const unsigned qx = (unsigned)((p.x - lo[0]) * sc[0]), qy = (unsigned)((p.y - lo[1]) * sc[1]),
+                               qz = (unsigned)((p.z - lo[2]) * sc[2]);
+                key = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+            }
+            s_key[i] = key;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < S; i += 1024) {
+            const unsigned mine = s_key[i];
+            int rank = 0;
+            for (int j = 0; j < S4; j += 4) {
+                const uint4 o = *reinterpret_cast<const uint4*>(&s_key[j]);
+                rank += (o.x < mine || (o.x == mine && j < i)) ? 1 : 0;
+                rank += (o.y < mine || (o.y == mine && j + 1 < i)) ? 1 : 0;
+                rank += (o.z < mine || (o.z == mine && j + 2 < i)) ? 1 : 0;
+                rank += (o.w < mine || (o.w == mine && j + 3 < i)) ? 1 : 0;
+            }
+            s_ord[rank] = i;
+        }
+    } else {                                                           // no positions: identity
+        for (int i = threadIdx.x; i < S; i += 1024) s_ord[i] = i;
     }
+    if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < S; i += 1024) {
-        const unsigned mine = s_key[i];
-        int rank = 0;
-        for (int j = 0; j < S4; j += 4) {
-            const uint4 o = *reinterpret_cast<const uint4*>(&s_key[j]);
-            rank += (o.x < mine || (o.x == mine && j < i)) ? 1 : 0;
-            rank += (o.y < mine || (o.y == mine && j + 1 < i)) ? 1 : 0;
-            rank += (o.z < mine || (o.z == mine && j + 2 < i)) ? 1 : 0;
-            rank += (o.w < mine || (o.w == mine && j + 3 < i)) ? 1 : 0;
+    for (int k0 = 0; k0 < S; k0 += 1024) {
+        const int k = k0 + threadIdx.x;
+        int id = 0, o = 0, n = 0, nch = 0;
+        if (k < S) {
+            id = b * S + s_ord[k];
+            o = off[id], n = cnt[id];
+            nch = (n + INV_CHUNK - 1) / INV_CHUNK;
         }
-        const int id = b * S + i;
-        items[(size_t)b * S + rank] = make_int4(id, off[id], cnt[id], 0);
+        int incl = nch;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int base = s_carry;
+        for (int w = 0; w < wave; ++w) base += s_w[w];
+        const int first = base + incl - nch;
+        if (k < S) {
+            items[(size_t)b * S + k] = make_int4(id, o, n, first);
+            for (int c = 0; c < nch; ++c)
+                chunks[(size_t)b * CM + first + c] = make_int4(id, o + c * INV_CHUNK, min(INV_CHUNK, n - c * INV_CHUNK), b);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = base + incl;
+        __syncthreads();
     }
+    for (int j = s_carry + threadIdx.x; j < CM; j += 1024) chunks[(size_t)b * CM + j] = make_int4(0, 0, 0, 0);
 }
 
 template <int CA>
@@ -759,6 +798,34 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
     }
 }
 
+// Where the d pre-activation rows of the source-side backward live (du_scratch).  With 33 or 34 channels a 36-float row
+// straddles two 128-byte lines nearly always, and the source pass -- which gathers single rows from all over a 75 MB array --
+// fetched both: 135 MB over the fabric for 75 MB of rows (PMC, round 3).  SPLIT layout for those widths: channels 0..31 of
+// row r as ONE aligned line at main[r * 32] (bfloat16: 64 bytes), channels 32, 33 as a pair at side[r * 2] behind the
+// R main rows (4.2 MB for the metric's batch: it stays in L2).  Other widths: plain rows of HS.
+template <int CO>
+constexpr bool dp_split() { return CO > 32 && CO <= 34; }
+template <bool BF>
+__device__ __forceinline__ void dp_side_st(float* __restrict__ dp, size_t R, size_t row, float a, float b) {
+    if constexpr (BF) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 v;
+        v[0] = (__bf16)a; v[1] = (__bf16)b;
+        reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(dp) + R * 32)[row] = __builtin_bit_cast(unsigned, v);
+    } else {
+        reinterpret_cast<float2*>(dp + R * 32)[row] = make_float2(a, b);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ float2 dp_side_ld(const float* __restrict__ dp, size_t R, size_t row) {
+    if constexpr (BF) {
+        const unsigned u = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(dp) + R * 32)[row];
+        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u));
+    } else {
+        return reinterpret_cast<const float2*>(dp + R * 32)[row];
+    }
+}
+
 // rows: dp = relu'/BN backward of dy (stored, row stride HS, pad channels 0), dW_B | db
 template <int CA, int CB, int CO, int NT, bool BF>
 __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride, float invR, const float* __restrict__ skip,
@@ -832,7 +899,12 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
                     aW[t][4 * b + 3] = fmaf(d4[t], sk[u][b].w, aW[t][4 * b + 3]);
                 }
             }
-            if (valid[u]) row_quad_st<BF>(dp_out, ro[u], HS, q, d4[0], d4[1], d4[2], d4[3]);
+            if constexpr (dp_split<CO>()) {
+                if (valid[u] && q < 8) row_quad_st<BF>(dp_out, ro[u], 32, q, d4[0], d4[1], d4[2], d4[3]);
+                if (valid[u] && q == 8) dp_side_st<BF>(dp_out, (size_t)R, ro[u], d4[0], d4[1]);
+            } else {
+                if (valid[u]) row_quad_st<BF>(dp_out, ro[u], HS, q, d4[0], d4[1], d4[2], d4[3]);
+            }
         }
     }
     // per-lane partials -> LDS (plain stores) -> one sum per element and workgroup -> global atomics
@@ -854,145 +926,249 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
     (void)NV;
 }
 
-// sources: G[s] = sum over the inverted list of w * dp[row] (QH lanes per entry, 64/QH entries per load instruction),
-// stored for the dW_A pass; dsrc[s] += G[s] W_A
+// Source pass of the source-side backward: G[s] = sum over the inverted list of s of w * d pre-activation row.
+// The unit of work is a CHUNK of a list (inv_order_kernel's chunk table: at most INV_CHUNK entries = one load of row numbers,
+// one of weights, STEPS row gathers in flight per lane), and a wave owns L CONSECUTIVE slots of the chunk table, wave w the
+// slots [w L, (w + 1) L): it loads their headers with one instruction, and the row numbers of the next chunk travel together
+// with the gathers of this one -- one memory round trip per chunk instead of three, the same short chain for
+// every wave whatever the lists look like (a wave per SOURCE waited for the few sources whose lists are 13 chunks long:
+// C2's lists have a median of 25 entries and a tenth of them 500-800).  Sums run on across the chunks of one source and are
+// written out as a partial row Gpart[slot] at the source's last chunk and at the wave's last slot;
+// fp_bwd_src_merge_dw_kernel adds a source's partial rows in slot order (and applies G to dsrc and dW_A).
 template <int CA, int CB, int CO, bool BF>
-__global__ __launch_bounds__(256) void fp_bwd_src_kernel(int n_src, int R_per_plot, int S, int dsrc_stride,
-                                                         const int4* __restrict__ items, const int* __restrict__ inv_row,
-                                                         const float* __restrict__ inv_w, const float* __restrict__ dp,
-                                                         const float* __restrict__ Wg, float* __restrict__ Gout,
-                                                         float* __restrict__ dsrc) {
-    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, STEPS = 64 / G, CH = G * STEPS;
-    __shared__ float s_W[CO * CA];
-    __shared__ __attribute__((aligned(16))) float s_part[4][G][HS];
-    __shared__ float s_G[4][HS];
-    constexpr int WREG = (CO * CA + 255) / 256;
-    float wreg[WREG];                                   // W_A on its way to LDS: only the last phase needs it
-#pragma unroll
-    for (int i = 0; i < WREG; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        wreg[i] = e < CO * CA ? Wg[(e / CA) * CI + (e % CA)] : 0.f;
-    }
-    bool w_staged = false;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane % QH, g = lane / QH;
-    const bool on = lane < G * QH;
-    // workgroups go to the XCDs round-robin: XCD x walks the stretch [x, x+1) * n_src/8 of the Morton order, its
-    // workgroups side by side (gridDim.x is a multiple of 8)
+__global__ __launch_bounds__(256) void fp_bwd_src_chunk_kernel(int n_chunks, int L, int R_total, int R_per_plot, int S,
+                                                               const int4* __restrict__ chunks, const int* __restrict__ inv_row,
+                                                               const float* __restrict__ inv_w, const float* __restrict__ dp,
+                                                               float* __restrict__ Gpart) {
+    constexpr bool SPLIT = dp_split<CO>();
+    constexpr int QH = (CO + 3) / 4, HS = 4 * QH, QM = SPLIT ? 8 : QH, RS = SPLIT ? 32 : HS, G = 64 / QM, STEPS = 64 / G;
+    constexpr unsigned EB = BF ? 2u : 4u, ROWB = RS * EB;                   // bytes per element / per row
+    static_assert(G * STEPS >= INV_CHUNK, "a chunk is one round of gathers");
+    static_assert(STEPS % 2 == 0, "two halves");
+    __shared__ __attribute__((aligned(16))) float s_part[SPLIT ? 1 : 4][G][HS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: SGPRs)
+    const int q = lane % QM, g = lane / QM;
+    const bool on = lane < G * QM;
+    const unsigned qoff = (unsigned)q * 4u * EB;
+    // workgroups go to the XCDs round-robin; the waves of one XCD own consecutive stretches of the table (plots one after the
+    // other, each along its sources' Morton order): neighbouring sources share target rows, and so an L2 (gridDim.x % 8 == 0)
     const int xcd = blockIdx.x & 7, wg_x = blockIdx.x >> 3, n_wg_x = gridDim.x >> 3;
-    const int p_lo = (int)((long)n_src * xcd / 8), p_hi = (int)((long)n_src * (xcd + 1) / 8);
-    for (int pp0 = p_lo + wg_x * 4; pp0 < p_hi; pp0 += n_wg_x * 4) {   // the same trip count for the four waves
-        const int pp = pp0 + wave;
-        const bool active = pp < p_hi;
-        const int4 item = active ? items[pp] : make_int4(0, 0, 0, 0);
-        const int s = __builtin_amdgcn_readfirstlane(item.x), st = __builtin_amdgcn_readfirstlane(item.y),
-                  n = __builtin_amdgcn_readfirstlane(item.z);
-        const int b = s / S;
-        const float d_old = (lane < CA && active) ? dsrc[(size_t)s * dsrc_stride + lane] : 0.f;   // early: off the chain
-        const float* dpb = BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(dp) + (size_t)b * R_per_plot * HS)
-                              : dp + (size_t)b * R_per_plot * HS;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int base = 0; base < n; base += CH) {
-            const int m = (n - base) < CH ? (n - base) : CH;
-            const int rj = lane < m ? inv_row[st + base + lane] : 0;       // entries past the end: row 0 with weight 0
-            const float wj = lane < m ? inv_w[st + base + lane] : 0.f;
-            float4 v[STEPS];
-            float wv[STEPS];
+    const long r0 = ((long)(xcd * n_wg_x + wg_x) * 4 + wave) * L;
+    if (r0 >= n_chunks) return;                              // (no workgroup barriers in this kernel)
+    const int nk = (n_chunks - r0) < L ? (int)(n_chunks - r0) : L;
+    const int4 it = lane < nk ? chunks[r0 + lane] : make_int4(0, 0, 0, 0);       // L <= 64
+    // (the headers are awaited HERE, once: left to the loop, the wait at its top also sits out every partial row's store)
+    if (__builtin_amdgcn_readlane(it.z, 0) == 0 && __builtin_amdgcn_readlane(it.z, nk - 1) == 0) return;   // padding only
+    int id = 0, pb = 0, m = 0, rj = 0;                               // round k = -1 only fetches the entries of chunk 0
+    float wj = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, sa0 = 0.f, sa1 = 0.f;
+    // one round of gathers: NS steps of G entries (entries past the chunk's end: row 0 with weight 0)
+    auto gather = [&](auto ns, const char* __restrict__ base) {
+        constexpr int NS = decltype(ns)::value;
+        float4 v[NS];
+        float wv[NS];
 #pragma unroll
-            for (int j = 0; j < STEPS; ++j) {
-                const int e = G * j + g;
-                const int r = __shfl(rj, e);
-                const float w = __shfl(wj, e);
-                wv[j] = on ? w : 0.f;
-                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (G * j < m) v[j] = row_quad_ld<BF>(dpb, (size_t)r, HS, q);
-            }
-#pragma unroll
-            for (int j = 0; j < STEPS; ++j) {
-                acc[0] = fmaf(wv[j], v[j].x, acc[0]);
-                acc[1] = fmaf(wv[j], v[j].y, acc[1]);
-                acc[2] = fmaf(wv[j], v[j].z, acc[2]);
-                acc[3] = fmaf(wv[j], v[j].w, acc[3]);
+        for (int j = 0; j < NS; ++j) {
+            const int e = G * j + g;
+            const unsigned r = (unsigned)__shfl(rj, e);
+            wv[j] = __shfl(wj, e);
+            if constexpr (!SPLIT) wv[j] = on ? wv[j] : 0.f;
+            const unsigned off = r * ROWB + qoff;
+            if constexpr (BF) {
+                const uint2 u = *reinterpret_cast<const uint2*>(base + off);
+                v[j] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                                   __uint_as_float(u.y & 0xFFFF0000u));
+            } else {
+                v[j] = *reinterpret_cast<const float4*>(base + off);
             }
         }
-        if (on) *reinterpret_cast<float4*>(&s_part[wave][g][4 * q]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < HS) {
-            float gk = 0.f;
 #pragma unroll
-            for (int gg = 0; gg < G; ++gg) gk += s_part[wave][gg][lane];
-            s_G[wave][lane] = gk;
-            if (active) Gout[(size_t)s * HS + lane] = gk;
+        for (int j = 0; j < NS; ++j) {
+            acc[0] = fmaf(wv[j], v[j].x, acc[0]);
+            acc[1] = fmaf(wv[j], v[j].y, acc[1]);
+            acc[2] = fmaf(wv[j], v[j].z, acc[2]);
+            acc[3] = fmaf(wv[j], v[j].w, acc[3]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (!w_staged) {
+    };
+    for (int k = -1; k < nk; ++k) {
+        int id_n = 0, st_n = 0, m_n = 0, pb_n = 0;
+        if (k + 1 < nk) {
+            id_n = __builtin_amdgcn_readlane(it.x, k + 1);
+            pb_n = __builtin_amdgcn_readlane(it.w, k + 1);
+            st_n = __builtin_amdgcn_readlane(it.y, k + 1);
+            m_n = __builtin_amdgcn_readlane(it.z, k + 1);
+        }
+        // the next chunk's entries first: in flight together with this chunk's gathers (loads return in order)
+        const int rj_n = lane < m_n ? inv_row[st_n + lane] : 0;          // entries past the end: row 0 with weight 0
+        const float wj_n = lane < m_n ? inv_w[st_n + lane] : 0.f;
+        if (m > 0) {
+            const size_t row0 = (size_t)pb * R_per_plot;
+            const char* base = reinterpret_cast<const char*>(dp) + row0 * ROWB;
+            float2 sv = make_float2(0.f, 0.f);
+            if constexpr (SPLIT) sv = dp_side_ld<BF>(dp, (size_t)R_total, row0 + rj);   // this lane's own entry
+            if (m > G * STEPS / 2) gather(std::integral_constant<int, STEPS>{}, base);
+            else gather(std::integral_constant<int, STEPS / 2>{}, base);
+            sa0 = fmaf(wj, sv.x, sa0);
+            sa1 = fmaf(wj, sv.y, sa1);
+            if (m_n == 0 || id_n != id) {                    // the source's last chunk, or this wave's last: a partial row
+                float* out = Gpart + (size_t)(r0 + k) * HS;
+                if constexpr (SPLIT) {
+                    // eight lanes per entry: the entries of a step differ in lane bits 3..5
 #pragma unroll
-            for (int i = 0; i < WREG; ++i) {
-                const int e = threadIdx.x + 256 * i;
-                if (e < CO * CA) s_W[e] = wreg[i];
+                    for (int t = 0; t < 4; ++t) {
+                        acc[t] += __int_as_float(SN2_DPP(__float_as_int(acc[t]), 0x128, 0xF));     // row_ror:8 = lane ^ 8
+                        acc[t] += __shfl_xor(acc[t], 16);
+                        acc[t] += __shfl_xor(acc[t], 32);
+                    }
+                    const float s0 = wave_sum(sa0), s1 = wave_sum(sa1);
+                    if (lane < 8) reinterpret_cast<float4*>(out)[lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    if (lane == 8) reinterpret_cast<float4*>(out)[8] = make_float4(s0, s1, 0.f, 0.f);
+                } else {
+                    if (on) *reinterpret_cast<float4*>(&s_part[wave][g][4 * q]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < HS) {
+                        float gk = 0.f;
+#pragma unroll
+                        for (int gg = 0; gg < G; ++gg) gk += s_part[wave][gg][lane];
+                        out[lane] = gk;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+                sa0 = sa1 = 0.f;
             }
-            __syncthreads();
-            w_staged = true;
         }
-        if (lane < CA && active) {
-            float d = 0.f;
-#pragma unroll
-            for (int o = 0; o < CO; ++o) d = fmaf(s_G[wave][o], s_W[o * CA + lane], d);
-            dsrc[(size_t)s * dsrc_stride + lane] = d_old + d;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        rj = rj_n, wj = wj_n, id = id_n, pb = pb_n, m = m_n;
     }
 }
 
-// dW_A += sum_s G[s]^T (a o src[s] + c): one source row per lane, rows = MFMA K
+// What G[s] is for, 64 sources per workgroup in the order of the item table, one per lane of EVERY wave: the four
+// waves add up the sources' partial rows (in slot order, a quarter of the channels each) and then each does a quarter of the
+// rest: dsrc[s][k] += sum_o G[s][o] W_A[o][k] for its quarter of the channels k (the weights through scalar loads), and
+// dW_A[:, 16 w .. 16 w + 15] += sum_s G[s]^T (a o src[s] + c) for its 16 columns (rows = MFMA K).  (One wave doing all of it
+// for its 64 sources was one long chain per CU: 18 us.)
 template <int CA, int CB, int CO>
-__global__ __launch_bounds__(256) void fp_bwd_src_dw_kernel(int n_src, int src_stride, const float* __restrict__ src,
-                                                            const float* __restrict__ src_a, const float* __restrict__ src_c,
-                                                            const float* __restrict__ Gin, float* __restrict__ dW,
-                                                            int rep_k, int rep_stride) {
-    constexpr int CI = CA + CB, HS = 4 * ((CO + 3) / 4);
-    using Acc = OuterAcc<CO, CA, 32>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lds = smem + (threadIdx.x >> 6) * Acc::LDS_FLOATS;
-    Acc acc;
-    acc.init(lds);
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = s < n_src;
-    const size_t ss = valid ? (size_t)s : 0;
-    float p[CO], x[CA];
-    const float4* gr = reinterpret_cast<const float4*>(Gin + ss * HS);
+__global__ __launch_bounds__(256) void fp_bwd_src_merge_dw_kernel(int n_src, int S, int CM, int src_stride, int dsrc_stride,
+                                                                  const int4* __restrict__ items, const float* __restrict__ src,
+                                                                  const float* __restrict__ src_a, const float* __restrict__ src_c,
+                                                                  const float* __restrict__ Gpart, const float* __restrict__ Wg,
+                                                                  float* __restrict__ dsrc, float* __restrict__ dW, int rep_k,
+                                                                  int rep_stride, int L) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, TK = (CA + 15) / 16, KQ = (CA + 3) / 4;
+    static_assert(TK <= 4, "a wave per 16 columns of dW_A");
+    static_assert(KQ <= CA, "a window of KQ columns fits a row");
+    using Acc = OuterAcc<CO, 16, 32>;
+    static_assert(CO * 16 <= Acc::LDS_FLOATS, "a wave's image fits its staging region");
+    __shared__ __attribute__((aligned(16))) float smem[4 * Acc::LDS_FLOATS];
+    __shared__ float s_p[HS * 64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* lds = smem + w * Acc::LDS_FLOATS;
+    const int pp = blockIdx.x * 64 + lane;
+    const bool valid = pp < n_src;
+    const int4 item = valid ? items[pp] : make_int4(0, 0, 0, 0);
+    const size_t ss = (size_t)item.x;
+    // what comes from memory at the END of the chain is asked for now: the old values of this wave's quarter of dsrc[s] ..
+    float* dr = dsrc + ss * dsrc_stride;
+    float d_old[KQ];
+    const int k0 = w * KQ + KQ <= CA ? w * KQ : CA - KQ;     // (the last wave's window of KQ columns is pulled back inside the row)
 #pragma unroll
-    for (int q4 = 0; q4 < (CO + 3) / 4; ++q4) {
-        const float4 a = gr[q4];
-        const float v[4] = {a.x, a.y, a.z, a.w};
+    for (int i = 0; i < KQ; ++i) d_old[i] = valid ? dr[k0 + i] : 0.f;
+    // .. and this wave's columns of (a o src + c)
+    float x[16];
+    if (w < TK) {
+        const float4* sr = reinterpret_cast<const float4*>(src + ss * src_stride);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (4 * q4 + t < CO) p[4 * q4 + t] = valid ? v[t] : 0.f;
+        for (int q4 = 0; q4 < 4; ++q4) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * (4 * w + q4) < CA) a = sr[4 * w + q4];
+            x[4 * q4] = a.x, x[4 * q4 + 1] = a.y, x[4 * q4 + 2] = a.z, x[4 * q4 + 3] = a.w;
+        }
     }
-    const float4* sr = reinterpret_cast<const float4*>(src + ss * src_stride);
+    // the source's chunks are the slots [f, f + nch) of the chunk table; its partial rows: at its last slot and at every
+    // slot that is the last of a wave of fp_bwd_src_chunk_kernel (slot % L == L - 1).  Wave w adds up the quads w, w + 4, ..
+    // of the rows, four rows in flight, and the waves swap their sums through LDS.
+    const int nch = (item.z + INV_CHUNK - 1) / INV_CHUNK;
+    const int f = (item.x / S) * CM + item.w, last = f + nch - 1;        // (slots: B * CM < 2^31, checked by the host)
+    constexpr int NQ = (QH + 3) / 4;
+    float4 pq[NQ];
 #pragma unroll
-    for (int q4 = 0; q4 < (CA + 3) / 4; ++q4) {
-        const float4 a = sr[q4];
-        const float v[4] = {a.x, a.y, a.z, a.w};
+    for (int i = 0; i < NQ; ++i) pq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = f; __builtin_amdgcn_ballot_w64(r <= last) != 0;) {
+        float4 a[4][NQ];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (4 * q4 + t < CA) x[4 * q4 + t] = v[t];
+        for (int j = 0; j < 4; ++j) {
+            const bool more = r <= last;
+            const int e = more ? min(last, (int)((unsigned)r / (unsigned)L) * L + L - 1) : 0;
+            const float4* gr = reinterpret_cast<const float4*>(Gpart + (size_t)e * HS);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                a[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (more && w + 4 * i < QH) a[j][i] = gr[w + 4 * i];
+            }
+            if (more) r = e + 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                pq[i].x += a[j][i].x, pq[i].y += a[j][i].y, pq[i].z += a[j][i].z, pq[i].w += a[j][i].w;
     }
-    if (src_a) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        if (w + 4 * i < QH) {
+            const int o = 4 * (w + 4 * i);
+            s_p[(o + 0) * 64 + lane] = pq[i].x, s_p[(o + 1) * 64 + lane] = pq[i].y;
+            s_p[(o + 2) * 64 + lane] = pq[i].z, s_p[(o + 3) * 64 + lane] = pq[i].w;
+        }
+    __syncthreads();
+    float p[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) p[o] = s_p[o * 64 + lane];
+    if (w < TK) {
         const cfp sa = opaque(as_const(src_a)), sc = opaque(as_const(src_c));
 #pragma unroll
-        for (int k = 0; k < CA; ++k) x[k] = fmaf(sa[k], x[k], sc[k]);
+        for (int i = 0; i < 16; ++i) {
+            const int k = 16 * w + i;
+            if (k >= CA || !valid) x[i] = 0.f;
+            else if (src_a) x[i] = fmaf(sa[k], x[i], sc[k]);
+        }
+        if (!valid) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) p[o] = 0.f;
+        }
+        Acc acc;
+        acc.init(lds);
+        acc.add(lds, p, x);
+        acc.store_slab(lds);                                 // slab[o * 16 + i]
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int img = sn2_grad_image(rep_k, rep_stride);
+        for (int i = lane; i < CO * 16; i += 64) {
+            const int o = i >> 4, k = 16 * w + (i & 15);
+            const float v = lds[i];
+            if (k < CA && v != 0.f) SN2_FLUSH_ADD(&dW[img + o * CI + k], v);
+        }
     }
-    acc.add(lds, p, x);
-    static_assert(CO * CA <= Acc::LDS_FLOATS, "a wave's image fits its staging region");
-    acc.store_slab(lds);
-    __syncthreads();
-    for (int i = threadIdx.x; i < CO * CA; i += 256) {
-        const float v = (smem[i] + smem[Acc::LDS_FLOATS + i]) + (smem[2 * Acc::LDS_FLOATS + i] + smem[3 * Acc::LDS_FLOATS + i]);
-        if (v != 0.f) SN2_FLUSH_ADD(&dW[sn2_grad_image(rep_k, rep_stride) + (i / CA) * CI + (i % CA)], v);
+    // dsrc last: its arithmetic runs while the float atomics above are on their way
+    if (valid) {
+        // (KQ consecutive weights per o: wide scalar loads; the last wave's window is pulled back inside the row, its
+        // first columns computed twice and not stored)
+        const cfp W = opaque(as_const(Wg)) + k0;
+        float d[KQ];
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) d[i] = 0.f;
+#pragma unroll 2
+        for (int o = 0; o < CO; ++o) {                       // (not unrolled in full: 306 weights do not fit the SGPRs)
+            const float po = s_p[o * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) d[i] = fmaf(po, W[o * CI + i], d[i]);
+        }
+        const int sh = w * KQ - k0;                          // columns of the window that belong to the wave before
+#pragma unroll
+        for (int i = 0; i < KQ; ++i)
+            if (i >= sh) dr[k0 + i] = d_old[i] + d[i];
     }
 }
 
@@ -1483,11 +1659,13 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
 }
 
 // the inverted index of a 3-NN table (kernels A-C, E above); workspace carve (32-bit words):
-// H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp] | (16-byte aligned) items [B*S] int4
+// H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp] | (16-byte aligned) items [B*S] int4 |
+// chunks [B*CM] int4
 struct InterpIndex {
     int *H, *off, *cnt, *inv_row;
-    int4* items;
+    int4 *items, *chunks;
     float* inv_w;
+    int CM;
 };
 InterpIndex carve_interp_index(float* ws, int B, int Rp, int S) {
     const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
@@ -1498,6 +1676,8 @@ InterpIndex carve_interp_index(float* ws, int B, int Rp, int S) {
     x.inv_row = x.cnt + (size_t)B * S;
     x.inv_w = reinterpret_cast<float*>(x.inv_row + (size_t)3 * B * Rp);
     x.items = reinterpret_cast<int4*>((reinterpret_cast<uintptr_t>(x.inv_w + (size_t)3 * B * Rp) + 15) & ~(uintptr_t)15);
+    x.chunks = x.items + (size_t)B * S;
+    x.CM = inv_chunks_per_plot(Rp, S);
     return x;
 }
 int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_pos, int B, int Rp, int S, float* ws,
@@ -1509,8 +1689,8 @@ int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_
     hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, x.H, x.off, x.cnt);
     hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, (const int*)x.H,
                        (const int*)x.off, x.inv_row, x.inv_w, row_perm);
-    hipLaunchKernelGGL(inv_order_kernel, dim3(B), dim3(1024), (size_t)((S + 3) & ~3) * 4, st,
-                       reinterpret_cast<const float4*>(src_pos), S, (const int*)x.off, (const int*)x.cnt, x.items);
+    hipLaunchKernelGGL(inv_order_kernel, dim3(B), dim3(1024), (size_t)(((S + 3) & ~3) + S) * 4, st,
+                       reinterpret_cast<const float4*>(src_pos), S, x.CM, (const int*)x.off, (const int*)x.cnt, x.items, x.chunks);
     SN2_RETURN_LAUNCH();
 }
 
@@ -1575,22 +1755,24 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
                                p->row_perm, Rp);
             if (!p->scatter_ready) SN2_TRY(build_interp_index(p->knn_idx, p->knn_w, nullptr, B, Rp, S, p->scatter_ws, st, p->row_perm));
             const InterpIndex x = carve_interp_index(p->scatter_ws, B, Rp, S);
-            // one source per wave (two per wave in half as many workgroups ran 30 % longer: the lists differ in length)
-            int gs = sn2_cdiv(n_src, 4);
-            if (gs > 65536) gs = 65536;
-            gs = (gs + 7) & ~7;                           // the same number of workgroups on each of the 8 XCDs
-            auto k2 = p->act_bf16 ? &fp_bwd_src_kernel<CA, CB, CO, true> : &fp_bwd_src_kernel<CA, CB, CO, false>;
-            hipLaunchKernelGGL(k2, dim3(gs), dim3(256), 0, st, n_src, Rp, S, p->dsrc_stride,
-                               (const int4*)x.items, (const int*)x.inv_row, (const float*)x.inv_w,
-                               (const float*)p->du_scratch, p->blk.W, p->src_ws, p->dsrc);
-            using AccD = OuterAcc<CO, CA, 32>;
-            constexpr size_t db3 = (size_t)AccD::LDS_FLOATS * 4 * 4;
-            static_assert(db3 >= (size_t)CO * CA * 4, "reduction image fits the staging regions");
-            auto k3 = &fp_bwd_src_dw_kernel<CA, CB, CO>;
-            if (db3 > 48 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)db3);
-            hipLaunchKernelGGL(k3, dim3(sn2_cdiv(n_src, 256)), dim3(256), db3, st, n_src, p->src_stride, p->src, p->src_a,
-                               p->src_c, (const float*)p->src_ws, p->blk.dW, p->blk.grad_replicas, p->blk.grad_replica_stride);
+            // waves over the chunk table (as many as the chip holds at once, L <= 64 slots each), then a lane per source for
+            // what G[s] is for
+            if ((long)B * x.CM >= (1L << 31) / 64) return SN2_ELIMIT;
+            const int n_chunks = B * x.CM;
+            const int waves_resident = sn2_cu_count() * 32;
+            int L = sn2_cdiv(n_chunks, waves_resident);
+            if (L < 4) L = 4;
+            static const int L_env = getenv("SN2_FP_SRC_L") ? atoi(getenv("SN2_FP_SRC_L")) : 0;
+            if (L_env > 0) L = L_env;
+            if (L > 64) L = 64;
+            const int gc = (sn2_cdiv(sn2_cdiv(n_chunks, L), 4) + 7) & ~7;
+            auto kc = p->act_bf16 ? &fp_bwd_src_chunk_kernel<CA, CB, CO, true> : &fp_bwd_src_chunk_kernel<CA, CB, CO, false>;
+            hipLaunchKernelGGL(kc, dim3(gc), dim3(256), 0, st, n_chunks, L, R, Rp, S, (const int4*)x.chunks, (const int*)x.inv_row,
+                               (const float*)x.inv_w, (const float*)p->du_scratch, p->src_ws);
+            hipLaunchKernelGGL((fp_bwd_src_merge_dw_kernel<CA, CB, CO>), dim3(sn2_cdiv(n_src, 64)), dim3(256), 0, st, n_src, S, x.CM,
+                               p->src_stride, p->dsrc_stride, (const int4*)x.items, p->src, p->src_a, p->src_c,
+                               (const float*)p->src_ws, p->blk.W, p->dsrc,
+                               p->blk.dW, p->blk.grad_replicas, p->blk.grad_replica_stride, L);
             SN2_RETURN_LAUNCH();
         }
     }

@@ -360,6 +360,27 @@ extern "C" int sn2_debug_mfma_chain(const float* a, const float* b, float* d, in
     SN2_RETURN_LAUNCH();
 }
 
+// ---- diagnostic: `blocks` one-wave workgroups that do nothing but wait for `clocks` shader clocks (bounded: every wave leaves
+// when its own clock count is up).  scripts/debug_contention.py uses it to tell what a concurrent kernel costs the feature
+// pass by merely BEING there from what it costs by the CUs, caches and memory it uses.
+namespace {
+__global__ __launch_bounds__(64) void debug_spin_kernel(long long clocks, int* __restrict__ out) {
+    const long long t0 = __builtin_readcyclecounter();
+    int n = 0;
+    while ((long long)__builtin_readcyclecounter() - t0 < clocks) {
+        __builtin_amdgcn_s_sleep(8);
+        ++n;
+    }
+    if (out && threadIdx.x == 0 && blockIdx.x == 0) *out = n;
+}
+}  // namespace
+
+extern "C" int sn2_debug_spin(int blocks, long long clocks, int* out, void* stream) {
+    if (blocks <= 0 || blocks > 4096 || clocks < 0 || clocks > (1LL << 34)) return SN2_EINVAL;
+    hipLaunchKernelGGL(debug_spin_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, clocks, out);
+    SN2_RETURN_LAUNCH();
+}
+
 extern "C" int sn2_version(void) { return SN2_VERSION; }
 
 

@@ -443,7 +443,13 @@ def sa_backward(d: SA):
 
 def interp_ws_words(B: int, R_per_plot: int, S_per_plot: int) -> int:
     """SN2_INTERP_WS_WORDS of include/strata_hip.h."""
-    return B * S_per_plot * ((R_per_plot + 2047) // 2048 + 6) + 6 * B * R_per_plot + 64
+    return (B * S_per_plot * ((R_per_plot + 2047) // 2048 + 6) + 6 * B * R_per_plot + 64
+            + 4 * B * interp_chunks(R_per_plot, S_per_plot))
+
+
+def interp_chunks(R_per_plot: int, S_per_plot: int) -> int:
+    """SN2_INTERP_CHUNKS of include/strata_hip.h: slots of the per-plot chunk table of an inverted index."""
+    return (3 * R_per_plot + 62) // 63 + S_per_plot
 
 
 def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[torch.Tensor] = None,
@@ -528,7 +534,7 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     # source-side workspace of the per-point layer (include/strata_hip.h: src_ws); scratch, so one per descriptor
     d._src_ws = None
     if SOURCE_SIDE and knn is not None and 0 < cb <= 16 and cb % 4 == 0 and R > 64 * _lib.STAT_SLOTS:
-        d._src_ws = torch.empty(B * S_per_plot * hs, dtype=F32, device=src.device)
+        d._src_ws = torch.empty(B * interp_chunks(R_per_plot, S_per_plot) * hs, dtype=F32, device=src.device)
     d.src_ws = _ptr(d._src_ws)
     d.row_perm = None
     if row_perm is not None and d._src_ws is not None and du_scratch is not None:

@@ -230,7 +230,7 @@ class PointNet2(nn.Module):
     # pass's gather did not get faster (45.2 against 46.8 us: neighbouring sources already share an XCD's L2, and the pass is
     # bound by the number of cache lines its gather instructions touch, not by where they come from), while the row pass's
     # permuted stores cost 7.8 us (57.9 against 50.1).  The path stays tested (tests/test_gpu_network.py).
-    fp1_morton_rows = False
+    fp1_morton_rows = os.environ.get("SN2_FP1_MORTON_ROWS", "0") == "1"
 
     @staticmethod
     def _fp1_source_side(rows):

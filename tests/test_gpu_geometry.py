@@ -284,3 +284,59 @@ def test_sa_work_items_order(B, M):
         positions = max(positions, nsolo + (M - nsolo + 3) // 4)
     want[4 * B * M] = positions
     assert torch.equal(got[:4 * B * M + 1], want[:4 * B * M + 1])
+
+
+@pytest.mark.parametrize("B,R,S,with_pos", [(2, 5000, 37, True), (3, 2049, 100, False), (1, 70000, 1024, True), (2, 300, 1, False)])
+def test_inverted_index_and_its_chunk_table(B, R, S, with_pos):
+    """sn2_interp_index: every (row, slot) of the 3-NN table is on its source's list exactly once with the normalised weight,
+    the item table is a permutation of the plot's sources, and the chunk table cuts every list into consecutive pieces of at
+    most 63 entries (unused slots: length 0) -- what fp_bwd_src_chunk_kernel walks (csrc/fp.hip).  Lists are made very
+    uneven on purpose (a few sources own most rows, some own none)."""
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    # skewed source choice: squares of uniforms pile up on the low ids; ids >= S - S // 5 are never chosen when S > 4
+    top = S - S // 5 if S > 4 else S
+    idx = (torch.rand(B * R, 3, generator=g) ** 3 * top).long().clamp_(0, S - 1).int()
+    w = torch.rand(B * R, 3, generator=g) + 0.1
+    w[::7, 2] = 0.0                                     # a zero weight in slot 1/2 = "no third neighbour": not listed
+    pos = torch.rand(B * S, 4, generator=g) if with_pos else None
+    ws = ops.interp_index((idx.cuda(), w.cuda()), B, R, S, src_pos=None if pos is None else pos.cuda())
+    torch.cuda.synchronize()
+    words = ws.cpu().view(torch.int32).numpy()
+    fl = ws.cpu().numpy()
+    SL = (R + 2047) // 2048
+    o_off = B * SL * S
+    o_cnt = o_off + B * S
+    o_row = o_cnt + B * S
+    o_w = o_row + 3 * B * R
+    o_items = (o_w + 3 * B * R + 3) // 4 * 4             # 16-byte aligned (the tensor's base is)
+    CM = ops.interp_chunks(R, S)
+    o_chunks = o_items + 4 * B * S
+    assert o_chunks + 4 * B * CM <= ops.interp_ws_words(B, R, S)
+    off, cnt = words[o_off:o_off + B * S], words[o_cnt:o_cnt + B * S]
+    inv_row, inv_w = words[o_row:o_row + 3 * B * R], fl[o_w:o_w + 3 * B * R]
+    items = words[o_items:o_items + 4 * B * S].reshape(B, S, 4)
+    chunks = words[o_chunks:o_chunks + 4 * B * CM].reshape(B, CM, 4)
+    idx_n, w_n = idx.numpy(), w.numpy()
+    wn = w_n / w_n.sum(1, keepdims=True)
+    for b in range(B):
+        assert sorted(items[b, :, 0].tolist()) == list(range(b * S, (b + 1) * S))
+        first = 0
+        for k in range(S):
+            sid, o, n, f = items[b, k]
+            assert o == off[sid] and n == cnt[sid] and f == first
+            nch = (n + 62) // 63
+            for c in range(nch):
+                assert chunks[b, first + c].tolist() == [sid, o + 63 * c, min(63, n - 63 * c), b]
+            first += nch
+        assert not chunks[b, first:].any()
+        rows = slice(b * R, (b + 1) * R)
+        listed = (np.arange(3)[None, :] == 0) | (w_n[rows] != 0)
+        want = {}
+        for r, j in zip(*np.nonzero(listed)):
+            want.setdefault(b * S + int(idx_n[rows][r, j]), []).append((int(r), float(wn[rows][r, j])))
+        for s in range(b * S, (b + 1) * S):
+            got = sorted(zip(inv_row[off[s]:off[s] + cnt[s]].tolist(), inv_w[off[s]:off[s] + cnt[s]].tolist()))
+            exp = sorted(want.get(s, []))
+            assert [r for r, _ in got] == [r for r, _ in exp]
+            np.testing.assert_allclose([x for _, x in got], [x for _, x in exp], rtol=2e-6)
+    assert S == 1 or (cnt.max() > 4 * 63 and (cnt == 0).any())
