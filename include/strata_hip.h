@@ -166,15 +166,22 @@ typedef struct sn2_sa {
     const float *dout;              /* backward in : d loss / d out (B*M,cout)                                  */
     float *dfeat;                   /* backward out: ACCUMULATED d loss / d feat (B*Nsrc,cf) or NULL            */
 } sn2_sa;
-/* Work items of the SA passes (position-only: part of the geometry pass).  A wave step is four 16-message tiles: a
- * centroid with more than SN2_SA_SOLO_MIN neighbours takes all four (a solo item), the others share a step four at a time
- * (a quad: ranks 4k..4k+3 of the plot's centroids by DESCENDING neighbour count, ties by ascending id -- deterministic).
- * Item k of plot b sits at position k*B + b, i.e. heaviest first across plots.  order: SN2_SA_ORDER_WORDS(B,M) ints = 4
- * per position (solo: id | SN2_SA_SOLO_FLAG four times; quad: four ids; -1 = none) + a 4-int trailer whose first word is
- * the largest item count of any plot.  (Ball sizes at C2: median 5, mean 25, maximum 261.) */
+/* Work items of the SA passes (position-only: part of the geometry pass).  A wave step is four 16-message tiles; a plot's
+ * centroids are ranked by DESCENDING neighbour count (ties by ascending id -- deterministic) and cut into classes:
+ *   SOLO (n > SN2_SA_SOLO_MIN: all four tiles, 64 messages per step), QUAD (n > SN2_SA_QUAD_MIN: ranks 4k..4k+3 share the
+ *   steps, a tile each), OCT (n > SN2_SA_OCT_MIN: eight ranks, half a tile each, one step), HEX (the rest: sixteen ranks, a
+ *   quarter tile each, one step).  (Ball sizes at C2: median 5, mean 25, maximum 261.)
+ * Item k of plot b sits at position k*B + b of its table, i.e. heaviest first across plots.  order = SN2_SA_ORDER_WORDS(B,M)
+ * ints (-1 = none): 4 B M ints of SOLO / QUAD positions, 4 each (solo: id | SN2_SA_SOLO_FLAG four times; quad: four ids);
+ * 16 B SN2_SA_PACKED_ITEMS(M) ints of OCT / HEX positions, 16 each = the centroid of every quarter tile (an OCT's ids twice
+ * each, | SN2_SA_OCT_FLAG); a trailer: [0] / [1] = the largest SOLO + QUAD / OCT + HEX item count of any plot. */
 #define SN2_SA_SOLO_MIN 64
+#define SN2_SA_QUAD_MIN 8
+#define SN2_SA_OCT_MIN 4
 #define SN2_SA_SOLO_FLAG 0x40000000
-#define SN2_SA_ORDER_WORDS(B, M) ((size_t)4 * (B) * (M) + 4)
+#define SN2_SA_OCT_FLAG 0x20000000
+#define SN2_SA_PACKED_ITEMS(M) ((M) / 8 + 2)
+#define SN2_SA_ORDER_WORDS(B, M) ((size_t)4 * (B) * (M) + (size_t)16 * (B) * SN2_SA_PACKED_ITEMS(M) + 8)
 int sn2_sa_order(const int *cnt, int B, int M, int *order, void *stream);
 int sn2_sa_forward(const sn2_sa *p, int training, void *stream);
 int sn2_sa_backward(const sn2_sa *p, void *stream);

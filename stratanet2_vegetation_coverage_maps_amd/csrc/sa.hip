@@ -120,74 +120,47 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
-// Work items of the SA passes.  A wave step is four 16-message tiles.  A centroid with more than SN2_SA_SOLO_MIN
-// neighbours takes all four tiles itself (a SOLO item: 64 messages per step); the others are ranked by descending
-// neighbour count (ties: ascending id) and ranks 4k..4k+3 share a step as a QUAD, one tile each, so that the four lists
-// end together.  (Ball sizes at C2: median 5, mean 25, maximum 261 -- four tiles of one centroid ran 32 % full; quads
-// alone made the longest item 17 steps.)  Ranking = comparison counting against the plot's counts in LDS: deterministic,
-// no atomics.  Items of all plots are interleaved heaviest first -- item k of plot b at position k*B + b -- and the SA
-// kernels deal them to their waves in that order (in a snake).  order: 4 ints per position (solo: the id | SN2_SA_SOLO_FLAG
-// four times; quad: four ids; -1 = none), 4*B*M ints + a 4-int trailer whose first word is max_b(items of plot b).
+// Work items of the SA passes.  A wave step is four 16-message tiles, and the plot's centroids are ranked by descending
+// neighbour count (ties: ascending id):
+//   SOLO  a centroid with more than SN2_SA_SOLO_MIN neighbours takes all four tiles itself (64 messages per step);
+//   QUAD  SN2_SA_QUAD_MIN < n <= SOLO_MIN: consecutive ranks 4k..4k+3 share the steps, one tile each (the lists end together);
+//   OCT   SN2_SA_OCT_MIN < n <= QUAD_MIN: eight consecutive ranks, half a tile each, ONE step;
+//   HEX   n <= OCT_MIN: sixteen, a quarter tile each, one step.
+// (Ball sizes at C2: median 5, mean 25, maximum 261 -- four tiles of one centroid ran 32 % full, quads alone 65 %: 40 % of
+// the centroids have at most four neighbours and another 38 % at most eight, each of them a whole 16-row tile of its own;
+// the parcel loop's 10 000-point plots: 52 %.)  Ranking = a bitonic sort of (count, index) keys in LDS: deterministic, no
+// atomics on the order.  Items of all plots are interleaved heaviest first -- item k of plot b at position k*B + b -- and
+// the SA kernels deal the positions to their waves in that order (in a snake).
+// order (SN2_SA_ORDER_WORDS ints, -1 = none):
+//   [0, 4 B M)               SOLO / QUAD positions, 4 ints each (solo: id | SN2_SA_SOLO_FLAG four times; quad: four ids);
+//   then 16 B SN2_SA_PACKED_ITEMS(M) ints: OCT / HEX positions, 16 ints each = the centroid of every QUARTER tile (an OCT's
+//                            ids twice each, | SN2_SA_OCT_FLAG);
+//   then the trailer: [0] = max_b(SOLO + QUAD items of plot b), [1] = max_b(OCT + HEX items of plot b).
 // ------------------------------------------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void sa_order_kernel(const int* __restrict__ cnt, int B, int M, int* __restrict__ order) {
-    extern __shared__ __attribute__((aligned(16))) int s_cnt[];
-    const int b = blockIdx.y;
-    const int* cb = cnt + (size_t)b * M;
-    for (int i = threadIdx.x; i < M; i += 256) s_cnt[i] = cb[i];
-    __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const int mine = s_cnt[i];
-    int rank = 0, nsolo = 0;
-    int j = 0;
-    for (; j + 4 <= M; j += 4) {                        // four counts per (broadcast) LDS read
-        const int4 o = *reinterpret_cast<const int4*>(&s_cnt[j]);
-        rank += (o.x > mine || (o.x == mine && j < i)) ? 1 : 0;
-        rank += (o.y > mine || (o.y == mine && j + 1 < i)) ? 1 : 0;
-        rank += (o.z > mine || (o.z == mine && j + 2 < i)) ? 1 : 0;
-        rank += (o.w > mine || (o.w == mine && j + 3 < i)) ? 1 : 0;
-        nsolo += (o.x > SN2_SA_SOLO_MIN) + (o.y > SN2_SA_SOLO_MIN) + (o.z > SN2_SA_SOLO_MIN) + (o.w > SN2_SA_SOLO_MIN);
-    }
-    for (; j < M; ++j) {
-        const int o = s_cnt[j];
-        rank += (o > mine || (o == mine && j < i)) ? 1 : 0;
-        nsolo += o > SN2_SA_SOLO_MIN ? 1 : 0;
-    }
-    const int id = b * M + i;
-    if (mine > SN2_SA_SOLO_MIN) {                       // the solos are exactly the ranks 0..nsolo-1
-        int* dst = order + 4 * ((size_t)rank * B + b);
-        dst[0] = dst[1] = dst[2] = dst[3] = id | SN2_SA_SOLO_FLAG;
-    } else {
-        const int rl = rank - nsolo;
-        order[4 * ((size_t)(nsolo + (rl >> 2)) * B + b) + (rl & 3)] = id;
-    }
-    if (i == 0) atomicMax(&order[(size_t)4 * B * M], nsolo + ((M - nsolo + 3) >> 2));
-}
-
-// The same order from a SORT: one workgroup per plot sorts the keys ((cap - count) << 14 | index) -- all different, so the
-// order is that of sa_order_kernel (count descending, index ascending) by construction -- with a bitonic network in LDS:
-// log2(P2) (log2(P2) + 1) / 2 compare-exchange stages instead of M comparisons per centroid (M = 1024: 55 stages against 1024
-// compares; the parcel loop's M = 2500: 78 against 2500: 0.17 -> 0.02 ms per call).
 __global__ __launch_bounds__(1024) void sa_order_sort_kernel(const int* __restrict__ cnt, int B, int M, int P2,
                                                              int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_key[];       // [P2]
-    __shared__ int s_nsolo;
+    __shared__ int s_n[3];                                                  // centroids of the classes SOLO, QUAD, OCT
     const int b = blockIdx.x, tid = threadIdx.x;
     const int* cb = cnt + (size_t)b * M;
-    if (tid == 0) s_nsolo = 0;
+    if (tid < 3) s_n[tid] = 0;
     __syncthreads();
-    int solo_here = 0;
+    int n_here[3] = {0, 0, 0};
     for (int i = tid; i < P2; i += 1024) {
         unsigned key = 0xFFFFFFFFu;                                        // padding sorts last
         if (i < M) {
             const int c = cb[i];
             key = ((unsigned)(0x3FFFF - c) << 14) | (unsigned)i;           // counts <= 2000 < 2^18, indices < 2^14
-            solo_here += c > SN2_SA_SOLO_MIN ? 1 : 0;
+            n_here[0] += c > SN2_SA_SOLO_MIN ? 1 : 0;
+            n_here[1] += (c > SN2_SA_QUAD_MIN && c <= SN2_SA_SOLO_MIN) ? 1 : 0;
+            n_here[2] += (c > SN2_SA_OCT_MIN && c <= SN2_SA_QUAD_MIN) ? 1 : 0;
         }
         s_key[i] = key;
     }
-    if (solo_here) atomicAdd(&s_nsolo, solo_here);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (n_here[k]) atomicAdd(&s_n[k], n_here[k]);
     __syncthreads();
     for (int k = 2; k <= P2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -203,37 +176,46 @@ __global__ __launch_bounds__(1024) void sa_order_sort_kernel(const int* __restri
             __syncthreads();
         }
     }
-    const int nsolo = s_nsolo;
+    // the classes are the rank ranges [0, nsolo), [nsolo, r_oct), [r_oct, r_hex), [r_hex, M)
+    const int nsolo = s_n[0], r_oct = nsolo + s_n[1], r_hex = r_oct + s_n[2];
+    const int items_a = nsolo + ((s_n[1] + 3) >> 2), n_oct_items = (s_n[2] + 7) >> 3, n_hex_items = (M - r_hex + 15) >> 4;
+    int* packed = order + (size_t)4 * B * M;
     for (int r = tid; r < M; r += 1024) {
         const int id = b * M + (int)(s_key[r] & 0x3FFFu);
-        if (r < nsolo) {                                                    // the solos are exactly the ranks 0..nsolo-1
+        if (r < nsolo) {
             int* dst = order + 4 * ((size_t)r * B + b);
             dst[0] = dst[1] = dst[2] = dst[3] = id | SN2_SA_SOLO_FLAG;
-        } else {
+        } else if (r < r_oct) {
             const int rl = r - nsolo;
             order[4 * ((size_t)(nsolo + (rl >> 2)) * B + b) + (rl & 3)] = id;
+        } else if (r < r_hex) {
+            const int rl = r - r_oct;                                       // half-tile (rl & 7) of OCT item rl >> 3
+            int* dst = packed + 16 * ((size_t)(rl >> 3) * B + b) + 2 * (rl & 7);
+            dst[0] = dst[1] = id | SN2_SA_OCT_FLAG;
+        } else {
+            const int rl = r - r_hex;                                       // quarter-tile (rl & 15) of HEX item rl >> 4
+            packed[16 * ((size_t)(n_oct_items + (rl >> 4)) * B + b) + (rl & 15)] = id;
         }
     }
-    if (tid == 0) atomicMax(&order[(size_t)4 * B * M], nsolo + ((M - nsolo + 3) >> 2));
+    if (tid == 0) {
+        int* trailer = packed + (size_t)16 * B * SN2_SA_PACKED_ITEMS(M);
+        atomicMax(&trailer[0], items_a);
+        atomicMax(&trailer[1], n_oct_items + n_hex_items);
+    }
 }
 }  // namespace
 
 extern "C" int sn2_sa_order(const int* cnt, int B, int M, int* order, void* stream) {
     if (!cnt || !order || B <= 0 || M <= 0) return SN2_EINVAL;
-    if (M > 16384) return SN2_ELIMIT;                     // the plot's counts must fit LDS
+    if (M > 16384) return SN2_ELIMIT;                     // the plot's keys must fit LDS (and 14 bits)
     hipStream_t st = (hipStream_t)stream;
     sn2_fill_words(order, 0xFFFFFFFFu, (size_t)SN2_SA_ORDER_WORDS(B, M), st);                                      // all -1
-    static const bool by_counting = getenv("SN2_SA_ORDER_COUNTING") != nullptr;      // (cross-check switch: the O(M^2) form)
-    if (!by_counting) {
-        int P2 = 2;
-        while (P2 < M) P2 <<= 1;
-        if ((size_t)P2 * 4 > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_order_sort_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, P2 * 4);
-        hipLaunchKernelGGL(sa_order_sort_kernel, dim3(B), dim3(1024), (size_t)P2 * 4, st, cnt, B, M, P2, order);
-        SN2_RETURN_LAUNCH();
-    }
-    hipLaunchKernelGGL(sa_order_kernel, dim3(sn2_cdiv(M, 256), B), dim3(256), (size_t)M * 4, st, cnt, B, M, order);
+    int P2 = 2;
+    while (P2 < M) P2 <<= 1;
+    if ((size_t)P2 * 4 > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_order_sort_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, P2 * 4);
+    hipLaunchKernelGGL(sa_order_sort_kernel, dim3(B), dim3(1024), (size_t)P2 * 4, st, cnt, B, M, P2, order);
     SN2_RETURN_LAUNCH();
 }
 

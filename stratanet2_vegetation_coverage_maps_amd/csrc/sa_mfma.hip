@@ -26,7 +26,7 @@
 namespace {
 
 struct SaFwdArgs {
-    int B, Nsrc, M, cap, feat_stride, spos_stride;
+    int B, Nsrc, M, cap, feat_stride, spos_stride, group;
     const float *feat, *spos, *cpos;
     const int *nbr, *cnt, *order;
     const float *W0, *b0, *a0, *c0, *gamma0;
@@ -59,13 +59,93 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
+
+// Reductions over a SEGMENT of a DPP row: W = 16 (a tile is one centroid's), 8 or 4 lanes (two / four short lists share a
+// tile: OCT and HEX items).  W is wave-uniform; every lane ends up with its segment's result.
+__device__ __forceinline__ float seg_max(float v, int W) {
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0xB1, 0xF)));
+    v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x4E, 0xF)));
+    if (W > 4) v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x141, 0xF)));
+    if (W > 8) v = fmaxf(v, __int_as_float(SN2_DPP(__float_as_int(v), 0x140, 0xF)));
+    return v;
+}
+__device__ __forceinline__ unsigned seg_min_u32(unsigned v, int W) {
+    v = min(v, (unsigned)SN2_DPP((int)v, 0xB1, 0xF));
+    v = min(v, (unsigned)SN2_DPP((int)v, 0x4E, 0xF));
+    if (W > 4) v = min(v, (unsigned)SN2_DPP((int)v, 0x141, 0xF));
+    if (W > 8) v = min(v, (unsigned)SN2_DPP((int)v, 0x140, 0xF));
+    return v;
+}
+
+// One work item of sn2_sa_order, as every lane sees it.  lane = (q, c), tile t: the message slot (t, c) belongs to centroid
+// lc[t], is entry le0 + eoff * t + (steps done) * estep of its neighbour list, which has ln[t] entries (-1: no centroid).
+//   SOLO  one centroid, 64 entries per step (tile t: entries 16 t + c)        QUAD  four centroids, 16 entries per step each
+//   OCT   eight centroids with 5..8 neighbours, half a tile each, one step     HEX   sixteen with 0..4, a quarter tile each
+// W = lanes per centroid in a tile (16, 8, 4); bt[t] = the plot of tile t's centroids (wave-uniform, as estep, eoff, W, nmax).
+// Returns false for an empty position.
+struct SaItem {
+    int lc[4], ln[4], le0;
+    int bt[4], estep, eoff, W, nmax;
+    bool solo;
+};
+__device__ __forceinline__ bool sa_item(SaItem& it, const int* __restrict__ order, const int* __restrict__ cnt, int B, int M,
+                                        int nA, int nB, int G, int qi, int c) {
+    const int ncent = B * M;
+    if (!order) {                                            // no order table: quads in index order
+        it.solo = false, it.estep = 16, it.eoff = 0, it.W = 16, it.nmax = 0, it.le0 = c;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ci = 4 * qi + t < ncent ? 4 * qi + t : -1;
+            it.lc[t] = ci >= 0 ? ci : 0;
+            it.ln[t] = ci >= 0 ? cnt[ci] : -1;
+            it.bt[t] = it.lc[t] / M;
+            it.nmax = max(it.nmax, __builtin_amdgcn_readfirstlane(it.ln[t]));
+        }
+        return it.nmax > 0;
+    }
+    // turn qi -> (plot b, item k): the plots are taken G at a time (all of them when they are few), the items of a group
+    // interleaved heaviest first; the SOLO / QUAD items of all groups come before the packed ones.  (The table itself keeps
+    // item k of plot b at position k B + b.)  With hundreds of plots -- the parcel loop's 256 -- the waves of a round then
+    // gather from G plots' feature rows, which stay in L2, instead of from all of them.
+    const int ngrp = (B + G - 1) / G;
+    const bool packed = qi >= ngrp * nA * G;
+    const int qq = packed ? qi - ngrp * nA * G : qi, nk = packed ? nB : nA;
+    const int g = qq / (nk * G), rem = qq - g * (nk * G), k = rem / G, pb = g * G + (rem - k * G);
+    if (pb >= B) return false;
+    const int qp = k * B + pb;
+    const int* rec = packed ? order + (size_t)4 * ncent + (size_t)16 * qp : order + (size_t)4 * qp;
+    int ent[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ent[t] = rec[packed ? 4 * t + (c >> 2) : t];
+    const int e0 = __builtin_amdgcn_readfirstlane(ent[0]);
+    if (e0 < 0) return false;
+    it.solo = !packed && (e0 & SN2_SA_SOLO_FLAG) != 0;
+    it.W = !packed ? 16 : ((e0 & SN2_SA_OCT_FLAG) ? 8 : 4);
+    it.estep = it.solo ? 64 : 16;
+    it.eoff = it.solo ? 16 : 0;
+    it.le0 = c & (it.W - 1);
+    it.nmax = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool some = ent[t] >= 0;
+        it.lc[t] = some ? (ent[t] & ~(SN2_SA_SOLO_FLAG | SN2_SA_OCT_FLAG)) : 0;
+        it.ln[t] = some ? cnt[it.lc[t]] : -1;
+        it.bt[t] = pb;
+        if (!packed) it.nmax = max(it.nmax, __builtin_amdgcn_readfirstlane(it.ln[t]));
+    }
+    if (packed) it.nmax = it.W;                              // one step (lists of at most W entries)
+    return it.nmax > 0;
+}
+
 // PASS 0: statistics of block 0 only (nl == 2);  PASS 1: full forward, statistics of the last block, extremum
 template <int CF, int NL, int C1, int C2, int PASS, bool BF16>
-__global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
+__global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
     constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16, CS = PASS == 0 ? C1 : CL, TOS = CS / 16;
     static_assert(CF % 4 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "tile shapes");
     __shared__ float s_red[4][2 * CS];          // per wave: added in wave order => the statistics are the same on every run
+    __builtin_amdgcn_s_setprio(3);              // the feature pass is the chain a step waits for: its waves go first where they
+                                                // share a SIMD with the position-only kernels of later batches (FPS above all)
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int nwaves = gridDim.x * 4;
@@ -118,30 +198,24 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_f
 #pragma unroll
         for (int r = 0; r < 4; ++r) ssum[io][r] = ssq[io][r] = 0.f;
 
-    const int nquads = a.order ? a.order[(size_t)4 * ncent] * a.B : (ncent + 3) >> 2;
+    // positions of the order table: nA per plot for SOLO / QUAD items, then nB per plot for the packed ones (OCT / HEX)
+    const int* trailer = a.order ? a.order + (size_t)4 * ncent + (size_t)16 * a.B * SN2_SA_PACKED_ITEMS(a.M) : nullptr;
+    const int nA = trailer ? trailer[0] : 0, nB = trailer ? trailer[1] : 0;
+    const int G = a.group > 0 && a.group < a.B ? a.group : a.B;
+    const int nitems = a.order ? (nA + nB) * G * ((a.B + G - 1) / G) : (ncent + 3) >> 2;
     // items are ordered heaviest first: the waves take them in a snake (round 0: item w, round 1: item 2W-1-w, ...), so the
     // wave with the longest item of a round gets the shortest of the next.  (A shared work counter was tried: 8000 atomics
     // on one address cost more than the imbalance they removed.)
     for (int round = 0;; ++round) {
         const int qi = round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave);
-        if (round * nwaves >= nquads) break;
-        if (qi >= nquads) continue;
-        // the quad's four centroids (wave-uniform: SGPRs), tile t walks the list of centroid cid[t]
-        int cid[4], nn[4], nmax = 0;
-        bool solo = false;
+        if (round * nwaves >= nitems) break;
+        if (qi >= nitems) continue;
+        SaItem it;
+        if (!sa_item(it, a.order, a.cnt, a.B, a.M, nA, nB, G, qi, c)) continue;          // an empty position
+        const int nmax = it.nmax, estep = it.estep;
         float cpq[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int slot = 4 * qi + t;
-            const int ent = a.order ? a.order[slot] : (slot < ncent ? slot : -1);
-            if (t == 0) solo = ent >= 0 && (ent & SN2_SA_SOLO_FLAG) != 0;
-            const int ci = ent >= 0 ? (ent & ~SN2_SA_SOLO_FLAG) : -1;
-            cid[t] = ci;
-            nn[t] = ci >= 0 ? a.cnt[ci] : 0;
-            nmax = nn[t] > nmax ? nn[t] : nmax;
-            const float4 cp = reinterpret_cast<const float4*>(a.cpos)[ci >= 0 ? ci : 0];
-            cpq[t] = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
-        }
+        for (int t = 0; t < 4; ++t) cpq[t] = a.cpos[(size_t)it.lc[t] * 4 + (q < 3 ? q : 0)];
         float best[4][TOL][4];
         int barg[4][TOL][4];
 #pragma unroll
@@ -153,20 +227,17 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_f
                     best[t][io][r] = -INFINITY;
                     barg[t][io][r] = 0x7FFFFFFF;
                 }
-        const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
         // the neighbour indices of a step are fetched one step ahead: index load -> row gather -> MFMA chain is what a
         // step waits for, and the first link does not depend on the step before.  The FIRST step's indices are requested
-        // together with the counts (the address needs the centroid only; entries past the count are masked afterwards):
-        // work item -> {count, position, indices} -> rows, one dependent round trip less per item
+        // together with the counts (the address needs the centroid only; entries past the count are masked afterwards)
         int jn[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int e = eoff * t + c;
-            jn[t] = e < a.cap ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
+            const int e = it.le0 + it.eoff * t;
+            jn[t] = e < a.cap ? a.nbr[(size_t)it.lc[t] * a.cap + e] : 0;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) jn[t] = eoff * t + c < nn[t] ? jn[t] : 0;
-        if (nmax == 0) continue;                                         // an empty position
+        for (int t = 0; t < 4; ++t) jn[t] = it.le0 + it.eoff * t < it.ln[t] ? jn[t] : 0;
         for (int e0 = 0; e0 < nmax; e0 += estep) {
             // ---- layer 1: gather straight into the B-operand layout, 4 message tiles
             f32x4 D1[TO1][4];
@@ -175,16 +246,14 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_f
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 jc[t] = jn[t];
-                const int en = e0 + estep + eoff * t + c;
-                jn[t] = en < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + en] : 0;
+                const int en = e0 + estep + it.le0 + it.eoff * t;
+                jn[t] = en < it.ln[t] ? a.nbr[(size_t)it.lc[t] * a.cap + en] : 0;
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int e = e0 + eoff * t + c;                         // slot in tile t's list
-                val[t] = e < nn[t];
-                const int cit = cid[t] >= 0 ? cid[t] : 0;
-                const int j = jc[t];
-                const size_t row = (size_t)(cit / a.M) * a.Nsrc + j;
+                const int e = e0 + it.le0 + it.eoff * t;                            // slot in the list of this lane's centroid
+                val[t] = e < it.ln[t];
+                const size_t row = (size_t)it.bt[t] * a.Nsrc + jc[t];
                 float bk[KB1];
 #pragma unroll
                 for (int kb = 0; kb < KB1 - 1; ++kb) bk[kb] = a.feat[row * a.feat_stride + 4 * kb + q];
@@ -242,7 +311,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_f
                 for (int io = 0; io < TOL; ++io)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int e = e0 + eoff * t + c;
+                        const int e = e0 + it.le0 + it.eoff * t;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float h = val[t] ? DL[io][t][r] : 0.f;
@@ -258,7 +327,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_f
             }
         }
         if constexpr (PASS == 1) {
-            if (solo) {   // the four tiles belong to one centroid: fold them (greater value, then lower slot), tile 0 writes
+            if (it.solo) {   // the four tiles belong to one centroid: fold them (greater value, then lower slot), tile 0 writes
 #pragma unroll
                 for (int t = 1; t < 4; ++t)
 #pragma unroll
@@ -271,22 +340,24 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_f
                             barg[0][io][r] = take ? barg[t][io][r] : barg[0][io][r];
                         }
             }
+            const int W = it.W;
+            const bool writer = (c & (W - 1)) == 0;          // first lane of a centroid's segment of the tile
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (cid[t] < 0 || (solo && t > 0)) continue;
+                if (it.solo && t > 0) continue;
 #pragma unroll
                 for (int io = 0; io < TOL; ++io) {
                     float ev[4];
                     int av[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float m = row_max(best[t][io][r]);
-                        const unsigned am = row_min_u32(best[t][io][r] == m ? (unsigned)barg[t][io][r] : 0xFFFFFFFFu);
-                        ev[r] = nn[t] > 0 ? sgn[io][r] * m : 0.f;
-                        av[r] = nn[t] > 0 ? (int)am : -1;
+                        const float m = seg_max(best[t][io][r], W);
+                        const unsigned am = seg_min_u32(best[t][io][r] == m ? (unsigned)barg[t][io][r] : 0xFFFFFFFFu, W);
+                        ev[r] = it.ln[t] > 0 ? sgn[io][r] * m : 0.f;
+                        av[r] = it.ln[t] > 0 ? (int)am : -1;
                     }
-                    if (c == 0) {
-                        const size_t o = (size_t)cid[t] * CL + 16 * io + 4 * q;
+                    if (writer && it.ln[t] >= 0) {
+                        const size_t o = (size_t)it.lc[t] * CL + 16 * io + 4 * q;
                         *reinterpret_cast<float4*>(a.ext + o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
                         *reinterpret_cast<int4*>(a.arg + o) = make_int4(av[0], av[1], av[2], av[3]);
                     }
@@ -329,7 +400,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 4 : 1) void sa_mfma_f
 //   * weight gradients contract over MESSAGES: both factors go through a wave-private LDS image [message][channel]
 //     (one ds_write_b128 per tile for a register tile) and come back in A/B layout with the message index as K.
 struct SaBwdArgs {
-    int B, Nsrc, M, cap, feat_stride, spos_stride;
+    int B, Nsrc, M, cap, feat_stride, spos_stride, group;
     const float *feat, *spos, *cpos;
     const int *nbr, *cnt, *order;
     const unsigned long long* total;
@@ -450,52 +521,45 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
         for (int r = 0; r < 4; ++r) dbe0[i][r] = dga0[i][r] = 0.f;
 
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16;
-    const int nquads = a.order ? a.order[(size_t)4 * ncent] * a.B : (ncent + 3) >> 2;
+    // positions of the order table: nA per plot for SOLO / QUAD items, then nB per plot for the packed ones (OCT / HEX)
+    const int* trailer = a.order ? a.order + (size_t)4 * ncent + (size_t)16 * a.B * SN2_SA_PACKED_ITEMS(a.M) : nullptr;
+    const int nA = trailer ? trailer[0] : 0, nB = trailer ? trailer[1] : 0;
+    const int G = a.group > 0 && a.group < a.B ? a.group : a.B;
+    const int nitems = a.order ? (nA + nB) * G * ((a.B + G - 1) / G) : (ncent + 3) >> 2;
     // items are ordered heaviest first: the waves take them in a snake (round 0: item w, round 1: item 2W-1-w, ...), so the
     // wave with the longest item of a round gets the shortest of the next.  (A shared work counter was tried: 8000 atomics
     // on one address cost more than the imbalance they removed.)
     for (int round = 0;; ++round) {
         const int qi = round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave);
-        if (round * nwaves >= nquads) break;
-        if (qi >= nquads) continue;
-        // the quad's four centroids (wave-uniform), tile t walks the list of centroid cid[t]
-        int cid[4], nn[4], nmax = 0;
-        bool solo = false;
+        if (round * nwaves >= nitems) break;
+        if (qi >= nitems) continue;
+        SaItem it;
+        if (!sa_item(it, a.order, a.cnt, a.B, a.M, nA, nB, G, qi, c)) continue;          // an empty position
+        const int nmax = it.nmax, estep = it.estep;
         float cpq[4];
-        // d loss / d output and the winning slot of this lane's 4 channels, per tile (= per centroid of the quad)
+        // d loss / d output and the winning slot of this lane's 4 channels, per tile (of this lane's centroid)
         float dov[4][TOL][4];
         int arv[4][TOL][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int slot = 4 * qi + t;
-            const int ent = a.order ? a.order[slot] : (slot < ncent ? slot : -1);
-            if (t == 0) solo = ent >= 0 && (ent & SN2_SA_SOLO_FLAG) != 0;
-            const int ci = ent >= 0 ? (ent & ~SN2_SA_SOLO_FLAG) : -1;
-            cid[t] = ci;
-            nn[t] = ci >= 0 ? a.cnt[ci] : 0;
-            nmax = nn[t] > nmax ? nn[t] : nmax;
-            const int cit = ci >= 0 ? ci : 0;
-            const float4 cp = reinterpret_cast<const float4*>(a.cpos)[cit];
-            cpq[t] = q == 0 ? cp.x : (q == 1 ? cp.y : cp.z);
+            cpq[t] = a.cpos[(size_t)it.lc[t] * 4 + (q < 3 ? q : 0)];
 #pragma unroll
             for (int io = 0; io < TOL; ++io) {
-                const size_t o = (size_t)cit * CL + 16 * io + 4 * q;
+                const size_t o = (size_t)it.lc[t] * CL + 16 * io + 4 * q;
                 const float4 dv = *reinterpret_cast<const float4*>(a.dout + o);
                 const int4 av = *reinterpret_cast<const int4*>(a.arg + o);
                 dov[t][io][0] = dv.x; dov[t][io][1] = dv.y; dov[t][io][2] = dv.z; dov[t][io][3] = dv.w;
                 arv[t][io][0] = av.x; arv[t][io][1] = av.y; arv[t][io][2] = av.z; arv[t][io][3] = av.w;
             }
         }
-        const int estep = solo ? 64 : 16, eoff = solo ? 16 : 0;
         int jn[4];                                 // neighbour indices, fetched one step ahead (the first step's: with the counts)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int e = eoff * t + c;
-            jn[t] = e < a.cap ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + e] : 0;
+            const int e = it.le0 + it.eoff * t;
+            jn[t] = e < a.cap ? a.nbr[(size_t)it.lc[t] * a.cap + e] : 0;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) jn[t] = eoff * t + c < nn[t] ? jn[t] : 0;
-        if (nmax == 0) continue;                                         // an empty position
+        for (int t = 0; t < 4; ++t) jn[t] = it.le0 + it.eoff * t < it.ln[t] ? jn[t] : 0;
         for (int e0 = 0; e0 < nmax; e0 += estep) {
             f32x4 D1[TO1][4];
             float bks[4][KB1];
@@ -505,16 +569,14 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 jc[t] = jn[t];
-                const int en = e0 + estep + eoff * t + c;
-                jn[t] = en < nn[t] ? a.nbr[(size_t)(cid[t] >= 0 ? cid[t] : 0) * a.cap + en] : 0;
+                const int en = e0 + estep + it.le0 + it.eoff * t;
+                jn[t] = en < it.ln[t] ? a.nbr[(size_t)it.lc[t] * a.cap + en] : 0;
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int e = e0 + eoff * t + c;                         // slot in tile t's list
-                val[t] = e < nn[t];
-                const int cit = cid[t] >= 0 ? cid[t] : 0;
-                const int j = jc[t];
-                rows[t] = (size_t)(cit / a.M) * a.Nsrc + j;
+                const int e = e0 + it.le0 + it.eoff * t;                            // slot in the list of this lane's centroid
+                val[t] = e < it.ln[t];
+                rows[t] = (size_t)it.bt[t] * a.Nsrc + jc[t];
 #pragma unroll
                 for (int kb = 0; kb < KB1 - 1; ++kb) bks[t][kb] = a.feat[rows[t] * a.feat_stride + 4 * kb + q];
                 const float pj = a.spos[rows[t] * a.spos_stride + (q < 3 ? q : 0)];
@@ -544,7 +606,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
                         f32x4 v = {bias2[io][0], bias2[io][1], bias2[io][2], bias2[io][3]};
                         v = contract<BF16, 4 * TO1>(v, [&](int kk) { return A2[io][kk >> 2][kk & 3]; },
                                                     [&](int kk) { return Y1[kk >> 2][t][kk & 3]; });
-                        const int e = e0 + eoff * t + c;
+                        const int e = e0 + it.le0 + it.eoff * t;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float h = fmaxf(v[r], 0.f);
@@ -597,7 +659,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
                 for (int is = 0; is < TO1; ++is)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int e = e0 + eoff * t + c;
+                        const int e = e0 + it.le0 + it.eoff * t;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dy1[is][t][r] = (val[t] && arv[t][is][r] == e) ? dov[t][is][r] : 0.f;
                     }
@@ -745,6 +807,13 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 
 }  // namespace
 
+// plots whose items a round of waves works on together (sa_item): all of a training batch, 8 of a parcel launch's hundreds
+static int sa_plot_group(int B) {
+    static const int g_env = getenv("SN2_SA_GROUP") ? atoi(getenv("SN2_SA_GROUP")) : 0;
+    if (g_env > 0) return g_env;
+    return B <= 32 ? B : 8;
+}
+
 // launched from sa.hip
 template <int CF, int NL, int C1, int C2, int PASS>
 int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nblocks_out) {
@@ -752,6 +821,7 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
     SaFwdArgs a;
     a.B = p->B; a.Nsrc = p->Nsrc; a.M = p->M; a.cap = p->cap; a.feat_stride = p->feat_stride; a.spos_stride = p->spos_stride;
     a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt; a.order = p->order;
+    a.group = sa_plot_group(p->B);
     const sn2_block& k0 = p->blk[0];
     const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
     a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma;
@@ -760,6 +830,11 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
     a.ext = p->ext; a.arg = p->arg;
     int blocks = sn2_cdiv((long)p->B * p->M, 16);          // one wave per quad of centroids, four waves per workgroup
     if (blocks > SN2_STAT_SLOTS) blocks = SN2_STAT_SLOTS;
+    // .. and no more workgroups than the chip holds at once (waves per SIMD by the kernels' register counts): the items are
+    // dealt heaviest first, a second wave of workgroups would start on the light tail when the first is done with the heads
+    static const int occ_env = getenv("SN2_SA_FWD_OCC") ? atoi(getenv("SN2_SA_FWD_OCC")) : 0;
+    const int occ = occ_env > 0 ? occ_env : (CF == 8 ? (PASS == 0 ? 4 : 3) : (CF == 16 ? 2 : 1));
+    if (blocks > sn2_cu_count() * occ) blocks = sn2_cu_count() * occ;
     if (nblocks_out) *nblocks_out = blocks;
     if (bf16) hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, true>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, false>), dim3(blocks), dim3(256), 0, st, a);
@@ -779,6 +854,7 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
     SaBwdArgs a;
     a.B = p->B; a.Nsrc = p->Nsrc; a.M = p->M; a.cap = p->cap; a.feat_stride = p->feat_stride; a.spos_stride = p->spos_stride;
     a.feat = p->feat; a.spos = p->spos; a.cpos = p->cpos; a.nbr = p->nbr; a.cnt = p->cnt; a.order = p->order; a.total = p->total;
+    a.group = sa_plot_group(p->B);
     const sn2_block& k0 = p->blk[0];
     const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
     a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma; a.mean0 = k0.mean; a.invstd0 = k0.invstd;
@@ -790,7 +866,9 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
     a.rep_k = k0.grad_replicas; a.rep_stride = k0.grad_replica_stride;
     a.dfeat = p->dfeat;
     int blocks = sn2_cdiv((long)p->B * p->M, 16);
-    if (blocks > 512) blocks = 512;
+    static const int occ_env = getenv("SN2_SA_BWD_OCC") ? atoi(getenv("SN2_SA_BWD_OCC")) : 0;
+    const int occ = occ_env > 0 ? occ_env : (CF == 8 ? 2 : 1);            // workgroups per CU that are resident together
+    if (blocks > sn2_cu_count() * occ) blocks = sn2_cu_count() * occ;
     const size_t lds = (size_t)Acc::LDS_FLOATS * 4 * sizeof(float);
     auto kern = p->blk[0].mma_bf16 ? &sa_mfma_bwd_kernel<CF, NL, C1, C2, PASS, true> : &sa_mfma_bwd_kernel<CF, NL, C1, C2, PASS, false>;
     if (lds > 48 * 1024)

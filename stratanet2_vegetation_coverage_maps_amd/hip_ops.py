@@ -385,12 +385,13 @@ def znorm(xyz: torch.Tensor, radius: float):
 
 def sa_order_len(B: int, M: int) -> int:
     """SN2_SA_ORDER_WORDS of include/strata_hip.h."""
-    return 4 * B * M + 4
+    return 4 * B * M + 16 * B * (M // 8 + 2) + 8
 
 
 def sa_order(cnt: torch.Tensor, B: int, M: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cnt (B*M) from ball_query -> the work items of the SA passes (include/strata_hip.h: sn2_sa_order): solo centroids
-    with long lists and quads of centroids with short lists, heaviest first."""
+    with long lists, quads of centroids with medium ones, and eight / sixteen centroids with at most 8 / 4 neighbours packed into
+    one step, heaviest first."""
     _chk(cnt, I32, (B * M,), "cnt")
     n = sa_order_len(B, M)
     if out is None:

@@ -260,30 +260,47 @@ def test_fps_workspace_is_only_handed_out_when_filled():
 @pytest.mark.parametrize("B,M", [(3, 1024), (2, 2500), (4, 256), (1, 10000), (2, 77)])
 def test_sa_work_items_order(B, M):
     """sn2_sa_order (the work items of the set-abstraction passes, ranked per plot by neighbour count descending, index
-    ascending -- a bitonic sort in LDS) against the rule evaluated on the host: solo centroids (more than SOLO_MIN neighbours)
-    first, one per position in four copies with the flag; the others four per position; -1 behind the last."""
+    ascending -- a bitonic sort in LDS) against the rule evaluated on the host (include/strata_hip.h): SOLO centroids (more
+    than 64 neighbours) first, one per position in four copies with the flag; QUADs (9..64) four per position; then the
+    packed table: OCTs (5..8) eight per 16-int position, every id twice with its flag, HEXes (0..4) sixteen per position;
+    -1 wherever nothing is; the trailer holds the largest position counts of any plot."""
     g = torch.Generator().manual_seed(B * 1000 + M)
     cnt = torch.randint(0, 40, (B * M,), generator=g, dtype=torch.int32)         # many ties
     heavy = torch.rand(B * M, generator=g) < 0.1
     cnt[heavy] = torch.randint(40, 2001, (int(heavy.sum()),), generator=g, dtype=torch.int32)
     got = ops.sa_order(cnt.to(DEV), B, M).cpu()
-    SOLO_MIN, FLAG = 64, 1 << 30
-    want = torch.full((4 * B * M + 4,), -1, dtype=torch.int32)
-    positions = 0
+    SOLO_MIN, QUAD_MIN, OCT_MIN, FLAG, OCT = 64, 8, 4, 1 << 30, 1 << 29
+    PK = M // 8 + 2
+    assert got.numel() == ops.sa_order_len(B, M) == 4 * B * M + 16 * B * PK + 8
+    want = torch.full((got.numel(),), -1, dtype=torch.int32)
+    offp, offt = 4 * B * M, 4 * B * M + 16 * B * PK
+    na = nb = 0
     for b in range(B):
         c = cnt[b * M:(b + 1) * M]
         order = sorted(range(M), key=lambda i: (-int(c[i]), i))
         nsolo = int((c > SOLO_MIN).sum())
+        r_oct = nsolo + int(((c > QUAD_MIN) & (c <= SOLO_MIN)).sum())
+        r_hex = r_oct + int(((c > OCT_MIN) & (c <= QUAD_MIN)).sum())
+        n_oct_items = (r_hex - r_oct + 7) // 8
         for r, i in enumerate(order):
             idv = b * M + i
             if r < nsolo:
                 want[4 * (r * B + b):4 * (r * B + b) + 4] = idv | FLAG
-            else:
+            elif r < r_oct:
                 rl = r - nsolo
                 want[4 * ((nsolo + (rl >> 2)) * B + b) + (rl & 3)] = idv
-        positions = max(positions, nsolo + (M - nsolo + 3) // 4)
-    want[4 * B * M] = positions
-    assert torch.equal(got[:4 * B * M + 1], want[:4 * B * M + 1])
+            elif r < r_hex:
+                rl = r - r_oct
+                o = offp + 16 * ((rl >> 3) * B + b) + 2 * (rl & 7)
+                want[o:o + 2] = idv | OCT
+            else:
+                rl = r - r_hex
+                want[offp + 16 * ((n_oct_items + (rl >> 4)) * B + b) + (rl & 15)] = idv
+        na = max(na, nsolo + (r_oct - nsolo + 3) // 4)
+        nb = max(nb, n_oct_items + (M - r_hex + 15) // 16)
+        assert n_oct_items + (M - r_hex + 15) // 16 <= PK
+    want[offt], want[offt + 1] = na, nb
+    assert torch.equal(got[:offt + 2], want[:offt + 2])
 
 
 @pytest.mark.parametrize("B,R,S,with_pos", [(2, 5000, 37, True), (3, 2049, 100, False), (1, 70000, 1024, True), (2, 300, 1, False)])
