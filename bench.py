@@ -193,9 +193,10 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
         # FP1: 24 B knn + 32 B skip + 3 x 144 B gathered rows (L2) read, 144 B written per point
         "sn2_fp_forward:34+8->34": (24 + 32 + 144) * N * B,
         # FP1 backward (source-side form): h + dy rows once (288 B; the BN sums come from the head's gradients), skip 32 B,
-        # d pre-activation written once and gathered back through the inverted index (2 x 144 B; the index entries 24 B);
+        # d pre-activation written once and gathered back through the inverted index (2 x 136 B: a 128-byte line + the pair of
+        # channels 32, 33; the index entries 24 B);
         # the per-source work (G, dsrc, dW_A over B*m1 rows) is < 1 % of that
-        "sn2_fp_backward:34+8->34": (288 + 32 + 144 + 144 + 24) * N * B,
+        "sn2_fp_backward:34+8->34": (288 + 32 + 136 + 136 + 24) * N * B,
         "sn2_head_forward": (144 + 32) * N * B,
         "sn2_head_backward": (144 + 32 + 144) * N * B,
         "sn2_plot_project_forward": (8 + 8 + 16 + 4) * N * B + 24 * D * D * B,
@@ -217,8 +218,8 @@ DOMINANT_KERNEL = {
 
 # entry point -> all device kernels it launches (for the PMC traffic of the whole entry point, where it has several)
 ENTRY_KERNELS = {
-    "sn2_fp_backward:34+8->34": ["fp_bwd_rows_kernel<34, 8, 34, 512, false>", "fp_bwd_src_kernel<34, 8, 34, false>",
-                                 "fp_bwd_src_dw_kernel<34, 8, 34>", "fp_bwd_bn_kernel<34>"],
+    "sn2_fp_backward:34+8->34": ["fp_bwd_rows_kernel<34, 8, 34, 512, false>", "fp_bwd_src_chunk_kernel<34, 8, 34, false>",
+                                 "fp_bwd_src_merge_dw_kernel<34, 8, 34>", "fp_bwd_bn_kernel<34>"],
     "sn2_fp_forward:34+8->34": ["fp_src_table_kernel<34, 8, 34>", "fp_fwd_rows_kernel<34, 8, 34, false>"],
 }
 

@@ -55,8 +55,9 @@ K["sa_mfma_fwd_kernel<16, 1, 32, 32, 1, false>"] = ("SA2 forward", 4 * E2 + 80 *
 K["sa_mfma_bwd_kernel<16, 1, 32, 32, 3, false>"] = ("SA2 backward", 4 * E2 + 80 * M1 * B + 16 * M2 * B + 256 * M2 * B, (80 + 64) * E2, (1216 + 1216 + 1024) * E2)
 K["scatter_max_kernel<0>"] = ("plot-wise projection: scatter-max", (8 + 16 + 4) * R + 24 * 400 * B, None, 0)
 K["fp_fwd_rows_kernel<34, 8, 34, false>"] = ("FP1 forward, row pass (source-side form)", (24 + 32 + 144) * R, 3 * 144 * R, 0)
-K["fp_bwd_rows_kernel<34, 8, 34, 512, false>"] = ("FP1 backward, row pass", (288 + 32 + 144) * R, None, 0)
-K["fp_bwd_src_kernel<34, 8, 34, false>"] = ("FP1 backward, source pass (gather through the inverted index)", 24 * R + 2 * 144 * M1 * B, 144 * R, 0)
+K["fp_bwd_rows_kernel<34, 8, 34, 512, false>"] = ("FP1 backward, row pass", (288 + 32 + 136) * R, None, 0)
+K["fp_bwd_src_chunk_kernel<34, 8, 34, false>"] = ("FP1 backward, source pass (rows gathered through the chunked inverted index)", (24 + 136) * R, 2 * 136 * R, 0)
+K["fp_bwd_src_merge_dw_kernel<34, 8, 34>"] = ("FP1 backward, partial rows -> G, dsrc, dW_A", (144 + 144 + 136 + 2 * 136) * M1 * B, None, 0)
 K["head_fwd_mfma_kernel<false>"] = ("head forward (lin1, lin2 on the matrix cores)", (144 + 32) * R, None, 2 * (16 * 35 + 5 * 17) * R)
 K["head_bwd_kernel<false>"] = ("head backward", (144 + 32 + 144) * R, None, 2 * (16 * 35 + 16 * 17) * R)
 K["three_nn_grid_kernel"] = ("3-NN of the N points among the level-1 centroids", 16 * R + 16 * M1 * B + 24 * R, None, 0)
