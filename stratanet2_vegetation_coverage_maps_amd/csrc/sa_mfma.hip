@@ -144,8 +144,6 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16, CS = PASS == 0 ? C1 : CL, TOS = CS / 16;
     static_assert(CF % 4 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "tile shapes");
     __shared__ float s_red[4][2 * CS];          // per wave: added in wave order => the statistics are the same on every run
-    __builtin_amdgcn_s_setprio(3);              // the feature pass is the chain a step waits for: its waves go first where they
-                                                // share a SIMD with the position-only kernels of later batches (FPS above all)
     const int lane = threadIdx.x & 63, q = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int nwaves = gridDim.x * 4;
