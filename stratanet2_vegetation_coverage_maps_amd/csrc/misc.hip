@@ -105,8 +105,11 @@ int sn2_bn_finalize_apply(const sn2_block* blk, int nslots, const unsigned long 
     if (!blk || blk->cout <= 0 || blk->cout > 64 || nslots < 0 || nslots > SN2_STAT_SLOTS || !ext || !arg || !out || rows <= 0)
         return SN2_EINVAL;
     if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
+    // training: every workgroup re-reads the statistic slots (up to 260 KB), so few of them; an eval pass reads no slots and
+    // takes as many as the rows ask for (the parcel loop's 640 000 centroids per launch)
     int grid = sn2_cdiv((long)rows * blk->cout, 8 * 1024);
-    if (grid > 32) grid = 32;
+    const int cap = training ? 32 : 2048;
+    if (grid > cap) grid = cap;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
                        blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
                        count_dev, count_imm, training, blk->num_batches_tracked, ext, arg, out, rows);
