@@ -411,6 +411,24 @@ struct SaBwdArgs {
     float* dfeat;
 };
 
+#ifdef SN2_SA_STAMPS
+// diagnostic build only (never shipped; scripts/sa_stamps.py): per-wave phase stamps of sa_mfma_bwd_kernel<8, 2, 16, 16, 3>
+__device__ unsigned long long g_sa_dbg[4096 * 10];
+extern "C" int sn2_debug_sa_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sa_dbg), sizeof(g_sa_dbg));
+}
+#define SASTAMP(i)                                                                                  \
+    if (CF == 8 && PASS == 3 && (threadIdx.x & 63) == 0 && wave < 4096) {                              \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        g_sa_dbg[wave * 10 + (i)] = t_;                                                              \
+    }
+#define SACOUNT(i, v) if (CF == 8 && PASS == 3 && (threadIdx.x & 63) == 0 && wave < 4096) g_sa_dbg[wave * 10 + (i)] = (v);
+#else
+#define SASTAMP(i)
+#define SACOUNT(i, v)
+#endif
+
 // PASS 2 = "C" (nl == 2): dW/db of block 1, dgamma/dbeta of block 0.   PASS 3 = "D": dW/db of block 0 (+ dfeat).
 template <int CF, int NL, int C1, int C2, int PASS, bool BF16>
 __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
@@ -428,6 +446,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
     const int ncent = a.B * a.M;
     float* lds_p = smem + wib * Acc::LDS_FLOATS;
     float* lds_q = lds_p + 64 * PS;
+    SASTAMP(0);
     for (int i = lane; i < Acc::LDS_FLOATS; i += 64) lds_p[i] = 0.f;
 
     const unsigned long long etot = *a.total;
@@ -519,6 +538,8 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
         for (int r = 0; r < 4; ++r) dbe0[i][r] = dga0[i][r] = 0.f;
 
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16;
+    SASTAMP(1);
+    unsigned long long n_items_dbg = 0, n_steps_dbg = 0;
     // positions of the order table: nA per plot for SOLO / QUAD items, then nB per plot for the packed ones (OCT / HEX)
     const int* trailer = a.order ? a.order + (size_t)4 * ncent + (size_t)16 * a.B * SN2_SA_PACKED_ITEMS(a.M) : nullptr;
     const int nA = trailer ? trailer[0] : 0, nB = trailer ? trailer[1] : 0;
@@ -533,6 +554,9 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
         if (qi >= nitems) continue;
         SaItem it;
         if (!sa_item(it, a.order, a.cnt, a.B, a.M, nA, nB, G, qi, c)) continue;          // an empty position
+        if (n_items_dbg == 0) { SASTAMP(2); }
+        ++n_items_dbg;
+        n_steps_dbg += (it.nmax + it.estep - 1) / it.estep;
         const int nmax = it.nmax, estep = it.estep;
         float cpq[4];
         // d loss / d output and the winning slot of this lane's 4 channels, per tile (of this lane's centroid)
@@ -745,7 +769,11 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        if (n_items_dbg == 1) { SASTAMP(3); }
     }
+    SASTAMP(4);
+    SACOUNT(8, n_items_dbg);
+    SACOUNT(9, n_steps_dbg);
 
     // ---- workgroup-level reduction (every wave's image in its own staging region, plain stores, added in wave order: LDS
     // float atomics run at ~0.4 lane-adds per clock), then one global atomic per element
@@ -780,7 +808,9 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
                 }
             }
     }
+    SASTAMP(5);
     __syncthreads();
+    SASTAMP(6);
     const int img = sn2_grad_image(a.rep_k, a.rep_stride);
     for (int i = threadIdx.x; i < NW + NB + NG; i += 256) {
         const float v = (smem[i] + smem[Acc::LDS_FLOATS + i]) + (smem[2 * Acc::LDS_FLOATS + i] + smem[3 * Acc::LDS_FLOATS + i]);
@@ -801,6 +831,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
             SN2_FLUSH_ADD(&a.dgamma0_out[i - NW - NB - C1], v);
         }
     }
+    SASTAMP(7);
 }
 
 }  // namespace
