@@ -1884,7 +1884,8 @@ struct HeadOut {
 // drop_mask / drop_scale: F.dropout(relu(lin1), p) of model/point_net2.py:142 -- bit j of the row's word set = channel j kept
 // and scaled by 1/(1-p); drop_mask == nullptr: no dropout.  z1 holds the values lin2 reads (after the dropout).
 // fv: the row's nine float4 quads (36 floats, 34 used)
-__device__ __forceinline__ void head_row_v(const float4 (&fv)[9], cfp fa, cfp fc, cfp W1, cfp b1, cfp W2, cfp b2, size_t r,
+template <class WP>
+__device__ __forceinline__ void head_row_v(const float4 (&fv)[9], WP fa, WP fc, WP W1, WP b1, WP W2, WP b2, size_t r,
                                            HeadOut& o, const int* __restrict__ drop_mask = nullptr, float drop_scale = 1.f) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
@@ -1895,12 +1896,18 @@ __device__ __forceinline__ void head_row_v(const float4 (&fv)[9], cfp fa, cfp fc
             if (4 * q + t < 34) o.y[4 * q + t] = fmaf(fa[4 * q + t], vv[t], fc[4 * q + t]);
     }
     o.y[34] = 1.f;
+    // two accumulators per output (even / odd inputs): pairs of consecutive weights and inputs are packed FMAs
+    // (v_pk_fma_f32: 2 x the rate of the scalar-operand FMA; one chain per output left 544 of the kernel's 1250 unpacked)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        float acc = b1[j];
+        f32x2 acc = {b1[j], 0.f};
 #pragma unroll
-        for (int k = 0; k < 34; ++k) acc = fmaf(W1[j * 34 + k], o.y[k], acc);
-        o.z1[j] = fmaxf(acc, 0.f);
+        for (int k = 0; k < 34; k += 2) {
+            const f32x2 w = {W1[j * 34 + k], W1[j * 34 + k + 1]}, y2 = {o.y[k], o.y[k + 1]};
+            acc = __builtin_elementwise_fma(w, y2, acc);
+        }
+        o.z1[j] = fmaxf(acc[0] + acc[1], 0.f);
     }
     if (drop_mask) {
         const int keep = drop_mask[r];
@@ -1928,9 +1935,9 @@ __device__ __forceinline__ void head_row_v(const float4 (&fv)[9], cfp fa, cfp fc
     o.dens = 1.0f / (1.0f + expf(-s[4]));
 }
 
-template <bool BF = false>
-__device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, cfp fa, cfp fc, cfp W1, cfp b1, cfp W2,
-                                         cfp b2, size_t r, HeadOut& o, const int* __restrict__ drop_mask = nullptr,
+template <bool BF = false, class WP = cfp>
+__device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stride, WP fa, WP fc, WP W1, WP b1, WP W2,
+                                         WP b2, size_t r, HeadOut& o, const int* __restrict__ drop_mask = nullptr,
                                          float drop_scale = 1.f) {
     float4 fv[9];
 #pragma unroll
