@@ -837,7 +837,7 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
                                                           int rep_stride, const int* __restrict__ row_perm, int R_per_plot) {
     constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 2, NV = 4 * (CB + 1);
     static_assert(CB > 0 && CB % 4 == 0, "skip quads");
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NV][NT]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NT / 64][HS][CB + 1]: the waves' sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane % QH, g = lane / QH;
     const bool on = lane < G * QH;
@@ -907,19 +907,31 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
             }
         }
     }
-    // per-lane partials -> LDS (plain stores) -> one sum per element and workgroup -> global atomics
+    // per-lane partials -> the wave's sums over its G row groups by lane shuffles (lanes q, q + QH, q + 2 QH, ... hold the same
+    // channel quad) -> a [wave][channel][CB + 1] image in LDS (10 KB; all lanes' partials side by side were 74 KB per
+    // workgroup: one workgroup per CU wherever an FPS workgroup holds its share of the LDS) -> one sum per element and
+    // workgroup -> global atomics
+    constexpr int NWV = NT / 64;
+    static_assert(G <= 8, "three shuffle steps add up to eight row groups");
+    float* red = smem;                                   // [NWV][HS][CB + 1]
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int k = 0; k < CB; ++k) smem[(t * (CB + 1) + k) * NT + threadIdx.x] = on ? aW[t][k] : 0.f;
-        smem[(t * (CB + 1) + CB) * NT + threadIdx.x] = on ? ab[t] : 0.f;
-    }
+        for (int k = 0; k <= CB; ++k) {
+            float v = on ? (k < CB ? aW[t][k] : ab[t]) : 0.f;
+#pragma unroll
+            for (int step = 4; step > 0; step >>= 1) {
+                const float o2 = __shfl(v, (lane + QH * step) & 63);
+                if (g < step && g + step < G) v += o2;
+            }
+            if (g == 0 && on) red[(wave * HS + 4 * q + t) * (CB + 1) + k] = v;
+        }
     __syncthreads();
     for (int e = threadIdx.x; e < CO * (CB + 1); e += NT) {
-        const int o = e / (CB + 1), k = e - o * (CB + 1), oq = o >> 2, ot = o & 3;
+        const int o = e / (CB + 1), k = e - o * (CB + 1);
         float acc = 0.f;
-        for (int w = 0; w < NT / 64; ++w)
-            for (int gg = 0; gg < G; ++gg) acc += smem[(ot * (CB + 1) + k) * NT + w * 64 + oq + QH * gg];
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) acc += red[(w * HS + o) * (CB + 1) + k];
         const int img = sn2_grad_image(rep_k, rep_stride);
         if (acc != 0.f) SN2_FLUSH_ADD(k < CB ? &dW[img + o * CI + CA + k] : &db[img + o], acc);
     }
@@ -1743,8 +1755,8 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
         if (!small && fp_source_side_ok<CA, CO>(p) && p->dsrc && !p->dskip && p->du_scratch && p->scatter_ws) {
             const int S = p->S_per_plot, Rp = p->R_per_plot, B = p->B, n_src = B * S;
             if (S > 8192) return SN2_ELIMIT;
-            constexpr int NT = 512;                       // 2 workgroups x 8 waves per CU; [4 (CB + 1)][NT] floats of LDS each
-            constexpr size_t lb1 = (size_t)4 * (CB + 1) * NT * sizeof(float);
+            constexpr int NT = 512;                       // 2 workgroups x 8 waves per CU
+            constexpr size_t lb1 = (size_t)(NT / 64) * (4 * ((CO + 3) / 4)) * (CB + 1) * sizeof(float);
             auto k1 = p->act_bf16 ? &fp_bwd_rows_kernel<CA, CB, CO, NT, true> : &fp_bwd_rows_kernel<CA, CB, CO, NT, false>;
             if (lb1 > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb1);
