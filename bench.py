@@ -290,6 +290,13 @@ def cpu_baseline():
                       f"torch {torch.get_num_threads()} threads + scipy cKDTree"}
 
 
+# batches one geometry pass of the pipelined loop covers (stratanet2_vegetation_coverage_maps_amd/pipeline.py: `group`).  FPS is one
+# workgroup per plot and a fixed number of sequential rounds, so a pass over 8 batches takes as long as a pass over one, and
+# what its workgroups cost the feature pass beside them is the TIME they are resident, not the CUs they hold (DESIGN.md
+# section 4): 1 batch per pass 0.96 ms/step, 2: 0.831, 4: 0.792, 8: 0.776, 16: 0.806 (128 plots: a third of the chip's CUs).
+PIPE_GROUP = int(os.environ.get("SN2_PIPE_GROUP", "8"))
+
+
 def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slots):
     """Model, optimiser, resident input slots and the feature-step closure of one training workload (the step of
     /root/reference/learning/train.py:52-66 minus exchange + optimiser)."""
@@ -340,11 +347,11 @@ def step_model_figures(B, n_points, m1, m2, e1, e2):
 
 
 def secondary_train_leg(dev, arch, B, n_points, dtype, steps, warmup, depth=3):
-    """One more training configuration through the SAME software-pipelined loop as the headline (pair mode, one hipGraph per
+    """One more training configuration through the SAME software-pipelined loop as the headline (PIPE_GROUP batches per geometry pass, one hipGraph per
     slot), compact: ms/step, plots/s and the whole step against both roofs.  Single GPU, inputs resident."""
     from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
-    w = build_training(dev, dev.index or 0, 0, 1, B, n_points, arch, dtype, 2 * depth + 2)
-    pipe = TrainPipeline(w.model, w.opt, w.feature_step, w.slots, depth=depth)
+    w = build_training(dev, dev.index or 0, 0, 1, B, n_points, arch, dtype, PIPE_GROUP * depth + PIPE_GROUP)
+    pipe = TrainPipeline(w.model, w.opt, w.feature_step, w.slots, depth=depth, group=PIPE_GROUP)
     pipe.capture()
     pipe.prime()
     for _ in range(warmup):
@@ -515,8 +522,8 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="headline = the unpipelined step (geometry and features of a batch back to back on one stream)")
     ap.add_argument("--depth", type=int, default=3, help="geometry passes kept in flight ahead of the feature pass")
-    ap.add_argument("--no-pair", action="store_true", help="one geometry pass per batch (default: one pass covers two "
-                    "consecutive batches -- FPS is one workgroup per plot, so 32 plots take as long as 16)")
+    ap.add_argument("--no-pair", action="store_true", help="one geometry pass per batch (default: one pass covers PIPE_GROUP = 8 "
+                    "consecutive batches -- FPS is one workgroup per plot, so 128 plots take as long as 16)")
     ap.add_argument("--points", type=int, default=N_POINTS, help="points per plot (default = the metric's 32768; other "
                     "values are extra measurements, e.g. 131072 with --plots 8 for BASELINE config 5's plot size)")
     ap.add_argument("--plots", type=int, default=PLOTS_PER_GPU, help="plots per GPU (default = the metric's 16)")
@@ -567,7 +574,8 @@ def main():
         return
     B, N_POINTS = a.plots, a.points
     # depth+1 resident batches (the pipeline's slots)
-    n_slots = 1 if a.serial else (a.depth + 1 if a.no_pair else 2 * a.depth + 2)
+    pipe_group = 1 if a.no_pair else PIPE_GROUP
+    n_slots = 1 if a.serial else pipe_group * a.depth + pipe_group
     w = build_training(dev, local_rank, rank, world, B, N_POINTS, a.arch, a.dtype, n_slots)
     args, model, opt, slots, feature_step = w.args, w.model, w.opt, w.slots, w.feature_step
     data = slots[0]
@@ -647,7 +655,7 @@ def main():
         # side streams while batch i's feature pass (one hipGraph per slot) runs; the all-reduce stays an eager RCCL call
         from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
         pipe = TrainPipeline(model, opt, feature_step, slots, depth=a.depth, use_graph=not a.eager,
-                             split_exchange=True if a.split_exchange else None)
+                             split_exchange=True if a.split_exchange else None, group=pipe_group)
         pipe.capture()                               # a failed hipGraph capture raises: no silent eager fallback
         launch = "eager" if a.eager else "hipGraph"
         if a.host_inputs:
@@ -656,7 +664,7 @@ def main():
         pipe.prime()
         for _ in range(a.warmup):
             pipe.step()
-        mode = (f"pipelined depth {a.depth}" + (", one geometry pass per two batches" if pipe.pair else "") + f"/{launch}" +
+        mode = (f"pipelined depth {a.depth}" + (f", one geometry pass per {pipe.group} batches" if pipe.pair else "") + f"/{launch}" +
                 (" + H2D of every batch from pinned host memory" if a.host_inputs else ""))
     log(f"mode: {mode}")
 
@@ -772,7 +780,7 @@ def main():
                           "mode": mode + ("" if a.serial else
                                           ": every step runs one feature pass (this batch); the position-only kernels (FPS, "
                                           "ball query, 3-NN) of every batch run exactly once, for later batches on side "
-                                          "streams" + (", two consecutive batches per launch" if (pipe is not None and pipe.pair) else "") +
+                                          "streams" + (f", {pipe.group} consecutive batches per launch" if (pipe is not None and pipe.pair) else "") +
                                           "; distinct batches in the slots"),
                           "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},

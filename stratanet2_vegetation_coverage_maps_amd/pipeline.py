@@ -8,8 +8,11 @@ forward/backward.  That matters on MI355X because FPS is M strictly sequential r
 
 The step is bound by (latency of a geometry pass under load) / (batches a pass covers x passes in flight), and the passes
 in flight by the hardware queues (three side streams + the main one; more streams share queues and serialise).  FPS is
-one workgroup per plot, so a pass over TWO batches (32 plots) has the latency of a pass over one: in pair mode
-(2*depth+2 slots, the default of bench.py) every side-stream pass delivers the tables of two consecutive batches.
+one workgroup per plot, so a pass over SEVERAL batches has the latency of a pass over one: with `group = G` (G*depth+G
+slots; bench.py runs G = 8, `pair=True` means G = 2) every side-stream pass delivers the tables of G consecutive batches.
+What the FPS workgroups cost the feature pass beside them is the time they are resident, not the CUs they hold (two plots'
+worth costs as much as thirty-two): G batches per pass divide that time by G -- 0.96 / 0.83 / 0.79 / 0.78 ms per step at
+G = 1 / 2 / 4 / 8 (C2), until the pass itself takes a third of the chip (G = 16: 0.81).
 
 Layout: `slots` = depth+1 sets of persistent buffers (inputs + `PointNet2.alloc_geometry`), `depth` side streams.
 
@@ -29,7 +32,7 @@ from .optim import allreduce_flat_grad
 
 class TrainPipeline:
     def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True, n_streams=None,
-                 split_exchange=None, pair=None):
+                 split_exchange=None, pair=None, group=None):
         """model: PointNet2 (train mode); opt: FlatAdam; slot_inputs: list of depth+1 dicts with device tensors "cloud"
         (B,10,N), "xyz" (B,3,N), "fps_start" (2,B) int32 + whatever `feature_step` needs;
         feature_step(inputs, geometry) -> loss: zero_grad, forward (with cloud_data["geometry"] = geometry),
@@ -38,13 +41,21 @@ class TrainPipeline:
         # rounds: 32 plots take as long as 16), so a side stream delivers two batches per pass.  The step is bound by
         # (latency of a geometry pass under load) / (batches it covers x passes in flight), and the passes in flight are
         # limited by the hardware queues (three side streams + the main one).  Needs 2*depth+2 slots.
-        if pair is None:
-            pair = len(slot_inputs) >= 2 * depth + 2 and len(slot_inputs) % 2 == 0 and getattr(model, "alloc_geometry_pair", None) is not None
-        self.pair = bool(pair)
-        if len(slot_inputs) < (2 * depth + 2 if self.pair else depth + 1):
-            raise ValueError("need at least depth+1 input slots (2*depth+2 in pair mode)")
-        if self.pair and len(slot_inputs) % 2:
-            raise ValueError("pair mode needs an even number of slots")
+        # group = G > 2: G consecutive batches per pass (G*depth+G slots).  The FPS workgroups cost the feature pass about as
+        # much with 2 plots as with 32: what counts is how long they are resident per step.
+        can = getattr(model, "alloc_geometry_pair", None) is not None
+        if group is None:
+            if pair is None:
+                pair = len(slot_inputs) >= 2 * depth + 2 and len(slot_inputs) % 2 == 0 and can
+            group = 2 if pair else 1
+        self.group = G = int(group)
+        self.pair = G > 1
+        if G > 1 and not can:
+            raise ValueError("this model has no grouped geometry pass")
+        if len(slot_inputs) < G * depth + G:
+            raise ValueError("need at least depth+1 input slots (G*depth+G with G batches per geometry pass)")
+        if len(slot_inputs) % G:
+            raise ValueError("the number of slots must be a multiple of the batches per geometry pass")
         self.model, self.opt, self.feature_step = model, opt, feature_step
         # the passes already run beside each other on the side streams: no further fork inside a pass
         self._geo_kw = {"fork": False, "shared": True} if hasattr(model, "geometry_fork") else {}
@@ -55,17 +66,18 @@ class TrainPipeline:
         B, _, N = slot_inputs[0]["xyz"].shape
         if self.pair:
             self.geo, self.geo_pairs, self.xyz2, self.fs2 = [None] * self.slots, [], [], []
-            for pb in range(self.slots // 2):
-                gp, (g0, g1) = model.alloc_geometry_pair(B, N, dev)
+            for pb in range(self.slots // G):
+                gp, parts = model.alloc_geometry_pair(B, N, dev, group=G) if G != 2 else model.alloc_geometry_pair(B, N, dev)
                 self.geo_pairs.append(gp)
-                self.geo[2 * pb], self.geo[2 * pb + 1] = g0, g1
-                self.xyz2.append(torch.empty(2 * B, 3, N, dtype=slot_inputs[0]["xyz"].dtype, device=dev))
-                self.fs2.append(torch.zeros(slot_inputs[0]["fps_start"].shape[0], 2 * B, dtype=torch.int32, device=dev))
+                for h in range(G):
+                    self.geo[G * pb + h] = parts[h]
+                self.xyz2.append(torch.empty(G * B, 3, N, dtype=slot_inputs[0]["xyz"].dtype, device=dev))
+                self.fs2.append(torch.zeros(slot_inputs[0]["fps_start"].shape[0], G * B, dtype=torch.int32, device=dev))
         else:
             self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
         self.B = B
         # batches the geometry may run ahead of the feature passes (never into a slot whose feature pass is not launched yet)
-        self.ahead = min(2 * depth, self.slots - 2) if self.pair else depth
+        self.ahead = min(G * depth, self.slots - G) if self.pair else depth
         self.n_streams = n_streams or depth
         self.side = [ops.shared_stream(dev, f"side{j}") for j in range(self.n_streams)]     # one set per process: hip_ops.shared_stream
         self.geo_ready = [torch.cuda.Event() for _ in range(self.slots)]
@@ -122,26 +134,26 @@ class TrainPipeline:
         self.issued = max(self.issued, i + 1)
 
     def _issue_pair(self, i):
-        """Geometry of batches i and i+1 (i even) in one pass on one side stream."""
-        i -= i % 2
+        """Geometry of the G consecutive batches i .. i+G-1 (i a multiple of G) in one pass on one side stream."""
+        G = self.group
+        i -= i % G
         B = self.B
-        k0, k1 = i % self.slots, (i + 1) % self.slots
-        pb = k0 // 2
-        st = self.side[(i // 2) % self.n_streams]
-        self._wait_slots(st, (k0, k1))
+        ks = [(i + h) % self.slots for h in range(G)]
+        pb = ks[0] // G
+        st = self.side[(i // G) % self.n_streams]
+        self._wait_slots(st, tuple(ks))
         with torch.cuda.stream(st):
-            for j, k in ((i, k0), (i + 1, k1)):
+            for h, k in enumerate(ks):
                 d = self.inputs[k]
                 if self.feeder is not None:
-                    for name, t in self.feeder(j).items():
+                    for name, t in self.feeder(i + h).items():
                         d[name].copy_(t, non_blocking=not self.feeder_blocking)
-                h = k - k0
                 self.xyz2[pb][h * B:(h + 1) * B].copy_(d["xyz"], non_blocking=True)
                 self.fs2[pb][:, h * B:(h + 1) * B].copy_(d["fps_start"], non_blocking=True)
-            self.model._geometry_pair(self.xyz2[pb], self.fs2[pb], self.geo_pairs[pb], (self.geo[k0], self.geo[k1]))
-            self.geo_ready[k0].record(st)
-            self.geo_ready[k1].record(st)
-        self.issued = max(self.issued, i + 2)
+            self.model._geometry_pair(self.xyz2[pb], self.fs2[pb], self.geo_pairs[pb], tuple(self.geo[k] for k in ks))
+            for k in ks:
+                self.geo_ready[k].record(st)
+        self.issued = max(self.issued, i + G)
 
     def _exchange_and_update(self, k):
         g = self.flat_grad[k]
@@ -152,7 +164,7 @@ class TrainPipeline:
         """Warm every slot eagerly (allocator, lazy loads), then capture each slot's feature pass.  Geometry of all
         slots must be valid while warming: computed here, and left valid for steps 0..slots-1."""
         main = torch.cuda.current_stream(self.dev)
-        for i in range(0, self.slots, 2 if self.pair else 1):
+        for i in range(0, self.slots, self.group):
             self.issue_geometry(i)
         self.issued = 0
         for st in self.side:
@@ -191,7 +203,7 @@ class TrainPipeline:
         self._run_ahead()
 
     def _run_ahead(self):
-        step = 2 if self.pair else 1
+        step = self.group
         while self.issued + step <= self.done + self.ahead:
             self.issue_geometry(self.issued)
 

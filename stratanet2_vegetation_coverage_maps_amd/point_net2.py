@@ -340,16 +340,16 @@ class PointNet2(nn.Module):
             cur.wait_stream(sc)
         return g
 
-    def alloc_geometry_pair(self, B, N, device=None):
-        """Buffers for `_geometry_pair`: the position-only kernels of TWO batches of B plots launched together (FPS is one
-        workgroup per plot and M sequential rounds: two batches take as long as one), plus the two per-batch views the
-        feature passes read.  -> (combined buffers, (geometry of the first batch, geometry of the second))."""
+    def alloc_geometry_pair(self, B, N, device=None, group=2):
+        """Buffers for `_geometry_pair`: the position-only kernels of `group` (2, or more) batches of B plots launched together
+        (FPS is one workgroup per plot and M sequential rounds: several batches take as long as one), plus the per-batch views
+        the feature passes read.  -> (combined buffers, (geometry of the first batch, of the second, ...))."""
         dev = torch.device(device if device is not None else self.lin1.weight.device)
         M1, M2 = self._sizes(N)
-        gp = self.alloc_geometry(2 * B, N, dev)
+        gp = self.alloc_geometry(group * B, N, dev)
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
         halves = []
-        for h in range(2):
+        for h in range(group):
             g = _Saved()
             g.B, g.N, g.M1, g.M2 = B, N, M1, M2
             pl, r1, r2, rn = slice(h * B, (h + 1) * B), slice(h * B * M1, (h + 1) * B * M1), \
@@ -370,11 +370,11 @@ class PointNet2(nn.Module):
         return gp, tuple(halves)
 
     def _geometry_pair(self, xyz2, fps_start2, gp, halves):
-        """`_geometry` for two batches at once: xyz2 (2B,3,N), fps_start2 (2,2B); FPS, ball queries and 3-NN tables run on
-        the 2B plots in one launch each (into `gp`), the per-batch products (message totals, SA work items, inverted 3-NN
-        indices) per half.  Same tables as two `_geometry` calls."""
+        """`_geometry` for len(halves) batches at once: xyz2 (G B,3,N), fps_start2 (2,G B); FPS, ball queries and 3-NN tables
+        run on all plots in one launch each (into `gp`), the per-batch products (message totals, SA work items, inverted 3-NN
+        indices) per batch.  Same tables as G `_geometry` calls."""
         B2, _, N = xyz2.shape
-        B = B2 // 2
+        B = B2 // len(halves)
         M1, M2 = self._sizes(N)
         if (gp.B, gp.N) != (B2, N):
             raise ValueError("geometry buffers do not match this batch pair")

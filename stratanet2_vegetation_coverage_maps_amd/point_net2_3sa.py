@@ -65,15 +65,15 @@ class PointNet2ThreeSA(PointNet2):
         return self._sizes3(N)[:2]
 
     # ------------------------------------------------------------------------------------------ geometry
-    def alloc_geometry_pair(self, B, N, device=None):
-        """As `PointNet2.alloc_geometry_pair` with the third ball-query level: buffers of one geometry pass over TWO batches
-        and the two per-batch views the feature passes read."""
+    def alloc_geometry_pair(self, B, N, device=None, group=2):
+        """As `PointNet2.alloc_geometry_pair` with the third ball-query level: buffers of one geometry pass over `group` batches
+        and the per-batch views the feature passes read."""
         dev = torch.device(device if device is not None else self.lin1.weight.device)
         M1, M2, M3 = self._sizes3(N)
-        gp = self.alloc_geometry(2 * B, N, dev)
+        gp = self.alloc_geometry(group * B, N, dev)
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
         halves = []
-        for h in range(2):
+        for h in range(group):
             g = _Saved()
             g.B, g.N, g.M1, g.M2, g.M3 = B, N, M1, M2, M3
             pl = slice(h * B, (h + 1) * B)
@@ -103,7 +103,7 @@ class PointNet2ThreeSA(PointNet2):
         """`_geometry` for two batches at once: xyz2 (2B,3,N), fps_start2 (3,2B); FPS, ball queries and 3-NN tables on the 2B
         plots in one launch each (into `gp`), the per-batch products (message totals, work items, inverted indices) per half."""
         B2, _, N = xyz2.shape
-        B = B2 // 2
+        B = B2 // len(halves)
         M1, M2, M3 = self._sizes3(N)
         if (gp.B, gp.N) != (B2, N):
             raise ValueError("geometry buffers do not match this batch pair")

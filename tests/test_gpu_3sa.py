@@ -35,14 +35,16 @@ def test_3sa_forward_backward_vs_oracle(B, N, ratio1):
     assert not fails, "\n".join(fails)
 
 
-@pytest.mark.parametrize("pair", [False, True])
+@pytest.mark.parametrize("pair", [False, True, 4])
 def test_3sa_in_the_pipelined_loop_matches_the_plain_loop(pair):
     """`bench.py --arch 3sa` drives this model through TrainPipeline (geometry passes on side streams -- one per batch, or one
     per two batches in pair mode --, feature graphs per slot): the same losses as the plain loop."""
     from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters
     from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
-    N, B, depth, steps = 4096, 2, 2, 8 if pair else 6
-    n_slots = 2 * depth + 2 if pair else depth + 1
+    G = int(pair) if pair not in (False, True) else (2 if pair else 1)          # batches per geometry pass
+    pair = G > 1
+    N, B, depth, steps = 4096, 2, 2, (2 * G + 4) if pair else 6
+    n_slots = G * depth + G
 
     def setup():
         args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0, ratio3=0.25, r3=4.0)
@@ -76,8 +78,8 @@ def test_3sa_in_the_pipelined_loop_matches_the_plain_loop(pair):
         ref.append(float(fstep(slots[i % len(slots)]).detach()))
         opt.step()
     model2, opt2, slots2, fstep2 = setup()
-    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth)
-    assert pipe.pair == pair
+    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, group=G)
+    assert pipe.pair == pair and pipe.group == G
     pipe.capture()
     pipe.prime()
     got = [float(pipe.step().detach()) for _ in range(steps)]

@@ -56,11 +56,14 @@ def _assert_same_losses(got, ref):
 
 
 @pytest.mark.parametrize("use_graph,split,pair", [(False, False, False), (True, False, False), (True, True, False),
-                                                  (False, False, True), (True, True, True)])
+                                                  (False, False, True), (True, True, True), (True, False, 4), (False, True, 3)])
 def test_pipeline_matches_plain_loop(use_graph, split, pair):
-    """pair: one geometry pass per TWO batches (2*depth+2 slots), the mode bench.py runs."""
-    N, B, depth, steps = 4096, 2, 2, 9 if pair else 7
-    n_slots = 2 * depth + 2 if pair else depth + 1
+    """pair: one geometry pass per TWO batches (2*depth+2 slots); an integer G > 2: per G batches (G*depth+G slots: the
+    mode bench.py runs, G = 8)."""
+    G = int(pair) if pair not in (False, True) else (2 if pair else 1)
+    pair = G > 1
+    N, B, depth, steps = 4096, 2, 2, (2 * G + 5) if pair else 7
+    n_slots = G * depth + G
     model, opt, slots, fstep = _setup(N, B, depth, n_slots)
     ref_losses = []
     for i in range(steps):
@@ -71,8 +74,8 @@ def test_pipeline_matches_plain_loop(use_graph, split, pair):
     ref_rm = model.fp1_module.nn[0][2].running_mean.clone()
 
     model2, opt2, slots2, fstep2 = _setup(N, B, depth, n_slots)
-    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=use_graph, split_exchange=split)
-    assert pipe.pair == pair
+    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=use_graph, split_exchange=split, group=G)
+    assert pipe.pair == pair and pipe.group == G
     pipe.capture()
     # capture() warms each slot with feature passes that update the BN running statistics but not the weights; reset
     # the model/optimiser state so both loops start equal
@@ -92,11 +95,12 @@ def test_pipeline_matches_plain_loop(use_graph, split, pair):
     # weights within nine steps; a missed or doubled update would show in the optimiser's step counter
     dp = np.abs(model2._flat_params.cpu().numpy() - ref_params.cpu().numpy())
     drm = np.abs(model2.fp1_module.nn[0][2].running_mean.cpu().numpy() - ref_rm.cpu().numpy()).max()
-    # stated bounds = 4 x the largest value ever measured (parameters 5e-4, running mean 5.3e-4), far below what a real
-    # defect shows (a missed, doubled or misplaced update: 1e-2 and more); the measured values of this run are printed
-    print(f"\n[pipeline graph={use_graph} split={split} pair={pair}] max |d parameters| {dp.max():.2e} (bound 2e-3), "
+    # stated bounds = 2.5 x the largest value ever measured (parameters 1.6e-3 after the 11 steps of the G = 3 case, 5e-4 after
+    # 9; running mean 6.6e-4), below what a real defect shows (a missed, doubled or misplaced update: 1e-2 and more); the
+    # measured values of this run are printed
+    print(f"\n[pipeline graph={use_graph} split={split} pair={pair}] max |d parameters| {dp.max():.2e} (bound 4e-3), "
           f"max |d running mean| {drm:.2e} (bound 2e-3), max |d loss| {np.abs(np.array(got) - np.array(ref_losses)).max():.2e}")
-    assert dp.max() < 2e-3, dp.max()
+    assert dp.max() < 4e-3, dp.max()
     assert int(opt2.step_dev.item()) == steps == int(opt.step_dev.item())
     np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(), ref_rm.cpu().numpy(), atol=2e-3)   # the same drift (seen: 5.3e-4); one update more or less: 1e-2
 
