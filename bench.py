@@ -605,9 +605,15 @@ def main():
     # which entry point gets the roofline: the longest one ON THE CRITICAL PATH of the timed mode.  Pipelined: the
     # geometry passes (FPS, ball query, 3-NN) run on side streams under the feature pass, which is what bounds the step, so
     # the candidates are the feature-pass entry points; serial: every entry point.  Measured on a second (warm) step.
-    with ops.timing() as t1:
-        step()
-    prof = t1.summary()
+    # (the shortest of three warm steps per entry point: a single measurement once made the 8 us Adam kernel the "longest"
+    # entry point -- an event record that waited on something else)
+    prof = {}
+    for _ in range(3):
+        with ops.timing() as t1:
+            step()
+        for k, v in t1.summary().items():
+            if k not in prof or v[1] < prof[k][1]:
+                prof[k] = v
     GEOMETRY = ("sn2_fps", "sn2_ball_query", "sn2_three_nn", "sn2_interp_index", "sn2_sa_order", "sn2_count_sum")
     on_path = {k: v for k, v in prof.items() if a.serial or not k.startswith(GEOMETRY)}
     dominant = max(on_path, key=lambda k: on_path[k][1]) if on_path else None

@@ -36,7 +36,8 @@ def fstep(inp, geo=None):
     return loss
 
 
-pipe = TrainPipeline(model, opt, fstep, [mk(j) for j in range(2 * depth + 2)], depth=depth)
+GROUP = int(os.environ.get("GROUP", "8"))          # batches per geometry pass (bench.py: 8)
+pipe = TrainPipeline(model, opt, fstep, [mk(j) for j in range(GROUP * depth + GROUP)], depth=depth, group=GROUP)
 pipe.capture()
 pipe.prime()
 
@@ -53,7 +54,7 @@ def measure(n=200):
 
 
 base = measure()
-print(f"all entry points: {base:.4f} ms/step (pair mode {pipe.pair})", flush=True)
+print(f"all entry points: {base:.4f} ms/step ({pipe.group} batches per geometry pass)", flush=True)
 if os.environ.get("ONLY_BASE"):
     pipe.drain(); torch.cuda.synchronize(); sys.exit(0)
 real = {}
@@ -96,7 +97,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "overhead":      # the loop's own cost: 
     torch.cuda.synchronize()
     issue = pipe.issue_geometry
     def no_issue(i):
-        pipe.issued = max(pipe.issued, i + (2 if pipe.pair else 1))
+        pipe.issued = max(pipe.issued, i + pipe.group)
     pipe.issue_geometry = no_issue
     print(f"no geometry pass issued (main stream: wait on an old event, graph, record): {measure():.4f} ms/step", flush=True)
     k = [0]
