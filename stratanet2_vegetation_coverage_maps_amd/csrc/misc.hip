@@ -10,8 +10,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
                                    float* __restrict__ a, float* __restrict__ c, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, const float* __restrict__ slots, int nslots,
                                    const unsigned long long* __restrict__ count_dev, long count_imm, int training,
-                                   long long* __restrict__ num_batches_tracked, const float* __restrict__ ext,
-                                   const int* __restrict__ arg, float* __restrict__ out, int rows) {
+                                   long long* __restrict__ num_batches_tracked) {
     // thread = (slot group g, column col of the 2C-wide slot row): consecutive threads read consecutive floats of one slot
     // row (coalesced; one lane per (channel, 16 slots) with a 2C-float stride took 13 us for 1024 slots), every thread adds
     // its slots g, g+G, ... in fp64 in a fixed order, then the G partials of a column are added in a fixed order: the
@@ -42,50 +41,31 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
             s2 += s_part[gg * W2 + C + o];
         }
     }
-    // With `out` (the set-abstraction levels): several workgroups, every one of them computes the same statistics from the same
-    // slots in the same order -- bit-identical -- and then applies the affine to its share of the extremum rows,
-    // out = a * ext + c (0 where no message arrived): what used to be a kernel of its own behind this one.  Workgroup 0 alone
-    // writes the BatchNorm's buffers.
-    __shared__ float s_a[64], s_c[64];
+    const int j = 0;
     const float eps = 1e-5f, mom = 0.1f;
-    const bool writer = blockIdx.x == 0;
-    if (live) {
-        if (writer && training && o == 0 && num_batches_tracked) *num_batches_tracked += 1;   // BatchNorm1d's counter: once per training forward
-        float mean, invstd;
-        if (training) {
-            double n = count_dev ? (double)(*count_dev) : (double)count_imm;
-            if (n < 1.0) n = 1.0;
-            const double m = s1 / n;
-            double var = s2 / n - m * m;
-            if (var < 0.0) var = 0.0;
-            mean = (float)m;
-            invstd = 1.0f / sqrtf((float)var + eps);
-            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-            if (writer) {
-                running_mean[o] = (1.f - mom) * running_mean[o] + mom * mean;
-                running_var[o] = (1.f - mom) * running_var[o] + mom * (float)unbiased;
-            }
-        } else {
-            mean = running_mean[o];
-            invstd = 1.0f / sqrtf(running_var[o] + eps);
-        }
-        const float aa = gamma[o] * invstd, cc = beta[o] - mean * aa;
-        s_a[o] = aa;
-        s_c[o] = cc;
-        if (writer) {
-            a[o] = aa;
-            c[o] = cc;
-            mean_out[o] = mean;
-            invstd_out[o] = invstd;
-        }
+    if (!live || j != 0) return;
+    if (training && o == 0 && num_batches_tracked) *num_batches_tracked += 1;   // BatchNorm1d's counter: once per training forward
+    float mean, invstd;
+    if (training) {
+        double n = count_dev ? (double)(*count_dev) : (double)count_imm;
+        if (n < 1.0) n = 1.0;
+        const double m = s1 / n;
+        double var = s2 / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = 1.0f / sqrtf((float)var + eps);
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[o] = (1.f - mom) * running_mean[o] + mom * mean;
+        running_var[o] = (1.f - mom) * running_var[o] + mom * (float)unbiased;
+    } else {
+        mean = running_mean[o];
+        invstd = 1.0f / sqrtf(running_var[o] + eps);
     }
-    if (!out) return;
-    __syncthreads();
-    const long n_el = (long)rows * C;
-    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n_el; i += (long)gridDim.x * 1024) {
-        const int ch = (int)(i % C);
-        out[i] = arg[i] >= 0 ? fmaf(s_a[ch], ext[i], s_c[ch]) : 0.f;
-    }
+    const float aa = gamma[o] * invstd;
+    a[o] = aa;
+    c[o] = beta[o] - mean * aa;
+    mean_out[o] = mean;
+    invstd_out[o] = invstd;
 }
 
 int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm, int training,
@@ -94,25 +74,7 @@ int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* 
     if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
                        blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
-                       count_dev, count_imm, training, blk->num_batches_tracked, (const float*)nullptr, (const int*)nullptr,
-                       (float*)nullptr, 0);
-    SN2_RETURN_LAUNCH();
-}
-
-// the same + out = a * ext + c on the (rows, cout) extremum rows of a set-abstraction level (0 where arg < 0)
-int sn2_bn_finalize_apply(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm, int training,
-                          const float* ext, const int* arg, float* out, int rows, hipStream_t st) {
-    if (!blk || blk->cout <= 0 || blk->cout > 64 || nslots < 0 || nslots > SN2_STAT_SLOTS || !ext || !arg || !out || rows <= 0)
-        return SN2_EINVAL;
-    if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
-    // training: every workgroup re-reads the statistic slots (up to 260 KB), so few of them; an eval pass reads no slots and
-    // takes as many as the rows ask for (the parcel loop's 640 000 centroids per launch)
-    int grid = sn2_cdiv((long)rows * blk->cout, 8 * 1024);
-    const int cap = training ? 32 : 2048;
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
-                       blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
-                       count_dev, count_imm, training, blk->num_batches_tracked, ext, arg, out, rows);
+                       count_dev, count_imm, training, blk->num_batches_tracked);
     SN2_RETURN_LAUNCH();
 }
 
