@@ -297,7 +297,72 @@ def cpu_baseline():
 PIPE_GROUP = int(os.environ.get("SN2_PIPE_GROUP", "8"))
 
 
-def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slots):
+def pipe_group_for(steps):
+    """Batches per geometry pass for a timed region of `steps` steps: PIPE_GROUP when it divides `steps`, else the best divisor
+    of `steps` near it -- so that the region launches EXACTLY `steps` batches' worth of FPS / ball query / 3-NN (round 3's
+    driver-timed line ran 20 steps with 8 batches per pass: three passes = 24 batches of geometry for 20 feature passes)."""
+    if "SN2_PIPE_GROUP" in os.environ or steps % PIPE_GROUP == 0:
+        return PIPE_GROUP
+    for g in (5, 10, 4, 6, 7, 3, 2):
+        if steps % g == 0:
+            return g
+    return PIPE_GROUP
+
+
+def pipe_phase_for(group, warmup, steps):
+    """TrainPipeline.phase: passes are issued at the end of the steps that complete batch numbers = phase (mod group).  Chosen so
+    that the LAST pass launched inside the timed region is launched group - 1 steps before the region ends: the region ends
+    with every stream drained, and a pass launched at its very last step would be waited for in full (1.4 ms = 0.07 ms per
+    step of a 20-step region) although the loop, left running, overlaps it.  Steady-state throughput does not depend on it."""
+    return (warmup + steps + 1) % group
+
+
+_ONE_RANK_GROUP = [False]
+
+
+def make_exchange(kind, dev, world):
+    """The gradient exchange of a training leg -> (rccl communicator or None, force torch's all_reduce at world 1, description).
+    "rccl": `ncclAllReduce` through the direct binding (stratanet2_vegetation_coverage_maps_amd/rccl.py) on the step's own stream,
+    INSIDE the slot's hipGraph, at any world size (world 1: a one-rank communicator -- the collective call still runs);
+    "torch": torch.distributed.all_reduce between the backward graph and the Adam graph (at world 1 over a one-rank process
+    group, so that the call really happens); "none": no exchange (only valid at world 1);
+    "auto": none at world 1; at world > 1 rccl if every rank's self-test passes (agreed on through torch's group), else torch."""
+    from stratanet2_vegetation_coverage_maps_amd import rccl
+    dist = torch.distributed
+    if kind == "auto":
+        if world == 1:
+            return None, False, "none (single GPU)"
+        ok, comm, why = 1, None, ""
+        try:
+            comm = rccl.comm_from_torch_group(dev)
+            rccl.self_test(comm, graph=True)
+        except Exception as exc:                     # noqa: BLE001
+            ok, why = 0, f"{type(exc).__name__}: {exc}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return comm, False, f"rccl {rccl.version()} ncclAllReduce inside the step's hipGraph (direct binding; self-test passed on all ranks)"
+        log(f"direct RCCL exchange not used ({why or 'another rank failed its self-test'}): torch.distributed.all_reduce between two graphs")
+        return None, False, "torch.distributed.all_reduce (nccl backend) between the backward graph and the Adam graph"
+    if kind == "rccl":
+        comm = rccl.comm_from_torch_group(dev)
+        rccl.self_test(comm, graph=True)
+        return comm, False, f"rccl {rccl.version()} ncclAllReduce inside the step's hipGraph (direct binding, {comm.world} rank(s))"
+    if kind == "torch":
+        if world == 1 and not dist.is_initialized():
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            _ONE_RANK_GROUP[0] = True
+        return None, True, "torch.distributed.all_reduce (nccl backend) between the backward graph and the Adam graph"
+    if world > 1:
+        raise SystemExit("--exchange none needs --gpus 1")
+    return None, False, "none (single GPU)"
+
+
+def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slots, exchange="auto"):
     """Model, optimiser, resident input slots and the feature-step closure of one training workload (the step of
     /root/reference/learning/train.py:52-66 minus exchange + optimiser)."""
     from types import SimpleNamespace
@@ -313,7 +378,9 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
         model = PointNet2(args).train()
     n_fps = 3 if arch == "3sa" else 2
     flatten_parameters(model)
-    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world)     # config.py:84,97
+    comm, force, exchange_desc = make_exchange(exchange, dev, world)
+    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world, comm=comm)     # config.py:84,97
+    opt.force_exchange = force
     # batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
     slots = []
     for j in range(n_slots):
@@ -334,7 +401,8 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
         loss.backward()
         return loss
 
-    return SimpleNamespace(args=args, model=model, opt=opt, slots=slots, feature_step=feature_step, n_fps=n_fps)
+    return SimpleNamespace(args=args, model=model, opt=opt, slots=slots, feature_step=feature_step, n_fps=n_fps,
+                           exchange=exchange_desc, split=True if force else None)
 
 
 def step_model_figures(B, n_points, m1, m2, e1, e2):
@@ -346,12 +414,14 @@ def step_model_figures(B, n_points, m1, m2, e1, e2):
     return B * 2.2 * fwd_bytes, B * (3 * fwd_flops - 352 * E1p)
 
 
-def secondary_train_leg(dev, arch, B, n_points, dtype, steps, warmup, depth=3):
-    """One more training configuration through the SAME software-pipelined loop as the headline (PIPE_GROUP batches per geometry pass, one hipGraph per
-    slot), compact: ms/step, plots/s and the whole step against both roofs.  Single GPU, inputs resident."""
+def secondary_train_leg(dev, arch, B, n_points, dtype, steps, warmup, depth=3, exchange="none"):
+    """One more training configuration through the SAME software-pipelined loop as the headline (pipe_group_for(steps) batches per
+    geometry pass, one hipGraph per slot), compact: ms/step, plots/s and the whole step against both roofs.  Single GPU, inputs resident."""
     from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
-    w = build_training(dev, dev.index or 0, 0, 1, B, n_points, arch, dtype, PIPE_GROUP * depth + PIPE_GROUP)
-    pipe = TrainPipeline(w.model, w.opt, w.feature_step, w.slots, depth=depth, group=PIPE_GROUP)
+    G = pipe_group_for(steps)
+    w = build_training(dev, dev.index or 0, 0, 1, B, n_points, arch, dtype, G * depth + G, exchange=exchange)
+    pipe = TrainPipeline(w.model, w.opt, w.feature_step, w.slots, depth=depth, group=G, phase=pipe_phase_for(G, warmup, steps),
+                         split_exchange=w.split)
     pipe.capture()
     pipe.prime()
     for _ in range(warmup):
@@ -370,15 +440,34 @@ def secondary_train_leg(dev, arch, B, n_points, dtype, steps, warmup, depth=3):
     by, fl = step_model_figures(B, n_points, m1, m2, e1, e2)       # the reference architecture's terms (3sa: a lower bound)
     peak = {"f32": 157.3e12, "bf16": 2.5e15}[dtype]
     out = {"arch": arch, "plots_per_gpu": B, "points_per_plot": n_points, "dtype": dtype, "steps": steps, "warmup": warmup,
-           "ms_per_step": round(ms, 4), "plots_per_s": round(B / (ms * 1e-3), 2), "loss": round(float(loss.item()), 6),
+           "batches_per_geometry_pass": G, "exchange": w.exchange, "ms_per_step": round(ms, 4), "plots_per_s": round(B / (ms * 1e-3), 2), "loss": round(float(loss.item()), 6),
            "messages_sa1": e1, "messages_sa2": e2,
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(by / (ms * 1e-3) / 1e9, 2),
                         "frac": round(by / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4), "compulsory_bytes": int(by),
                         "dense_flops": int(fl), "mfma_frac": round(fl / (ms * 1e-3) / peak, 4),
                         "what": "whole step: SURVEY.md 8d compulsory bytes / dense flops of the reference architecture's "
                                 "layers at the measured message counts over ms_per_step"}}
+    if w.opt.comm is not None:
+        w.opt.comm.destroy()
     del pipe, w
     torch.cuda.empty_cache()
+    return out
+
+
+def exchange_leg(dev, steps=100, warmup=10):
+    """The metric's workload on ONE GPU with the gradient exchange really executed: (a) `ncclAllReduce` through
+    the direct RCCL binding, captured INSIDE each slot's hipGraph (one graph per step: the launch sequence of an N-GPU run),
+    (b) torch.distributed.all_reduce over a one-rank nccl process group between the backward graph and the Adam graph (the
+    fallback's launch sequence), (c) no exchange.  Same loop, same kernels; only the exchange differs."""
+    out = {}
+    for kind in ("rccl", "torch", "none"):
+        r = secondary_train_leg(dev, "ref", PLOTS_PER_GPU, 32768, "f32", steps, warmup, exchange=kind)
+        out[kind] = {"ms_per_step": r["ms_per_step"], "plots_per_s": r["plots_per_s"], "exchange": r["exchange"], "loss": r["loss"]}
+    if _ONE_RANK_GROUP[0]:
+        torch.distributed.destroy_process_group()
+        _ONE_RANK_GROUP[0] = False
+    out["what"] = ("C2 ref-arch on one GPU, world size 1: the same pipelined loop with the exchange step executed by RCCL through "
+                   "the direct binding inside the graph / by torch's process group between two graphs / not at all")
     return out
 
 
@@ -506,7 +595,8 @@ def secondary_legs(dev):
             "config5_128k_bf16": lambda: secondary_train_leg(dev, "ref", 8, 131072, "bf16", 50, 6),
             "config4_parcel_inference": lambda: inference_leg(dev),
             "config4_parcel_inference_bf16": lambda: inference_leg(dev, dtype="bf16"),
-            "dropin_eager": lambda: dropin_eager_leg(dev, 16, 32768)}
+            "dropin_eager": lambda: dropin_eager_leg(dev, 16, 32768),
+            "exchange_world1": lambda: exchange_leg(dev)}
 
 
 def main():
@@ -538,7 +628,12 @@ def main():
                     help="f32 = the reference's precision (the metric); bf16 = BASELINE config 5's variant: bfloat16 operands on the "
                          "matrix cores (SA levels and the dense layers over centroids), fp32 accumulate, fp32 everywhere else")
     ap.add_argument("--split-exchange", action="store_true",
-                    help="one GPU: use the multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
+                    help="one GPU: use the fallback's multi-GPU launch sequence (backward graph, eager exchange, Adam graph)")
+    ap.add_argument("--exchange", choices=("auto", "rccl", "torch", "none"), default="auto",
+                    help="the gradient exchange: rccl = ncclAllReduce through the direct binding inside the step's hipGraph (any "
+                         "world size, also 1); torch = torch.distributed.all_reduce between two graphs (also at world 1, over a "
+                         "one-rank group); auto = none at 1 GPU, rccl at N > 1 when every rank's self-test passes, else torch")
+    ap.add_argument("--force-exchange", action="store_true", help="same as --exchange rccl: run the collective even at --gpus 1")
     ap.add_argument("--only-leg", default=None,
                     help="run ONE secondary leg by name and print its JSON (no headline): config2_3sa_arch, config5_128k_f32, "
                          "config5_128k_bf16, config4_parcel_inference, config4_parcel_inference_bf16, dropin_eager -- for profiling and experiments")
@@ -574,9 +669,11 @@ def main():
         return
     B, N_POINTS = a.plots, a.points
     # depth+1 resident batches (the pipeline's slots)
-    pipe_group = 1 if a.no_pair else PIPE_GROUP
+    pipe_group = 1 if a.no_pair else pipe_group_for(a.steps)
     n_slots = 1 if a.serial else pipe_group * a.depth + pipe_group
-    w = build_training(dev, local_rank, rank, world, B, N_POINTS, a.arch, a.dtype, n_slots)
+    if a.force_exchange:
+        a.exchange = "rccl"
+    w = build_training(dev, local_rank, rank, world, B, N_POINTS, a.arch, a.dtype, n_slots, exchange=a.exchange)
     args, model, opt, slots, feature_step = w.args, w.model, w.opt, w.slots, w.feature_step
     data = slots[0]
 
@@ -661,7 +758,8 @@ def main():
         # side streams while batch i's feature pass (one hipGraph per slot) runs; the all-reduce stays an eager RCCL call
         from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
         pipe = TrainPipeline(model, opt, feature_step, slots, depth=a.depth, use_graph=not a.eager,
-                             split_exchange=True if a.split_exchange else None, group=pipe_group)
+                             split_exchange=True if a.split_exchange else w.split, group=pipe_group,
+                             phase=pipe_phase_for(pipe_group, a.warmup, a.steps))
         pipe.capture()                               # a failed hipGraph capture raises: no silent eager fallback
         launch = "eager" if a.eager else "hipGraph"
         if a.host_inputs:
@@ -677,10 +775,15 @@ def main():
     barrier()
     t_start = time.perf_counter()
     tdom = None
+    ev_last = ev_end = None
+    issued0 = pipe.issued if pipe is not None else 0
     if pipe is not None:
         for _ in range(a.steps):
             loss = pipe.step()
+        ev_last, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_last.record()                         # behind the last feature pass
         pipe.drain()
+        ev_end.record()                          # ... and behind every geometry pass still in flight
     elif graph is not None:
         for _ in range(a.steps):
             graph.replay()
@@ -696,7 +799,10 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el.item())
-    log(f"timed region: {elapsed / a.steps * 1e3:.3f} ms/step")
+    drain_ms = None if ev_last is None else float(ev_last.elapsed_time(ev_end))
+    log(f"timed region: {elapsed / a.steps * 1e3:.3f} ms/step" + ("" if drain_ms is None else f" (of which the final drain: {drain_ms:.3f} ms in total)"))
+    if pipe is not None:
+        ops.fps_gave_up(dev)                     # (the region is over: reading the status word costs nothing now)
     loss_value = float(loss.item())
     if tdom is None:
         # graph replays / side streams cannot carry the event records: time the dominant entry point over 5 unpipelined
@@ -789,6 +895,10 @@ def main():
                                           "streams" + (f", {pipe.group} consecutive batches per launch" if (pipe is not None and pipe.pair) else "") +
                                           "; distinct batches in the slots"),
                           "plots_per_gpu": B, "points_per_plot": N_POINTS, "messages_sa1": e1, "messages_sa2": e2,
+                          "batches_per_geometry_pass": (pipe.group if pipe is not None else 1),
+                          "geometry_passes_launched_in_timed_region": (None if pipe is None else (pipe.issued - issued0) // pipe.group),
+                          "drain_ms_inside_timed_region": (None if drain_ms is None else round(drain_ms, 4)),
+                          "exchange": w.exchange,
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
                "loss": round(loss_value, 6), "roofline": roof, "kernels": kernels,
                "host_cores_of_this_rank": os.environ.get("SN2_BENCH_PINNED", f"all:{len(os.sched_getaffinity(0))}")}

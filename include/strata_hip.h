@@ -94,6 +94,17 @@ int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *id
  * Same indices whichever runs. */
 int sn2_fps_waves(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
                   float *cpos_aos, int *order_ws, int waves, void *stream);
+/* The same with a STATUS word.  The multi-workgroup kernel's workgroups wait for their peers, and HIP does not promise that
+ * the B * P workgroups of a launch are resident together (kernels of other streams or processes may hold the CUs a peer
+ * needs): every wait is bounded, a workgroup whose wait runs out leaves without writing, and a REPAIR launch that every
+ * multi-workgroup pass is followed by (the single-workgroup kernel, same stream; it reads one control word and returns when
+ * no wait gave up) samples all plots again.  The results are the reference's either way; *status (device, one 32-bit
+ * word, caller-zeroed once, or NULL) accumulates the number of waits that gave up, so that a host that synchronises anyway
+ * can tell that passes are being repeated (torch_cluster.fps has no such failure mode: model/point_net2.py:22). */
+int sn2_fps_status(const float *pos_soa, int B, int N, int M, const int *start, int *idx, float *cpos_soa,
+                   float *cpos_aos, int *order_ws, int waves, unsigned *status, void *stream);
+/* tests only: sweeps a wait of the multi-workgroup FPS makes before it gives up (0 = the default, 2^18 ~ 0.2 s) */
+int sn2_debug_fps_spin_limit(unsigned sweeps);
 
 /* radius ball query -- torch_cluster.radius, model/point_net2.py:23-25.
  * For centroid i of plot b: all source points j of plot b with d2 < r2 (strict, canonical fp32 arithmetic; r2 = the

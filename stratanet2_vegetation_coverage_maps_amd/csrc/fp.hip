@@ -970,7 +970,9 @@ __global__ __launch_bounds__(256) void fp_bwd_src_chunk_kernel(int n_chunks, int
     const int nk = (n_chunks - r0) < L ? (int)(n_chunks - r0) : L;
     const int4 it = lane < nk ? chunks[r0 + lane] : make_int4(0, 0, 0, 0);       // L <= 64
     // (the headers are awaited HERE, once: left to the loop, the wait at its top also sits out every partial row's store)
-    if (__builtin_amdgcn_readlane(it.z, 0) == 0 && __builtin_amdgcn_readlane(it.z, nk - 1) == 0) return;   // padding only
+    // padding only: NO slot of the wave holds a chunk (first and last slot empty is not enough: with plots of fewer than 64
+    // chunks a wave's range may start in one plot's padding, cover the next plot's chunks and end in that plot's padding)
+    if (__ballot(lane < nk && it.z != 0) == 0ull) return;
     int id = 0, pb = 0, m = 0, rj = 0;                               // round k = -1 only fetches the entries of chunk 0
     float wj = 0.f;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, sa0 = 0.f, sa1 = 0.f;
@@ -1701,7 +1703,13 @@ int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_
     hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, x.H, x.off, x.cnt);
     hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, (const int*)x.H,
                        (const int*)x.off, x.inv_row, x.inv_w, row_perm);
-    hipLaunchKernelGGL(inv_order_kernel, dim3(B), dim3(1024), (size_t)(((S + 3) & ~3) + S) * 4, st,
+    // keys + the source of every rank: 64 KB of dynamic LDS at the S = 8192 limit (+ ~450 B static): above the 48 KB a kernel
+    // gets without asking
+    const size_t order_lds = (size_t)(((S + 3) & ~3) + S) * 4;
+    if (order_lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)order_lds);
+    hipLaunchKernelGGL(inv_order_kernel, dim3(B), dim3(1024), order_lds, st,
                        reinterpret_cast<const float4*>(src_pos), S, x.CM, (const int*)x.off, (const int*)x.cnt, x.items, x.chunks);
     SN2_RETURN_LAUNCH();
 }

@@ -583,7 +583,8 @@ template <int SPW, int NW, int K>
 __global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restrict__ pos, int N, int M,
                                                         const int* __restrict__ start, const int* __restrict__ order,
                                                         float4* sorted, int* __restrict__ idx_out,
-                                                        float* __restrict__ cpos_soa, float* __restrict__ cpos_aos) {
+                                                        float* __restrict__ cpos_soa, float* __restrict__ cpos_aos,
+                                                        const unsigned* gate, unsigned* status) {
     constexpr int NBK = SPW * NW;
     constexpr int SL = (SPW + 63) / 64;                // bucket slots per lane of the owning wave
     constexpr int T = 4;                               // maxima every wave hands to the final selection
@@ -607,6 +608,17 @@ __global__ __launch_bounds__(NW * 64) void fps_spec_kernel(const float* __restri
     const float* pz = py + N;
     const int* ord = order + (size_t)b * N;
     float4* pts = sorted + (size_t)b * N;              // (x, y, z, running distance = +inf from spatial_order_kernel)
+    if (gate) {
+        // REPAIR launch behind fps_cluster_kernel (gate = that launch's control words): nothing to do unless one of its waits
+        // gave up (gate[1] = the count); then every plot is sampled again by this kernel, which waits for nobody.  The running
+        // distances the abandoned pass left in the sorted table go back to +inf first.
+        const unsigned gave_up = __builtin_amdgcn_readfirstlane(gate[1]);
+        if (gave_up == 0u) return;
+        for (int p = tid; p < N; p += NW * 64) fps_st_dist(pts, p, INFINITY);
+        if (b == 0 && tid == 0 && status) atomicAdd(status, gave_up);      // sticky: the host reads it where it synchronises anyway
+        __threadfence_block();
+        __syncthreads();
+    }
     float* my_box = s_box + wave * SPW;                // + component * NBK + slot; bucket of (wave, slot) = slot * NW + wave
     for (int k = 0; k < SPW; ++k) {
         const int p = (k * NW + wave) * 64 + lane;     // position in the sorted order (bucket k*NW + wave)
@@ -915,20 +927,23 @@ static size_t fps_spec_lds_bytes() {
 #endif
 template <int SPW, int NW = 16>
 static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* start, int* ws, int* idx, float* cs,
-                             float* ca, hipStream_t st, bool speculate = true) {
+                             float* ca, hipStream_t st, bool speculate = true, bool repair = false, unsigned* status = nullptr) {
     int* order = ws;                                               // B*N ints
     float4* sorted = reinterpret_cast<float4*>(ws + (size_t)B * N);   // B*N float4 (16-byte aligned: B*N*4 bytes offset
                                                                    // from a 16-byte aligned base with B*N % 4 == 0)
     int* grid = ws + (size_t)5 * B * N;                              // B*GRID_WORDS ints
     unsigned* xchg = reinterpret_cast<unsigned*>(grid + (size_t)B * GRID_WORDS);      // B*FPS_XCHG_WORDS + FPS_CTL_WORDS
-    launch_spatial_order(pos, B, N, order, sorted, grid, xchg, xchg + (size_t)B * FPS_XCHG_WORDS, st);
+    // repair = this launch follows fps_cluster_kernel on the same workspace: the tables are there, and the kernel returns at once
+    // unless the control words say that the multi-workgroup pass gave up
+    const unsigned* gate = repair ? xchg + (size_t)B * FPS_XCHG_WORDS : nullptr;
+    if (!repair) launch_spatial_order(pos, B, N, order, sorted, grid, xchg, xchg + (size_t)B * FPS_XCHG_WORDS, st);
     if (speculate) {
         constexpr int K = SN2_FPS_K;
         const size_t lds = fps_spec_lds_bytes<SPW, NW, K>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_spec_kernel<SPW, NW, K>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((fps_spec_kernel<SPW, NW, K>), dim3(B), dim3(NW * 64), lds, st, pos, N, M, start, (const int*)order,
-                           sorted, idx, cs, ca);
+                           sorted, idx, cs, ca, gate, status);
         SN2_RETURN_LAUNCH();
     }
     hipLaunchKernelGGL((fps_bucket_kernel<SPW, NW>), dim3(B), dim3(NW * 64), 0, st, pos, N, M, start, (const int*)order,
@@ -959,13 +974,17 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
 //     those of fps_spec_kernel, bit for bit (tests/test_gpu_geometry.py holds all kernels to each other and to the oracle).
 // Residency: a workgroup waits only for the P-1 peers of its plot.  Plots are handed out by a ticket counter in arrival
 // order (not by blockIdx), so the peers of every resident workgroup are resident too or are the very next workgroups to
-// start -- no dispatch-order assumption; every spin is bounded (FC_SPIN_LIMIT sweeps, then the kernel gives up, counts the
-// timeout in the control words and exits: wrong samples, never a hang).
+// start -- no dispatch-order assumption; every spin is bounded (`spin_limit` sweeps, then the kernel gives up, counts the
+// timeout in control word 1 and exits WITHOUT writing its samples: never a hang).  Nothing guarantees that the B * P workgroups
+// are resident together (another stream's or another process's kernels may hold the CUs a peer needs), so every launch of
+// this kernel is followed, on the same stream, by the single-workgroup kernel as a REPAIR launch (fps_spec_kernel with
+// `gate`): it returns at once when control word 1 is zero and samples every plot again when it is not -- the results are
+// right either way, and the count reaches the host through `status` (sn2_fps_status).
 // ------------------------------------------------------------------------------------------------------------
 typedef unsigned long long fc_u64;
 constexpr int FC_TP = 8;                     // records a workgroup publishes per super-round
 constexpr int FC_PARITY_U64 = 512;           // granules per parity (6 * 8P record fields + P bounds + P tie words <= 400)
-constexpr unsigned FC_SPIN_LIMIT = 1u << 21; // sweeps (~1 us each) before a wait gives up
+constexpr unsigned FC_SPIN_LIMIT = 1u << 18; // sweeps (~1 us each) before a wait gives up (a resident peer answers within a few)
 #ifndef SN2_FC_FLAG_SLEEP
 #define SN2_FC_FLAG_SLEEP 3
 #endif
@@ -1012,7 +1031,8 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
                                                            const int* __restrict__ start, const int* __restrict__ order,
                                                            float4* sorted, int* __restrict__ idx_out,
                                                            float* __restrict__ cpos_soa, float* __restrict__ cpos_aos,
-                                                           fc_u64* xchg_all, unsigned* ctl, int log_cap, int tau_keep) {
+                                                           fc_u64* xchg_all, unsigned* ctl, int log_cap, int tau_keep,
+                                                           unsigned spin_limit) {
     constexpr int NBL = SPW * NW;                      // buckets of this workgroup: local bucket lb = slot * NW + wave
     constexpr int SL = (SPW + 63) / 64;                // bucket slots per lane of the owning wave
     constexpr int VL = (NBL + 63) / 64;                // bucket values per lane of wave 0 in the selection
@@ -1060,7 +1080,7 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
         } else {
             unsigned o = atomicAdd(&ctl[0], 1u);
             unsigned n[8];
-            for (unsigned spins = 0; spins < FC_SPIN_LIMIT; ++spins) {
+            for (unsigned spins = 0; spins < spin_limit; ++spins) {
                 unsigned sum = 0;
                 for (int x = 0; x < 8; ++x) {
                     n[x] = __hip_atomic_load(&ctl[16 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1119,6 +1139,7 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
     int j = 1, cnt = 1;
     unsigned epoch = 0;
     float tau = -1.f;                                  // wave 0's threshold for the next selection
+    bool gave_up = false;                              // a wait ran out: leave without writing (the repair launch samples the plot)
     int* out_idx = idx_out + (size_t)b * M;
     // one sample of the plot: (x, y, z) and its code = -1 - sorted position (translated at the end) or the original index
     auto emit = [&](int at, float x, float y, float z, int code) {
@@ -1398,7 +1419,7 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
                     ok &= (unsigned)(hb >> 32) == epoch;
                 }
                 if (__ballot(!ok) == 0ull) break;
-                if (++spins > FC_SPIN_LIMIT) {
+                if (++spins > spin_limit) {
                     failed = true;
                     break;
                 }
@@ -1512,7 +1533,10 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
         j = s_ctl[0];
         int done = s_ctl[1];
         const int mode = s_ctl[4];
-        if (mode == 3) break;
+        if (mode == 3) {
+            gave_up = true;
+            break;
+        }
         if (mode == 0) {
             const float4 a = s_acc[lane < j ? lane : 0];
             ax = a.x; ay = a.y; az = a.z;
@@ -1550,7 +1574,7 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
                         ok = (unsigned)(tw >> 32) == epoch;
                     }
                     if (__ballot(!ok) == 0ull) break;
-                    if (++spins > FC_SPIN_LIMIT) {
+                    if (++spins > spin_limit) {
                         failed = true;
                         break;
                     }
@@ -1568,7 +1592,10 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
                 }
             }
             __syncthreads();
-            if (s_ctl[4] == 3) break;
+            if (s_ctl[4] == 3) {
+                gave_up = true;
+                break;
+            }
             cur = __builtin_amdgcn_readfirstlane(s_ctl[5]);
             ax = px[cur]; ay = py[cur]; az = pz[cur];
             if (tid == 0 && part == 0) emit(cnt, ax, ay, az, cur);
@@ -1586,7 +1613,8 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
     }
 #endif
     // the samples leave: sorted positions -> original indices (kept out of the loop: the loads would sit on wave 0's critical path)
-    if (part != 0) return;
+    // (after a give-up the log holds `cnt` samples and uninitialised LDS behind them: nothing is translated, nothing written)
+    if (part != 0 || gave_up) return;
     __syncthreads();
     for (int i = tid; i < M; i += NW * 64) {
         if (use_log) {
@@ -1606,6 +1634,13 @@ __global__ __launch_bounds__(NW * 64) void fps_cluster_kernel(const float* __res
 
 static bool fps_cluster_lds_points = getenv("SN2_FC_NO_LDS_POINTS") == nullptr;     // (diagnostic switches)
 static int fps_cluster_tau_keep = getenv("SN2_FC_TAU_KEEP") ? atoi(getenv("SN2_FC_TAU_KEEP")) : SN2_FC_TAU_KEEP;
+static unsigned fps_cluster_spin_limit = getenv("SN2_FC_SPIN_LIMIT") ? (unsigned)strtoul(getenv("SN2_FC_SPIN_LIMIT"), nullptr, 0) : FC_SPIN_LIMIT;
+// tests only: how many sweeps a wait of fps_cluster_kernel makes before it gives up (0 = back to the default); a tiny limit
+// makes every exchange give up, which is how tests/test_gpu_geometry.py exercises the repair launch
+extern "C" int sn2_debug_fps_spin_limit(unsigned sweeps) {
+    fps_cluster_spin_limit = sweeps ? sweeps : FC_SPIN_LIMIT;
+    return 0;
+}
 template <int SPW, int NW, int P>
 static int launch_fps_cluster(const float* pos, int B, int N, int M, const int* start, int* ws, int* idx, float* cs,
                               float* ca, hipStream_t st) {
@@ -1626,13 +1661,15 @@ static int launch_fps_cluster(const float* pos, int B, int N, int M, const int* 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_cluster_kernel<SPW, NW, P, can_lp>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((fps_cluster_kernel<SPW, NW, P, can_lp>), dim3(B * P), dim3(NW * 64), lds, st, pos, B, N, M, start,
-                           (const int*)order, sorted, idx, cs, ca, reinterpret_cast<fc_u64*>(xchg), ctl, log_cap, fps_cluster_tau_keep);
+                           (const int*)order, sorted, idx, cs, ca, reinterpret_cast<fc_u64*>(xchg), ctl, log_cap, fps_cluster_tau_keep,
+                           fps_cluster_spin_limit);
         SN2_RETURN_LAUNCH();
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_cluster_kernel<SPW, NW, P, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
     hipLaunchKernelGGL((fps_cluster_kernel<SPW, NW, P, false>), dim3(B * P), dim3(NW * 64), lds0, st, pos, B, N, M, start,
-                       (const int*)order, sorted, idx, cs, ca, reinterpret_cast<fc_u64*>(xchg), ctl, log_cap, fps_cluster_tau_keep);
+                       (const int*)order, sorted, idx, cs, ca, reinterpret_cast<fc_u64*>(xchg), ctl, log_cap, fps_cluster_tau_keep,
+                       fps_cluster_spin_limit);
     SN2_RETURN_LAUNCH();
 }
 
@@ -1653,8 +1690,25 @@ static int dispatch_fps_cluster(const float* pos, int B, int N, int M, const int
     return SN2_ELIMIT;
 }
 
+// the single-workgroup kernel for a plot of N points, 16 waves (what `waves = 16` runs); repair = behind fps_cluster_kernel
+static int dispatch_fps_bucket16(const float* pos_soa, int B, int N, int M, const int* start, int* order_ws, int* idx,
+                                 float* cpos_soa, float* cpos_aos, hipStream_t st, bool spec, bool repair, unsigned* status) {
+    if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec, repair, status);
+    if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec, repair, status);
+    if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec, repair, status);
+    if (N <= 32768) return launch_fps_bucket<32>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec, repair, status);
+    if (N <= 65536) return launch_fps_bucket<64>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec, repair, status);
+    if (N <= 131072) return launch_fps_bucket<128>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec, repair, status);
+    return SN2_ELIMIT;
+}
+
 extern "C" int sn2_fps_waves(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
                              float* cpos_aos, int* order_ws, int waves, void* stream) {
+    return sn2_fps_status(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, order_ws, waves, nullptr, stream);
+}
+
+extern "C" int sn2_fps_status(const float* pos_soa, int B, int N, int M, const int* start, int* idx, float* cpos_soa,
+                              float* cpos_aos, int* order_ws, int waves, unsigned* status, void* stream) {
     if (!pos_soa || !idx || !cpos_soa || !cpos_aos || B <= 0 || N <= 0 || M <= 0 || M > N) return SN2_EINVAL;
     bool cluster = waves == 34 || waves == 36 || waves == 40 || waves == 66 || waves == 68 || waves == 72;
     if (waves != 0 && waves != 16 && waves != 8 && waves != 1 && !cluster) return SN2_EINVAL;
@@ -1678,12 +1732,17 @@ extern "C" int sn2_fps_waves(const float* pos_soa, int B, int N, int M, const in
             const int P = waves & 15, NWc = (waves & 64) ? 8 : 16;
             const bool fits = (long)B * P <= sn2_cu_count() && sn2_cdiv(N, 64) >= 2 * P * NWc && sn2_cdiv(N, 64) <= 512 * P;
             if (fits) {
-                if (waves == 34) return dispatch_fps_cluster<16, 2>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-                if (waves == 36) return dispatch_fps_cluster<16, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-                if (waves == 40) return dispatch_fps_cluster<16, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-                if (waves == 66) return dispatch_fps_cluster<8, 2>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-                if (waves == 68) return dispatch_fps_cluster<8, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
-                return dispatch_fps_cluster<8, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                int rc;
+                if (waves == 34) rc = dispatch_fps_cluster<16, 2>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                else if (waves == 36) rc = dispatch_fps_cluster<16, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                else if (waves == 40) rc = dispatch_fps_cluster<16, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                else if (waves == 66) rc = dispatch_fps_cluster<8, 2>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                else if (waves == 68) rc = dispatch_fps_cluster<8, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                else rc = dispatch_fps_cluster<8, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+                if (rc != 0) return rc;
+                // the repair launch: B workgroups that read control word 1 and leave -- unless a wait of the pass above gave
+                // up (its workgroups are not guaranteed to be resident together), in which case they sample every plot again
+                return dispatch_fps_bucket16(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, true, true, status);
             }
             waves = 16;
         }
@@ -1697,13 +1756,7 @@ extern "C" int sn2_fps_waves(const float* pos_soa, int B, int N, int M, const in
             if (N <= 16384) return launch_fps_bucket<32, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
             return launch_fps_bucket<64, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
         }
-        if (N <= 4096) return launch_fps_bucket<4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
-        if (N <= 8192) return launch_fps_bucket<8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
-        if (N <= 16384) return launch_fps_bucket<16>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
-        if (N <= 32768) return launch_fps_bucket<32>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
-        if (N <= 65536) return launch_fps_bucket<64>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
-        if (N <= 131072) return launch_fps_bucket<128>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec);
-        return SN2_ELIMIT;
+        return dispatch_fps_bucket16(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st, spec, false, nullptr);
     }
     if (N <= 256) return launch_fps<1, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 512) return launch_fps<2, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);

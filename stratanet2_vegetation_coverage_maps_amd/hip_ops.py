@@ -139,7 +139,8 @@ def fps_ws_words(B: int, N: int) -> int:
 
 
 def fps_ws_ctl(ws: torch.Tensor, B: int, N: int) -> torch.Tensor:
-    """The 32 control words of a filled FPS workspace ([1] = exchange waits of the multi-workgroup kernel that gave up: 0)."""
+    """The 32 control words of a filled FPS workspace ([1] = exchange waits of the multi-workgroup kernel that gave up in the LAST
+    pass over this workspace; the process-wide running total is `fps_gave_up`)."""
     o = 5 * B * N + (4104 + 4096) * B
     return ws[o:o + 32]
 
@@ -154,6 +155,47 @@ def fps_fills_ws(B: int, N: int, m: int) -> bool:
     starts) that ball_query / three_nn may then walk.  Must mirror the condition in csrc/geometry.hip (sn2_fps): handing
     those kernels a workspace nobody filled would send them through garbage cell lists."""
     return N > 2048 and m > 16 and (B * N) % 4 == 0 and N <= 131072
+
+
+_FPS_STATUS = {}          # device index -> [status word (1,) int32 on the device, count already reported]
+
+
+class StrataHipWarning(RuntimeWarning):
+    pass
+
+
+def fps_status_word(dev) -> torch.Tensor:
+    """The device word every `fps` call of this process hands to sn2_fps_status (include/strata_hip.h): it accumulates the
+    waits of the multi-workgroup FPS kernel that gave up (each such pass is repeated by the single-workgroup kernel inside
+    the same call: the samples are right either way)."""
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _FPS_STATUS:
+        _FPS_STATUS[key] = [torch.zeros(1, dtype=I32, device=dev), 0]
+    return _FPS_STATUS[key][0]
+
+
+def fps_gave_up(dev, warn: bool = True) -> int:
+    """Waits of the multi-workgroup FPS that gave up on this device since the process started.  Reads one word from the
+    device: call it where the host synchronises anyway (TrainPipeline.drain, the end of predict_parcel, after a test).
+    A count that grew since the last call means FPS passes are being run twice (the workgroups of the multi-workgroup
+    kernel were not resident together -- another stream or process held the CUs): results are unaffected, the pass takes
+    its bounded wait + the single-workgroup kernel longer; `warn` reports that once per growth as a StrataHipWarning."""
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _FPS_STATUS:
+        return 0
+    word, seen = _FPS_STATUS[key]
+    n = int(word.item())
+    if n > seen:
+        _FPS_STATUS[key][1] = n
+        if warn:
+            import warnings
+            warnings.warn(f"multi-workgroup FPS: {n - seen} exchange wait(s) gave up on {dev} and the passes were repeated by "
+                          "the single-workgroup kernel (results unaffected, the passes took longer); ask for one workgroup "
+                          "per plot (fps(..., waves=8 or 16)) where other kernels or processes share the device",
+                          StrataHipWarning, stacklevel=2)
+    return n
 
 
 def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, bucketed: bool = True,
@@ -188,8 +230,8 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
         cs = torch.empty(B, 3, m, dtype=F32, device=dev)
         ca = torch.empty(B * m, 4, dtype=F32, device=dev)
         order = torch.empty(fps_ws_words(B, N), dtype=I32, device=dev) if use_ws else None
-    _call("sn2_fps_waves", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), int(waves),
-          _stream(), tag=f"N={N}", key="sn2_fps")
+    _call("sn2_fps_status", _ptr(pos_soa), B, N, m, _ptr(start), _ptr(idx), _ptr(cs), _ptr(ca), _ptr(order), int(waves),
+          _ptr(fps_status_word(dev)), _stream(), tag=f"N={N}", key="sn2_fps")
     if return_ws:
         return idx, cs, ca, order
     return idx, cs, ca

@@ -113,4 +113,6 @@ def predict_parcel(model, batches, mosaic: ParcelMosaic, args, prefetch: int = 3
         rasters, _ = project_batch_to_2d_rasters(clouds_dev, cov, args)
         mosaic.add(rasters, cur["plot_center"])
         n += clouds_dev.shape[0]
+    # (no check of hip_ops.fps_gave_up here: it reads a device word, i.e. synchronises; callers that synchronise anyway --
+    # reading the mosaic back -- may ask for it)
     return n

@@ -18,10 +18,17 @@ def shard_of_rank(rank: int, plots_per_rank: int):
     return rank * plots_per_rank, plots_per_rank
 
 
-def allreduce_flat_grad(flat_grad: torch.Tensor, world_size: int, group=None) -> float:
+def allreduce_flat_grad(flat_grad: torch.Tensor, world_size: int, group=None, comm=None, force: bool = False) -> float:
     """The only exchange step of the data-parallel path: one SUM all-reduce of the flat gradient buffer (14 997 fp32 =
-    60 KB, latency-bound on xGMI).  Returns the 1/world scale the optimiser kernel applies afterwards."""
-    if world_size > 1:
+    60 KB, latency-bound on xGMI).  Returns the 1/world scale the optimiser kernel applies afterwards.
+    comm: an `rccl.RcclComm` -- `ncclAllReduce` on torch's CURRENT stream ("on the compute stream"; inside a
+    graph capture it becomes a node of the step's hipGraph), run at ANY world size including 1; None: torch's process group
+    (its own stream and event hand-offs; skipped at world 1 unless `force`: a one-rank process group then runs the call, which
+    is how bench.py times this path on a one-GPU box)."""
+    if comm is not None:
+        comm.all_reduce_sum_(flat_grad)
+        return 1.0 / comm.world
+    if world_size > 1 or force:
         torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=group)
     return 1.0 / world_size
 
@@ -67,7 +74,7 @@ def flatten_parameters(model) -> torch.Tensor:
 
 class FlatAdam:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None,
-                 world_size=1):
+                 world_size=1, comm=None):
         self.model = model
         self.flat = getattr(model, "_flat_params", None)
         if self.flat is None:
@@ -80,6 +87,10 @@ class FlatAdam:
         self.step_dev = self.step_words[:1]
         self.world_size = world_size
         self.process_group = process_group
+        self.comm = comm                      # rccl.RcclComm: the exchange as ncclAllReduce on the step's own stream (graph-capturable)
+        self.force_exchange = False           # torch's all_reduce even at world 1 (needs an initialised one-rank process group)
+        if comm is not None and comm.world != world_size:
+            raise ValueError("FlatAdam: the RCCL communicator and world_size disagree")
 
     def reset(self):
         """Forget the optimiser state: moments, step count AND the Adam kernel's arrival ticket (`step_words[1]`: the last
@@ -107,6 +118,6 @@ class FlatAdam:
         g = self.model._last_flat_grad
         if g is None:
             raise RuntimeError("FlatAdam.step: no gradient (run backward through PointNet2 first)")
-        scale = allreduce_flat_grad(g, self.world_size, self.process_group)   # RCCL over xGMI when world > 1
+        scale = allreduce_flat_grad(g, self.world_size, self.process_group, self.comm, self.force_exchange)   # RCCL over xGMI when world > 1
         ops.adam_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
                       self.weight_decay, self.step_words, scale)

@@ -32,7 +32,7 @@ from .optim import allreduce_flat_grad
 
 class TrainPipeline:
     def __init__(self, model, opt, feature_step, slot_inputs, depth=2, use_graph=True, n_streams=None,
-                 split_exchange=None, pair=None, group=None):
+                 split_exchange=None, pair=None, group=None, phase=0):
         """model: PointNet2 (train mode); opt: FlatAdam; slot_inputs: list of depth+1 dicts with device tensors "cloud"
         (B,10,N), "xyz" (B,3,N), "fps_start" (2,B) int32 + whatever `feature_step` needs;
         feature_step(inputs, geometry) -> loss: zero_grad, forward (with cloud_data["geometry"] = geometry),
@@ -78,6 +78,14 @@ class TrainPipeline:
         self.B = B
         # batches the geometry may run ahead of the feature passes (never into a slot whose feature pass is not launched yet)
         self.ahead = min(G * depth, self.slots - G) if self.pair else depth
+        # phase (0 <= phase < G, grouped passes only): the passes are issued at the end of the steps that complete batch numbers
+        # = phase (mod G) -- phase 0 issues a pass as late as the slots allow, phase s > 0 issues it G - s steps earlier (the
+        # tables then wait longer in their slots: depth - 1 whole passes + s batches ahead instead of depth passes).  A timed
+        # region that must END with all streams drained wants its last pass issued early in a group, not at its last step
+        # (bench.py picks the phase from its step counts; steady-state throughput does not depend on it).
+        self.phase = int(phase) % G if self.pair else 0
+        if self.phase:
+            self.ahead -= self.phase
         self.n_streams = n_streams or depth
         self.side = [ops.shared_stream(dev, f"side{j}") for j in range(self.n_streams)]     # one set per process: hip_ops.shared_stream
         self.geo_ready = [torch.cuda.Event() for _ in range(self.slots)]
@@ -94,7 +102,10 @@ class TrainPipeline:
         self.feeder = None                        # optional: feeder(i) -> dict of HOST tensors for batch number i
         # exchange between the backward graph and the Adam graph (always when world > 1; can be forced on one GPU to
         # exercise exactly the launch sequence the multi-GPU run uses)
-        self.split_exchange = (getattr(opt, "world_size", 1) > 1) if split_exchange is None else bool(split_exchange)
+        # With an RCCL communicator on the optimiser (opt.comm: ncclAllReduce on the step's own stream) the exchange is a node
+        # of the slot's graph like any kernel: ONE graph per step at any world size, nothing split.
+        in_graph = getattr(opt, "comm", None) is not None
+        self.split_exchange = ((getattr(opt, "world_size", 1) > 1) and not in_graph) if split_exchange is None else bool(split_exchange)
 
     def _wait_slots(self, st, ks):
         """Before a geometry pass overwrites the tables of slots `ks`, the feature passes that last read them must have
@@ -218,7 +229,8 @@ class TrainPipeline:
         if self.graph_fb[k] is not None:
             self.graph_fb[k].replay()
             if self.graph_opt[k] is not None:
-                allreduce_flat_grad(self.flat_grad[k], self.opt.world_size, self.opt.process_group)
+                allreduce_flat_grad(self.flat_grad[k], self.opt.world_size, self.opt.process_group, getattr(self.opt, "comm", None),
+                                    getattr(self.opt, "force_exchange", False))
                 self.graph_opt[k].replay()
             loss = self.loss[k]
         else:
@@ -239,6 +251,10 @@ class TrainPipeline:
         geometry pass.  None = the slots already hold the data (the resident-input mode of bench.py)."""
         self.feeder = feeder
 
-    def drain(self):
+    def drain(self, check: bool = False):
+        """Make the main stream wait for every geometry pass in flight.  check=True (where the caller synchronises with the
+        device anyway): also read the FPS status word and warn when passes had to be repeated (hip_ops.fps_gave_up)."""
         for st in self.side:
             torch.cuda.current_stream(self.dev).wait_stream(st)
+        if check:
+            ops.fps_gave_up(self.dev)

@@ -108,6 +108,51 @@ def test_bucketed_fps_on_dense_plots(B, N, M):
     assert torch.equal(a_i, b_i) and torch.equal(a_w, b_w)
 
 
+def test_multi_workgroup_fps_gives_up_safely_and_is_repaired():
+    """The workgroups of the multi-workgroup FPS wait for their peers, and nothing guarantees that they are resident together.
+    Provoked here with a wait limit of ONE sweep (sn2_debug_fps_spin_limit): every exchange gives up almost at once.  The
+    call must return (no hang), count the give-ups (control word 1 of the workspace, and the process-wide status word that
+    `ops.fps_gave_up` reads and warns about), write nothing out of range, and still deliver the reference's samples: the
+    repair launch behind every multi-workgroup pass (the single-workgroup kernel) samples the plots again."""
+    import warnings
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    B, N, M = 4, 32768, 512
+    xyz, _ = _pos(B, N, first=3)
+    start = torch.tensor([(977 * b + 13) % N for b in range(B)])
+    dev = xyz.to(DEV)
+    ref = P.fps_batched(xyz.permute(0, 2, 1).contiguous(), M, start)
+    before = ops.fps_gave_up(DEV, warn=False)
+    lib = _lib.load()
+    try:
+        assert lib.sn2_debug_fps_spin_limit(1) == 0
+        for w in (72, 36, 0):
+            out = (torch.full((B, M), -7, dtype=torch.int32, device=DEV), torch.full((B, 3, M), float("nan"), device=DEV),
+                   torch.full((B * M, 4), float("nan"), device=DEV), torch.empty(ops.fps_ws_words(B, N), dtype=torch.int32, device=DEV))
+            idx, cs, ca, ws = ops.fps(dev, M, start.to(DEV, torch.int32), out=out, waves=w, return_ws=True)
+            torch.cuda.synchronize()
+            assert int(ops.fps_ws_ctl(ws, B, N)[1]) > 0, f"waves={w}: the one-sweep limit did not make a wait give up"
+            assert torch.equal(idx.cpu().long(), ref), f"waves={w}: the repair launch did not restore the samples"
+            g = torch.gather(xyz, 2, ref.unsqueeze(1).expand(-1, 3, -1))
+            assert torch.equal(cs.cpu(), g) and torch.equal(ca.cpu().view(B, M, 4)[..., :3], g.permute(0, 2, 1))
+            # the tables the ball query walks are intact as well
+            nbr_g, cnt_g, _ = ops.ball_query(dev, cs, 1.0, 64, fps_ws=ws)
+            nbr_f, cnt_f, _ = ops.ball_query(dev, cs, 1.0, 64)
+            live = torch.arange(64, device=DEV)[None, :] < cnt_f[:, None]
+            assert torch.equal(cnt_g, cnt_f) and torch.equal(nbr_g[live], nbr_f[live])
+    finally:
+        lib.sn2_debug_fps_spin_limit(0)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        after = ops.fps_gave_up(DEV)
+    assert after > before and any(issubclass(r.category, ops.StrataHipWarning) for r in rec)
+    with warnings.catch_warnings(record=True) as rec:              # reported once per growth
+        warnings.simplefilter("always")
+        assert ops.fps_gave_up(DEV) == after and not rec
+    # and with the default limit nothing gives up
+    idx, _, _, ws = ops.fps(dev, M, start.to(DEV, torch.int32), waves=72, return_ws=True)
+    assert torch.equal(idx.cpu().long(), ref) and int(ops.fps_ws_ctl(ws, B, N)[1]) == 0 and ops.fps_gave_up(DEV) == after
+
+
 def test_fps_with_duplicate_points_and_default_start():
     """sample_cloud pads small plots by sampling with replacement (loader.py:238-244) => exact ties."""
     xyz, _ = _pos(1, 500)
@@ -303,7 +348,8 @@ def test_sa_work_items_order(B, M):
     assert torch.equal(got[:offt + 2], want[:offt + 2])
 
 
-@pytest.mark.parametrize("B,R,S,with_pos", [(2, 5000, 37, True), (3, 2049, 100, False), (1, 70000, 1024, True), (2, 300, 1, False)])
+@pytest.mark.parametrize("B,R,S,with_pos", [(2, 5000, 37, True), (3, 2049, 100, False), (1, 70000, 1024, True), (2, 300, 1, False),
+                                             (1, 32768, 8192, True)])       # S = 8192: the limit (64 KB of dynamic LDS)
 def test_inverted_index_and_its_chunk_table(B, R, S, with_pos):
     """sn2_interp_index: every (row, slot) of the 3-NN table is on its source's list exactly once with the normalised weight,
     the item table is a permutation of the plot's sources, and the chunk table cuts every list into consecutive pieces of at

@@ -348,6 +348,73 @@ def test_per_point_layer_source_side_form(N):
         assert err <= 1e-3, f"{k}: {err:.2e}"
 
 
+def test_source_side_form_with_many_tiny_plots():
+    """72 plots of 1024 points with 8 level-1 centroids each: more than 65 536 rows, so the per-point layer takes its
+    source-side form, but a plot's chunk table has only 57 slots (< 64 = the slots one wave of fp_bwd_src_chunk_kernel owns):
+    a wave's range starts in one plot's padding, covers the next plot's chunks and ends in that plot's padding.  (The
+    kernel's "padding only" early return once looked at the first and the last slot only and skipped such waves, and the
+    merge then summed partial rows nobody had written.)  The allocator is poisoned with NaN first, so unwritten scratch
+    shows.  Checked against the row-per-lane form and against the fp64 oracle."""
+    B, N = 72, 1024
+    args = make_args(subsample_size=N, ratio1=8 / N, r1=6.0, ratio2=0.5, r2=12.0)
+    assert ops.interp_chunks(N, 8) < 64 and B * N > 65536
+    d = make_batch(B, N, first_plot=400)
+    sd = network.init_state_dict(6)
+    fs = torch.stack([torch.arange(B) * 11 % N, torch.arange(B) % 8])
+    d["fps_start"] = fs
+    from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
+
+    def run(source_side):
+        ops.SOURCE_SIDE = source_side
+        try:
+            junk = [torch.full((n,), float("nan"), device="cuda") for n in (1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24) for _ in range(4)]
+            del junk                                   # the caching allocator hands these blocks to the next torch.empty calls
+            m = _model(args, sd).train()
+            cov, proba = m(d)
+            assert (cov.grad_fn.saved.h1.shape[0] == B * N)
+            pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+            loss, _ = dev_losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.SOURCE_SIDE = True
+        return cov.detach().cpu().numpy(), loss.item(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+
+    cov, loss, grads = run(True)
+    cov0, loss0, grads0 = run(False)
+    assert np.isfinite(cov).all() and all(np.isfinite(g).all() for g in grads.values())
+    np.testing.assert_allclose(cov, cov0, atol=2e-5, rtol=0)
+    for k in grads:
+        np.testing.assert_allclose(grads[k], grads0[k], atol=1e-7 + 2e-4 * np.abs(grads0[k]).max(), rtol=0, err_msg=k)
+    ref = check.train_step(sd, d, args, fps_start=fs)
+    assert np.abs(cov - ref["cov"].numpy()).max() <= TOL and abs(loss - ref["loss"]) <= TOL
+    worst = max(np.abs(grads[k] - ref["grads"][k].numpy()).max() / np.abs(ref["grads"][k].numpy()).max() for k in grads)
+    print(f"\n[72 x 1024, 8 sources per plot] worst gradient error vs the fp64 oracle {worst:.2e} (tol 2e-3)")
+    assert worst <= 2e-3
+
+
+def test_last_G_tensor_holds_the_plot_embeddings():
+    """`args.log_embeddings` (model/point_net2.py:134-135; read by learning/test.py:105-107): after a forward
+    `model.last_G_tensor` is the (B,64) output of the global set-abstraction level -- against the oracle's x3."""
+    B, N = 3, 4096
+    args = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0, log_embeddings=True)
+    d = make_batch(B, N, first_plot=60)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.long)
+    sd = network.init_state_dict(2)
+    m = _model(args, sd).eval()
+    assert m.last_G_tensor is None
+    with torch.no_grad():
+        m(d)
+        _, _, ex = network.forward(sd, d["cloud"], d["xyz"], args, training=False, details=True)
+    assert tuple(m.last_G_tensor.shape) == (B, 64)
+    np.testing.assert_allclose(m.last_G_tensor.cpu().numpy(), ex["x3"].numpy(), atol=TOL, rtol=0)
+    args2 = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0, log_embeddings=False)
+    m2 = _model(args2, sd).eval()
+    with torch.no_grad():
+        m2(d)
+    assert m2.last_G_tensor is None                       # only kept when asked for, as in the reference
+
+
 @pytest.mark.parametrize("B,N", [(2, 4096), (3, 24001)])
 def test_training_forward_is_bit_reproducible(B, N):
     """The training-mode forward pass (batch statistics included) gives the same bits on every run, for the small-layer

@@ -105,6 +105,43 @@ def test_pipeline_matches_plain_loop(use_graph, split, pair):
     np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(), ref_rm.cpu().numpy(), atol=2e-3)   # the same drift (seen: 5.3e-4); one update more or less: 1e-2
 
 
+def test_pipeline_in_the_headline_mode_matches_plain_loop():
+    """The mode bench.py's `value` is measured in: EIGHT consecutive batches per geometry pass, depth 3 => 32 slots, one
+    hipGraph per slot, Adam in the same graph -- on tiny plots, for more steps than there are slots (every slot is reused: its
+    tables are overwritten by a later pass while earlier feature passes are still queued).  Learning rate 0 (the optimiser
+    kernel still runs and counts): every loss is a function of that step's batch and tables only, so the pipelined loop must
+    reproduce the plain loop to 1e-6 at EVERY step; a stale, late or misplaced table shows as 1e-2 and more."""
+    N, B, depth, G = 4096, 2, 3, 8
+    n_slots = G * depth + G
+    steps = n_slots + 2 * G + 3
+    model, opt, slots, fstep = _setup(N, B, depth, n_slots, lr=0.0)
+    ref = []
+    for i in range(steps):
+        l = fstep(slots[i % n_slots])
+        opt.step()
+        ref.append(float(l.detach()))
+    assert np.ptp(ref[:n_slots]) > 1e-3               # the slots hold different batches: their losses tell them apart
+    model2, opt2, slots2, fstep2 = _setup(N, B, depth, n_slots, lr=0.0)
+    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=True, group=G)
+    assert pipe.group == G and pipe.slots == 32 and pipe.ahead == G * depth
+    pipe.capture()
+    model2.load_state_dict(network.init_state_dict(5))
+    opt2.reset()
+    pipe.prime()
+    out = torch.zeros(steps, dtype=torch.float64, device="cuda")
+    for i in range(steps):                              # no host synchronisation inside the loop
+        out[i] = pipe.step().detach()
+    pipe.drain(check=True)
+    torch.cuda.synchronize()
+    got = out.cpu().tolist()
+    print(f"\n[pipeline G = 8, 32 slots, {steps} steps] max |d loss| {np.abs(np.array(got) - np.array(ref)).max():.2e}")
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    assert int(opt2.step_dev.item()) == steps
+    # BatchNorm running statistics went through the same `steps` updates in both loops (bit-reproducible forward)
+    np.testing.assert_allclose(model2.fp1_module.nn[0][2].running_mean.cpu().numpy(),
+                               model.fp1_module.nn[0][2].running_mean.cpu().numpy(), rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("pair", [False, True])
 def test_pipeline_with_host_feeder_matches_plain_loop(pair):
     """Batches fed from pinned host memory on the side streams (the way a DataLoader user of
