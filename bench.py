@@ -377,6 +377,7 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
     else:
         model = PointNet2(args).train()
     n_fps = 3 if arch == "3sa" else 2
+    model.p2_diam_pix = args.diam_pix        # geometry passes also compute the projection's pixel ids (functions of x, y only)
     flatten_parameters(model)
     comm, force, exchange_desc = make_exchange(exchange, dev, world)
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world, comm=comm)     # config.py:84,97
@@ -396,7 +397,7 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
         if geo is not None:
             cd["geometry"] = geo
         cov, proba = model(cd)
-        pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
+        pred = project_to_plotwise_coverages(cov, inp["cloud"], args, geometry=geo)
         loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
         loss.backward()
         return loss
@@ -460,7 +461,7 @@ def exchange_leg(dev, steps=100, warmup=10):
     (b) torch.distributed.all_reduce over a one-rank nccl process group between the backward graph and the Adam graph (the
     fallback's launch sequence), (c) no exchange.  Same loop, same kernels; only the exchange differs."""
     out = {}
-    for kind in ("rccl", "torch", "none"):
+    for kind in ("none", "rccl", "torch"):
         r = secondary_train_leg(dev, "ref", PLOTS_PER_GPU, 32768, "f32", steps, warmup, exchange=kind)
         out[kind] = {"ms_per_step": r["ms_per_step"], "plots_per_s": r["plots_per_s"], "exchange": r["exchange"], "loss": r["loss"]}
     if _ONE_RANK_GROUP[0]:
@@ -654,6 +655,10 @@ def main():
     backend = os.environ.get("SN2_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # HIP deals streams onto its few hardware queues in the order they are created: the loop's own side streams come FIRST, before
+    # RCCL / the process group create theirs (a pipeline whose side streams were created after a communicator shared queues
+    # with them and ran 15 % slower per step: 0.905 instead of 0.787 ms)
+    ops.create_shared_streams(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":

@@ -303,6 +303,15 @@ int sn2_fp_bn_sums(const sn2_fp *p, const float *gamma, const float *beta, const
 int sn2_plot_project_forward(const float *pred_pointwise, const float *cloud_xy, long plot_stride, int B, int N,
                              int D, unsigned long long *keys, int *pix, int *arg, int *nocc, float *pred,
                              void *stream);
+/* The same in two parts, for callers that run their position-only kernels ahead of the feature kernels (the pixel id of a
+ * point is a function of the plot's x, y only, project_to_2d.py:16-22): sn2_plot_pixels computes mm (B,4) = the plots'
+ * (xmin, xmax, ymin, ymax) and pix (B*N) = the ids sn2_plot_project_forward would write; sn2_plot_project_forward_pix is the
+ * rest of it from those ids -- keys: u64 workspace of SN2_P2_KEY_PARTS(N)*B*D*D*3 words (no initialisation: every slice of a
+ * plot writes its own table, the finalisation takes their maximum), same arg / nocc / pred. */
+#define SN2_P2_KEY_PARTS(N) (((N) + 4095) / 4096 < 1 ? 1 : (((N) + 4095) / 4096 > 64 ? 64 : ((N) + 4095) / 4096))
+int sn2_plot_pixels(const float *cloud_xy, long plot_stride, int B, int N, int D, float *mm, int *pix, void *stream);
+int sn2_plot_project_forward_pix(const float *pred_pointwise, const int *pix, int B, int N, int D,
+                                 unsigned long long *keys, int *arg, int *nocc, float *pred, void *stream);
 /* d pred (B,4) -> d pred_pointwise (B*N,4): every row written (a point gets its pixel's gradient iff it is the pixel's
  * arg-max; pix, arg, nocc from the forward). */
 int sn2_plot_project_backward(const float *dpred, const int *arg, const int *nocc, const int *pix, int B, int N,

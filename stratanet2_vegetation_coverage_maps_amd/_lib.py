@@ -83,6 +83,8 @@ SIGNATURES = {
     "sn2_head_backward": [POINTER(Head), c_void_p],
     "sn2_plot_project_forward": [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p],
+    "sn2_plot_pixels": [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sn2_plot_project_forward_pix": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_plot_project_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_raster_project": [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                            c_void_p],

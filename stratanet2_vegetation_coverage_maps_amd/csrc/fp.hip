@@ -1603,6 +1603,10 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     FSTAMP(8);
 }
 
+// (experiment switch) SN2_GRID_MULT: the row kernels' grids times this factor (more, shorter workgroups than the chip holds at
+// once: the hardware then hands the later ones to whichever CU frees up first -- dynamic balancing beside concurrent kernels)
+static const int grid_mult = getenv("SN2_GRID_MULT") ? atoi(getenv("SN2_GRID_MULT")) : 1;
+
 int pick_grid(long R, int threads, int rows_per_lane) {
     long g = (R + (long)threads * rows_per_lane - 1) / ((long)threads * rows_per_lane);
     if (g < 1) g = 1;
@@ -1650,7 +1654,7 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
             int grid = sn2_cdiv(n_grp, 8);
             // two workgroups per CU: at 143 VGPRs three waves fit a SIMD, so 1024 workgroups ran as one full round and a
             // third of a second one (0.057 ms; 768: 0.056; 512: 0.052; 384: 0.058)
-            const int cap_fwd_rows = 2 * sn2_cu_count() < SN2_STAT_SLOTS ? 2 * sn2_cu_count() : SN2_STAT_SLOTS;
+            const int cap_fwd_rows = 2 * grid_mult * sn2_cu_count() < SN2_STAT_SLOTS ? 2 * grid_mult * sn2_cu_count() : SN2_STAT_SLOTS;
             if (grid > cap_fwd_rows) grid = cap_fwd_rows;
             auto kr = p->act_bf16 ? &fp_fwd_rows_kernel<CA, CB, CO, true> : &fp_fwd_rows_kernel<CA, CB, CO, false>;
             hipLaunchKernelGGL(kr, dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
@@ -1768,7 +1772,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             auto k1 = p->act_bf16 ? &fp_bwd_rows_kernel<CA, CB, CO, NT, true> : &fp_bwd_rows_kernel<CA, CB, CO, NT, false>;
             if (lb1 > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb1);
-            hipLaunchKernelGGL(k1, dim3(2 * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
+            hipLaunchKernelGGL(k1, dim3(2 * grid_mult * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
                                p->blk.gamma, (const float*)p->blk.mean, (const float*)p->blk.invstd,
                                (const float*)p->blk.dgamma, (const float*)p->blk.dbeta, (const float*)p->h, p->dy,
                                p->du_scratch, p->blk.dW, p->blk.db, p->blk.grad_replicas, p->blk.grad_replica_stride,
@@ -2286,7 +2290,7 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     if (!p->coverages || !p->proba) return SN2_EINVAL;
     // check_head: rows of exactly 36 floats (34 channels)
     auto kf = p->act_bf16 ? &head_fwd_mfma_kernel<true> : &head_fwd_mfma_kernel<false>;
-    hipLaunchKernelGGL(kf, dim3(pick_grid(p->R, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
+    hipLaunchKernelGGL(kf, dim3(pick_grid(p->R * grid_mult, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
                        p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba, p->drop_mask,
                        p->drop_mask ? p->drop_scale : 1.f);
     SN2_RETURN_LAUNCH();
@@ -2324,7 +2328,7 @@ extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     auto kb = p->act_bf16 ? &head_bwd_kernel<true> : &head_bwd_kernel<false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     int grid = pick_grid(p->R, HEAD_BWD_THREADS, 1);
-    if (grid > 1024) grid = 1024;
+    if (grid > 1024 * grid_mult) grid = 1024 * grid_mult;
     hipLaunchKernelGGL(kb, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
                        p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
                        p->db2, p->grad_replicas, p->grad_replica_stride, p->drop_mask, p->drop_mask ? p->drop_scale : 1.f);

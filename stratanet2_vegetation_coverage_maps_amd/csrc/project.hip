@@ -133,8 +133,48 @@ __global__ __launch_bounds__(1024) void scatter_max_kernel(const float* __restri
     }
 }
 
+// The pixel id of every point depends on the plot's x, y only (project_to_2d.py:16-22): a training loop that runs its
+// position-only kernels ahead of the feature pass computes them there (sn2_plot_pixels) and the feature pass keeps two
+// launches: this scatter from the stored ids and the finalisation.  No key table to clear and no global atomics: the
+// `gridDim.x` slices of a plot each write their own table, the finalisation takes the maximum over the slices (same keys,
+// same winner: the maximum of maxima).
+__global__ __launch_bounds__(1024) void plot_pixels_kernel(const float* __restrict__ xy, long plot_stride, int N, int D,
+                                                           const float* __restrict__ mm, int* __restrict__ pix) {
+    const int b = blockIdx.y;
+    const float* x = xy + (size_t)b * plot_stride;
+    const float* y = x + N;
+    const float xmn = mm[b * 4 + 0], xmx = mm[b * 4 + 1], ymn = mm[b * 4 + 2], ymx = mm[b * 4 + 3];
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(N, lo + per);
+    for (int n = lo + threadIdx.x; n < hi; n += 1024) pix[(size_t)b * N + n] = p2_pix(x[n], xmn, xmx, D) * D + p2_pix(y[n], ymn, ymx, D);
+}
+
+__global__ __launch_bounds__(1024) void scatter_max_pix_kernel(const float* __restrict__ vals, const int* __restrict__ pix, int N,
+                                                               int D, unsigned long long* __restrict__ keys_part) {
+    extern __shared__ unsigned long long s_keys[];  // D*D*3
+    const int b = blockIdx.y;
+    const int ncell3 = D * D * 3;
+    for (int i = threadIdx.x; i < ncell3; i += 1024) s_keys[i] = 0ull;
+    __syncthreads();
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(N, lo + per);
+    for (int n = lo + threadIdx.x; n < hi; n += 1024) {
+        const int cell = pix[(size_t)b * N + n];
+        const float4 v = reinterpret_cast<const float4*>(vals)[(size_t)b * N + n];
+        const unsigned long long tag = (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+        atomicMax(&s_keys[cell * 3 + 0], ((unsigned long long)f2ord(v.x) << 32) | tag);
+        atomicMax(&s_keys[cell * 3 + 1], ((unsigned long long)f2ord(v.z) << 32) | tag);
+        atomicMax(&s_keys[cell * 3 + 2], ((unsigned long long)f2ord(v.w) << 32) | tag);
+    }
+    __syncthreads();
+    unsigned long long* g = keys_part + ((size_t)b * gridDim.x + blockIdx.x) * ncell3;
+    for (int i = threadIdx.x; i < ncell3; i += 1024) g[i] = s_keys[i];
+}
+
 // P2: pred[b] = mean over occupied pixels of [low, 1-low, med, high]   (project_to_2d.py:41-53)
-__global__ __launch_bounds__(256) void p2_finalize_kernel(const unsigned long long* __restrict__ keys, int D,
+// parts: key tables per plot (1 = the table the global atomics of scatter_max_kernel<0> filled; more: the slices of
+// scatter_max_pix_kernel, of which the maximum is taken here)
+__global__ __launch_bounds__(256) void p2_finalize_kernel(const unsigned long long* __restrict__ keys, int D, int parts,
                                                           int* __restrict__ arg, int* __restrict__ nocc,
                                                           float* __restrict__ pred) {
     __shared__ float s[5][4];
@@ -143,7 +183,15 @@ __global__ __launch_bounds__(256) void p2_finalize_kernel(const unsigned long lo
     float lo = 0.f, so = 0.f, me = 0.f, hi = 0.f, cnt = 0.f;
     for (int c = threadIdx.x; c < ncell; c += 256) {
         const size_t base = ((size_t)b * ncell + c) * 3;
-        const unsigned long long k0 = keys[base], k1 = keys[base + 1], k2 = keys[base + 2];
+        const unsigned long long* kp = keys + ((size_t)b * parts * ncell + c) * 3;
+        unsigned long long k0 = kp[0], k1 = kp[1], k2 = kp[2];
+        for (int q = 1; q < parts; ++q) {
+            const unsigned long long* kq = kp + (size_t)q * ncell * 3;
+            const unsigned long long a0 = kq[0], a1 = kq[1], a2 = kq[2];
+            k0 = a0 > k0 ? a0 : k0;
+            k1 = a1 > k1 ? a1 : k1;
+            k2 = a2 > k2 ? a2 : k2;
+        }
         if (k0) {
             const float l = ord2f((uint32_t)(k0 >> 32));
             lo += l;
@@ -235,7 +283,30 @@ extern "C" int sn2_plot_project_forward(const float* pred_pointwise, const float
     hipLaunchKernelGGL(plot_minmax_kernel, dim3(B), dim3(1024), 0, st, cloud_xy, plot_stride, N, mm, keys, D * D * 3);
     hipLaunchKernelGGL((scatter_max_kernel<0>), dim3(grid_slices(N), B), dim3(1024), (size_t)D * D * 3 * 8, st,
                        pred_pointwise, cloud_xy, plot_stride, N, D, (const float*)mm, 0.f, 0.f, keys, pix);
-    hipLaunchKernelGGL(p2_finalize_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long*)keys, D, arg, nocc, pred);
+    hipLaunchKernelGGL(p2_finalize_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long*)keys, D, 1, arg, nocc, pred);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_plot_pixels(const float* cloud_xy, long plot_stride, int B, int N, int D, float* mm, int* pix, void* stream) {
+    if (!cloud_xy || !mm || !pix || B <= 0 || N <= 0 || D <= 0) return SN2_EINVAL;
+    if (D * D > MAX_CELLS || plot_stride < 2L * N) return SN2_ELIMIT;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(plot_minmax_kernel, dim3(B), dim3(1024), 0, st, cloud_xy, plot_stride, N, mm,
+                       (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL(plot_pixels_kernel, dim3(grid_slices(N), B), dim3(1024), 0, st, cloud_xy, plot_stride, N, D,
+                       (const float*)mm, pix);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_plot_project_forward_pix(const float* pred_pointwise, const int* pix, int B, int N, int D,
+                                            unsigned long long* keys, int* arg, int* nocc, float* pred, void* stream) {
+    if (!pred_pointwise || !pix || !keys || !arg || !nocc || !pred || B <= 0 || N <= 0 || D <= 0) return SN2_EINVAL;
+    if (D * D > MAX_CELLS) return SN2_ELIMIT;
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = grid_slices(N);
+    hipLaunchKernelGGL(scatter_max_pix_kernel, dim3(parts, B), dim3(1024), (size_t)D * D * 3 * 8, st, pred_pointwise, pix, N, D,
+                       keys);
+    hipLaunchKernelGGL(p2_finalize_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long*)keys, D, parts, arg, nocc, pred);
     SN2_RETURN_LAUNCH();
 }
 

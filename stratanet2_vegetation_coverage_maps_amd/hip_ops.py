@@ -84,6 +84,71 @@ def shared_stream(dev, name: str) -> torch.cuda.Stream:
     return _SHARED_STREAMS[key]
 
 
+class PinnedRing:
+    """Host-to-device uploads of pageable tensors through a small ring of PINNED staging buffers.
+
+    The reference hands `PointNet2.forward` CPU tensors from a DataLoader without `pin_memory` (`learning/train.py:33-44`,
+    `model/point_net2.py:119-124` moves them with `.cuda()`): a copy from pageable memory is staged by the runtime chunk by chunk
+    and blocks the host for its whole length (40 MB per step at C2: 5 of the eager loop's 5.8 ms).  Here the host copies into a
+    pinned buffer itself (a multi-threaded memcpy) and the DMA runs asynchronously on the stream it is given, so the kernels
+    that need only the first tensor (the geometry pass needs `xyz` only) start while the rest is still on its way.
+    A slot is reused only after the DMA that read it has finished (an event per slot, waited for on the host)."""
+
+    def __init__(self, dev, slots: int = 3):
+        self.dev = torch.device(dev)
+        self.bufs = [None] * slots
+        self.events = [None] * slots
+        self.k = 0
+
+    def upload(self, t: torch.Tensor, stream=None, dtype=None) -> torch.Tensor:
+        """CPU tensor -> new device tensor of `dtype` (default: its own) with the same shape, copied asynchronously on
+        `stream` (default: torch's current stream).  The result is safe to use on that stream (record_stream / events for
+        others are the caller's business)."""
+        dtype = dtype or t.dtype
+        src = t.detach()
+        if src.dtype != dtype:
+            src = src.to(dtype)
+        src = src.contiguous()
+        n = src.numel() * src.element_size()
+        i = self.k
+        self.k = (self.k + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()                      # the DMA that last read this slot
+        if self.bufs[i] is None or self.bufs[i].numel() < n:
+            self.bufs[i] = torch.empty(max(n, 1 << 20), dtype=torch.uint8).pin_memory()
+        stage = self.bufs[i][:n].view(dtype).view(src.shape)
+        stage.copy_(src)                                      # host memcpy into pinned memory
+        st = torch.cuda.current_stream(self.dev) if stream is None else stream
+        with torch.cuda.stream(st):
+            out = torch.empty(src.shape, dtype=dtype, device=self.dev)
+            out.copy_(stage, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self.events[i] = ev
+        return out
+
+
+_RINGS = {}
+
+
+def pinned_ring(dev) -> PinnedRing:
+    """The process-wide upload ring of a device."""
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _RINGS:
+        _RINGS[key] = PinnedRing(dev)
+    return _RINGS[key]
+
+
+def create_shared_streams(dev, lanes: int = 4):
+    """Create the process's side streams NOW ("side0".."side<lanes-1>", the fork / pack / capture streams), in a fixed order.
+    Call it before anything else creates streams on the device (RCCL communicators, torch.distributed process groups): the
+    hardware queues go to the first streams created, and a loop whose side streams come late shares queues with the
+    communicator's streams (measured: 0.905 instead of 0.787 ms per step)."""
+    for name in [f"side{j}" for j in range(lanes)] + ["fork_b", "fork_c", "pack", "capture", "upload"]:
+        shared_stream(dev, name)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -757,6 +822,43 @@ def plot_project_forward(pred_pointwise: torch.Tensor, clouds_dev: torch.Tensor,
     pred = torch.empty(B, 4, dtype=F32, device=dev)
     _call("sn2_plot_project_forward", _ptr(pred_pointwise), _ptr(t), stride, B, N, D, _ptr(keys), _ptr(pix),
                                                _ptr(arg), _ptr(nocc), _ptr(pred), _stream())
+    return pred, pix, arg, nocc
+
+
+def p2_key_parts(N: int) -> int:
+    """SN2_P2_KEY_PARTS of include/strata_hip.h."""
+    return max(1, min(64, (N + 4095) // 4096))
+
+
+def plot_pixels(clouds_dev: torch.Tensor, diam_pix: int, out=None):
+    """clouds (B,C,N) on the device -> (mm (B,4) bounding boxes, pix (B*N) int32): the pixel ids of
+    `project_to_plotwise_coverages` (project_to_2d.py:16-22), computed from the positions alone -- what a pipelined loop runs
+    ahead of the feature pass (include/strata_hip.h: sn2_plot_pixels).  out = (mm, pix): caller-owned buffers."""
+    B, C, N = clouds_dev.shape
+    t, stride = _xy_rows(clouds_dev)
+    if out is None:
+        mm = torch.empty(B, 4, dtype=F32, device=clouds_dev.device)
+        pix = torch.empty(B * N, dtype=I32, device=clouds_dev.device)
+    else:
+        mm, pix = out
+        _chk(mm, F32, (B, 4), "out mm")
+        _chk(pix, I32, (B * N,), "out pix")
+    _call("sn2_plot_pixels", _ptr(t), stride, B, N, int(diam_pix), _ptr(mm), _ptr(pix), _stream())
+    return mm, pix
+
+
+def plot_project_forward_pix(pred_pointwise: torch.Tensor, pix: torch.Tensor, B: int, N: int, diam_pix: int):
+    """`plot_project_forward` from pixel ids that `plot_pixels` computed ahead of time: two launches, no key table to clear."""
+    _chk(pred_pointwise, F32, (B * N, 4), "pred_pointwise")
+    _chk(pix, I32, (B * N,), "pix")
+    dev = pred_pointwise.device
+    D = int(diam_pix)
+    keys = torch.empty(p2_key_parts(N) * B * D * D * 3, dtype=I64, device=dev)
+    arg = torch.empty(B * D * D * 3, dtype=I32, device=dev)
+    nocc = torch.empty(B, dtype=I32, device=dev)
+    pred = torch.empty(B, 4, dtype=F32, device=dev)
+    _call("sn2_plot_project_forward_pix", _ptr(pred_pointwise), _ptr(pix), B, N, D, _ptr(keys), _ptr(arg), _ptr(nocc), _ptr(pred),
+          _stream(), key="sn2_plot_project_forward")
     return pred, pix, arg, nocc
 
 

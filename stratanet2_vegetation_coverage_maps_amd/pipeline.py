@@ -100,6 +100,9 @@ class TrainPipeline:
         self.slot_wait = "host"                   # how a geometry pass waits for its slots to be free: _wait_slots
         self.feeder_blocking = False              # diagnostic: make the feeder's host-to-device copies synchronous
         self.feeder = None                        # optional: feeder(i) -> dict of HOST tensors for batch number i
+        # the geometry passes also run the input-only pieces of the feature pass (PointNet2._input_only: row packing, P2 pixel
+        # ids) when the model has them: they are off the feature pass's critical path then
+        self.input_only = hasattr(model, "_input_only") and all("cloud" in d for d in slot_inputs)
         # exchange between the backward graph and the Adam graph (always when world > 1; can be forced on one GPU to
         # exercise exactly the launch sequence the multi-GPU run uses)
         # With an RCCL communicator on the optimiser (opt.comm: ncclAllReduce on the step's own stream) the exchange is a node
@@ -140,7 +143,7 @@ class TrainPipeline:
                 # in front of the geometry pass that reads it and behind the feature pass that last read the slot
                 for name, t in self.feeder(i).items():
                     d[name].copy_(t, non_blocking=not self.feeder_blocking)
-            self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k], **self._geo_kw)
+            self.model._geometry(d["xyz"], d["fps_start"], out=self.geo[k], **self._geo_kw, **self._cloud_kw(d))
             self.geo_ready[k].record(st)
         self.issued = max(self.issued, i + 1)
 
@@ -161,10 +164,14 @@ class TrainPipeline:
                         d[name].copy_(t, non_blocking=not self.feeder_blocking)
                 self.xyz2[pb][h * B:(h + 1) * B].copy_(d["xyz"], non_blocking=True)
                 self.fs2[pb][:, h * B:(h + 1) * B].copy_(d["fps_start"], non_blocking=True)
-            self.model._geometry_pair(self.xyz2[pb], self.fs2[pb], self.geo_pairs[pb], tuple(self.geo[k] for k in ks))
+            kw = {"clouds": [self.inputs[k]["cloud"] for k in ks]} if self.input_only else {}
+            self.model._geometry_pair(self.xyz2[pb], self.fs2[pb], self.geo_pairs[pb], tuple(self.geo[k] for k in ks), **kw)
             for k in ks:
                 self.geo_ready[k].record(st)
         self.issued = max(self.issued, i + G)
+
+    def _cloud_kw(self, d):
+        return {"cloud": d["cloud"]} if self.input_only else {}
 
     def _exchange_and_update(self, k):
         g = self.flat_grad[k]

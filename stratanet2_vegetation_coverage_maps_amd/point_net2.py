@@ -164,6 +164,12 @@ class PointNet2(nn.Module):
     # the level-1 FPS kernel when its pass shares the chip with feature kernels (sn2_fps_waves: 8 = one workgroup of 8 waves per plot)
     fps_waves_shared = int(os.environ.get("SN2_FPS_WAVES_SHARED", "8"))
     geometry_fork = True       # `_geometry`: the three independent chains behind the level-1 FPS on three streams
+    # additive: a geometry pass that is handed the batch's `cloud` also does the two INPUT-only pieces of the feature pass --
+    # the level-0 rows (`sn2_pack_rows`: 12 us of the step's critical path at C2) and, when `p2_diam_pix` is set (to
+    # args.diam_pix), the pixel ids of `project_to_plotwise_coverages` (project_to_2d.py:16-22: a function of x, y only; 10 us) --
+    # so that a loop which runs its geometry passes ahead (pipeline.TrainPipeline, prefetch_geometry) takes them off the
+    # feature pass.  Same kernels, same results.
+    p2_diam_pix = None
 
     def set_mma_dtype(self, dtype: str):
         """"fp32" (default: exact fp32 products, the reference's precision) or "bf16": the dense contractions of
@@ -188,8 +194,10 @@ class PointNet2(nn.Module):
             raise ValueError(f"expected cloud (B,{self.n_input_feats + 2},N) and xyz (B,3,N), got "
                              f"{tuple(cloud.shape)} and {tuple(xyz.shape)}")
         with torch.cuda.device(dev):
-            cloud_d = cloud.to(device=dev, dtype=F32, non_blocking=True).contiguous()
             geo = cloud_data.get("geometry", None) if isinstance(cloud_data, dict) else None
+            if geo is None and not cloud.is_cuda and not xyz.is_cuda and self.host_upload_overlap:
+                return self._forward_from_host(cloud_data, cloud, dev)
+            cloud_d = cloud.to(device=dev, dtype=F32, non_blocking=True).contiguous()
             if geo is not None:
                 if getattr(geo, "ready", None) is not None:
                     # position-only kernels already ran (or are running) on the side stream: wait for them here
@@ -207,6 +215,28 @@ class PointNet2(nn.Module):
             params = [p for p in self.parameters()]
             cov, proba = _PointNet2Fn.apply(self, xyz_d, cloud_d, fs, geo, self._dropout_keep(cloud_data, cloud_d), *params)
         return cov, proba
+
+    # CPU inputs (the reference's calling convention, learning/train.py:46-56): upload `xyz` (6 MB at C2) first through a pinned
+    # ring, launch the position-only kernels on it, and let `cloud` (21 MB) follow on a copy stream while they run
+    host_upload_overlap = os.environ.get("SN2_HOST_UPLOAD_OVERLAP", "1") == "1"
+
+    def _forward_from_host(self, cloud_data, cloud, dev):
+        """`forward` for CPU-resident inputs: same kernels, same results; only the order of uploads and launches differs."""
+        ring = ops.pinned_ring(dev)
+        cur = torch.cuda.current_stream(dev)
+        xyz_d, fs = self._stage_positions(cloud_data, dev, ring=ring)
+        g = self._geometry(xyz_d, fs, defer_join=True, inverted=self.training)       # launched: the device is busy from here on
+        up = ops.shared_stream(dev, "upload")
+        cloud_d = ring.upload(cloud, stream=up, dtype=F32)                             # host memcpy + DMA beside the geometry pass
+        ev = torch.cuda.Event()
+        ev.record(up)
+        cur.wait_event(ev)
+        cloud_d.record_stream(cur)
+        self._last_cloud_dev = (cloud, cloud_d)
+        from .project_to_2d import remember_upload
+        remember_upload(cloud, cloud_d)              # `project_to_plotwise_coverages(pred, clouds, args)` as the reference calls it
+        params = [p for p in self.parameters()]
+        return _PointNet2Fn.apply(self, xyz_d, cloud_d, None, g, self._dropout_keep(cloud_data, cloud_d), *params)
 
     def _dropout_keep(self, cloud_data, cloud_d):
         """F.dropout(x, p=self.drop, training=self.training) between lin1 and lin2 (model/point_net2.py:142): the (B*N) words
@@ -277,10 +307,28 @@ class PointNet2(nn.Module):
         g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1)))
         g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S, T), dt=I32) if ops.three_nn_uses_grid(S, T) else None
                         for S, T in ((M2, M1), (M1, N)))
+        self._alloc_input_only(g, B, N, dev)
         g.ready = None
         return g
 
-    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False, inverted=True):
+    def _alloc_input_only(self, g, B, N, dev):
+        """Buffers of the input-only pieces a geometry pass may produce (see `p2_diam_pix`)."""
+        g.rows0 = torch.empty(B * N, 12, dtype=F32, device=dev)
+        g.has_rows0 = False
+        g.p2_pix, g.p2_mm, g.p2_diam_pix = None, None, None
+        if self.p2_diam_pix is not None:
+            g.p2_pix = torch.empty(B * N, dtype=I32, device=dev)
+            g.p2_mm = torch.empty(B, 4, dtype=F32, device=dev)
+
+    def _input_only(self, g, cloud, xyz):
+        """The input-only pieces of the feature pass, run with the geometry pass when it is handed the batch's `cloud` (device)."""
+        ops.pack_rows(cloud, xyz, out=g.rows0)
+        g.has_rows0 = True
+        if g.p2_pix is not None and self.p2_diam_pix is not None:
+            ops.plot_pixels(cloud, self.p2_diam_pix, out=(g.p2_mm, g.p2_pix))
+            g.p2_diam_pix = int(self.p2_diam_pix)
+
+    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False, inverted=True, cloud=None):
         """Everything that depends on the point POSITIONS only (no weights, no features): both FPS levels, both ball
         queries, the three 3-NN tables.  In the reference these are the torch_cluster calls inside SAModule / FPModule
         (point_net2.py:22-25, 63).  Because they need no parameters they can run ahead of the feature kernels: see
@@ -295,7 +343,8 @@ class PointNet2(nn.Module):
         `inverted=False`: skip the inverted 3-NN tables (only the backward pass gathers through them: an eval-mode forward
         does not need them -- a tenth of the geometry pass of the parcel loop); `g.has_inverted` records it.
         `shared`: the pass runs beside other batches' feature kernels (a pipelined loop, `prefetch_geometry`): the level-1
-        FPS takes `fps_waves_shared` waves per plot (include/strata_hip.h: sn2_fps_waves)."""
+        FPS takes `fps_waves_shared` waves per plot (include/strata_hip.h: sn2_fps_waves).
+        `cloud` (B,10,N) on the device: also run the input-only pieces of the feature pass here (`_input_only`)."""
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
@@ -329,6 +378,9 @@ class PointNet2(nn.Module):
             if inverted:
                 ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos, row_perm=g.rank1)
         g.has_inverted = bool(inverted)
+        g.has_rows0 = False
+        if cloud is not None:
+            self._input_only(g, cloud, xyz)
         # (a)
         ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
         ops.sa_order(g.cnt1, B, M1, out=g.ord1)
@@ -365,14 +417,16 @@ class PointNet2(nn.Module):
             g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1)))
             g.ws1 = g.ws2 = g.nn_ws = None
             g.rank1 = gp.rank1[rn] if (gp.rank1 is not None and self._fp1_source_side(B * N)) else None
+            self._alloc_input_only(g, B, N, dev)
             g.ready = None
             halves.append(g)
         return gp, tuple(halves)
 
-    def _geometry_pair(self, xyz2, fps_start2, gp, halves):
+    def _geometry_pair(self, xyz2, fps_start2, gp, halves, clouds=None):
         """`_geometry` for len(halves) batches at once: xyz2 (G B,3,N), fps_start2 (2,G B); FPS, ball queries and 3-NN tables
         run on all plots in one launch each (into `gp`), the per-batch products (message totals, SA work items, inverted 3-NN
-        indices) per batch.  Same tables as G `_geometry` calls."""
+        indices) per batch.  Same tables as G `_geometry` calls.  clouds: the G batches' (B,10,N) device tensors -> also the
+        input-only pieces of their feature passes (`_input_only`)."""
         B2, _, N = xyz2.shape
         B = B2 // len(halves)
         M1, M2 = self._sizes(N)
@@ -389,6 +443,9 @@ class PointNet2(nn.Module):
         ops.three_nn(gp.pos1_soa, xyz2, 3, out=gp.knn1, ws=gp.nn_ws[1])
         for h, g in enumerate(halves):
             g.xyz = xyz2[h * B:(h + 1) * B]
+            g.has_rows0 = False
+            if clouds is not None:
+                self._input_only(g, clouds[h], g.xyz)
             ops.count_sum(g.cnt1, g.tot1)
             ops.count_sum(g.cnt2, g.tot2)
             ops.sa_order(g.cnt1, B, M1, out=g.ord1)
@@ -418,16 +475,21 @@ class PointNet2(nn.Module):
             with torch.cuda.stream(side):
                 # one stream per pass: several passes are in flight on their own lanes already, and a fork inside each
                 # (three more streams + their events) cost the parcel loop 18 % (33 300 -> 27 100 plots/s)
-                g = self._geometry(xyz_d, fs, shared=True, fork=False, inverted=self.training)
+                cl = cloud_data.get("cloud", None) if isinstance(cloud_data, dict) else None
+                cl = cl if (isinstance(cl, torch.Tensor) and cl.is_cuda and cl.dtype == F32 and cl.is_contiguous()) else None
+                g = self._geometry(xyz_d, fs, shared=True, fork=False, inverted=self.training, cloud=cl)
                 g.fps_start = fs
                 g.ready = torch.cuda.Event()
                 g.ready.record(side)
             g.stream = side
         return g
 
-    def _stage_positions(self, cloud_data, dev):
+    def _stage_positions(self, cloud_data, dev, ring=None):
         xyz = cloud_data["xyz"]
-        xyz_d = xyz.to(device=dev, dtype=F32, non_blocking=True).contiguous()
+        if ring is not None and not xyz.is_cuda:
+            xyz_d = ring.upload(xyz, dtype=F32)
+        else:
+            xyz_d = xyz.to(device=dev, dtype=F32, non_blocking=True).contiguous()
         B, _, N = xyz_d.shape
         fs = cloud_data.get("fps_start", None) if isinstance(cloud_data, dict) else None
         if fs is None:
@@ -445,6 +507,8 @@ class PointNet2(nn.Module):
         M1, M2 = self._sizes(N)
         cur_stream = torch.cuda.current_stream(dev)
         rows0, packed = None, None
+        if geo is not None and getattr(geo, "has_rows0", False) and geo.rows0.shape[0] == B * N:
+            rows0 = geo.rows0                    # packed by the geometry pass (`_input_only`)
         if geo is None:
             if self.geometry_fork:
                 # the row packing needs the inputs only: beside the level-1 FPS (16 workgroups) instead of behind it
@@ -468,7 +532,7 @@ class PointNet2(nn.Module):
             geo.has_inverted = True
         s = _Saved()
         s.__dict__.update({k: v for k, v in geo.__dict__.items()
-                           if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws", "fps_start", "_join")})
+                           if k not in ("ready", "stream", "ws1", "ws2", "totals", "nn_ws", "fps_start", "_join", "has_rows0")})
         s.xyz = xyz
         # per-forward arenas for the BN side buffers of the 7 blocks: a,c,mean,invstd and the per-workgroup statistics
         # slots (written before they are read: no zero fill)
@@ -488,6 +552,8 @@ class PointNet2(nn.Module):
         # ---- level 0 rows: [8 features | x y z 0]
         if packed is not None:
             cur_stream.wait_event(packed)
+            s.rows0 = rows0
+        elif rows0 is not None:
             s.rows0 = rows0
         else:
             s.rows0 = ops.pack_rows(cloud, xyz)

@@ -95,11 +95,12 @@ class PointNet2ThreeSA(PointNet2):
             g.inv4, g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M3, 1), (M2, M3), (M1, M2), (N, M1)))
             g.nn_ws = None
             g.rank1 = gp.rank1[h * B * N:(h + 1) * B * N] if (gp.rank1 is not None and self._fp1_source_side(B * N)) else None
+            self._alloc_input_only(g, B, N, dev)
             g.ready = None
             halves.append(g)
         return gp, tuple(halves)
 
-    def _geometry_pair(self, xyz2, fps_start2, gp, halves):
+    def _geometry_pair(self, xyz2, fps_start2, gp, halves, clouds=None):
         """`_geometry` for two batches at once: xyz2 (2B,3,N), fps_start2 (3,2B); FPS, ball queries and 3-NN tables on the 2B
         plots in one launch each (into `gp`), the per-batch products (message totals, work items, inverted indices) per half."""
         B2, _, N = xyz2.shape
@@ -122,6 +123,9 @@ class PointNet2ThreeSA(PointNet2):
         ops.three_nn(gp.pos1_soa, xyz2, 3, out=gp.knn1, ws=gp.nn_ws[2])
         for h, g in enumerate(halves):
             g.xyz = xyz2[h * B:(h + 1) * B]
+            g.has_rows0 = False
+            if clouds is not None:                      # the input-only pieces of the feature pass (PointNet2._input_only)
+                self._input_only(g, clouds[h], g.xyz)
             for lvl, M in ((1, M1), (2, M2), (3, M3)):
                 ops.count_sum(getattr(g, f"cnt{lvl}"), getattr(g, f"tot{lvl}"))
                 ops.sa_order(getattr(g, f"cnt{lvl}"), B, M, out=getattr(g, f"ord{lvl}"))
@@ -155,10 +159,11 @@ class PointNet2ThreeSA(PointNet2):
         g.nn_ws = tuple(e(ops.three_nn_ws_words(B, S, T), dt=I32) if ops.three_nn_uses_grid(S, T) else None
                         for S, T in ((M3, M2), (M2, M1), (M1, N)))
         g.rank1 = ops.fps_ws_rank(g.ws1, B, N) if (self.fp1_morton_rows and g.ws1 is not None and self._fp1_source_side(B * N)) else None       # as PointNet2.alloc_geometry
+        self._alloc_input_only(g, B, N, dev)
         g.ready = None
         return g
 
-    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False, inverted=True):
+    def _geometry(self, xyz, fps_start, out=None, fork=None, shared=False, defer_join=False, inverted=True, cloud=None):
         """As `PointNet2._geometry` with the third ball-query level; one stream (`fork` / `defer_join` are accepted and
         ignored: nothing is forked, so there is nothing to join), `shared` = the level-1 FPS with `fps_waves_shared` waves
         per plot, `inverted=False` = skip the inverted 3-NN tables (an eval-mode forward never gathers through them;
@@ -170,6 +175,9 @@ class PointNet2ThreeSA(PointNet2):
         if (g.B, g.N, g.M1, g.M2, g.M3) != (B, N, M1, M2, M3):
             raise ValueError("geometry buffers do not match this batch")
         g.xyz = xyz
+        g.has_rows0 = False
+        if cloud is not None:
+            self._input_only(g, cloud, xyz)
         cap = _p2.MAX_NEIGHBORS
         src = xyz
         for lvl, (M, mod) in enumerate(((M1, self.sa1_module), (M2, self.sa2_module), (M3, self.sa3_module)), 1):
@@ -199,8 +207,12 @@ class PointNet2ThreeSA(PointNet2):
         ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
         ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos, row_perm=getattr(g, "rank1", None))
 
-    def _stage_positions(self, cloud_data, dev):
-        xyz_d = cloud_data["xyz"].to(device=dev, dtype=F32, non_blocking=True).contiguous()
+    def _stage_positions(self, cloud_data, dev, ring=None):
+        xyz = cloud_data["xyz"]
+        if ring is not None and not xyz.is_cuda:
+            xyz_d = ring.upload(xyz, dtype=F32)           # (hip_ops.PinnedRing: PointNet2._forward_from_host)
+        else:
+            xyz_d = xyz.to(device=dev, dtype=F32, non_blocking=True).contiguous()
         B, _, N = xyz_d.shape
         fs = cloud_data.get("fps_start", None) if isinstance(cloud_data, dict) else None
         if fs is None:
@@ -226,7 +238,7 @@ class PointNet2ThreeSA(PointNet2):
             geo.has_inverted = True
         s = _Saved()
         s.__dict__.update({k: v for k, v in geo.__dict__.items()
-                           if k not in ("ready", "stream", "totals", "nn_ws", "fps_start", "_join", "has_inverted")})
+                           if k not in ("ready", "stream", "totals", "nn_ws", "fps_start", "_join", "has_inverted", "has_rows0")})
         s.xyz = xyz
         widths = [16, 16, 32, 64, 64, 64, 64, 34, 34]
         aux = torch.empty(4 * sum(widths), dtype=F32, device=dev)
@@ -243,7 +255,10 @@ class PointNet2ThreeSA(PointNet2):
         s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
         s.aux, s.stats = aux, stats
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
-        s.rows0 = ops.pack_rows(cloud, xyz)
+        if getattr(geo, "has_rows0", False) and geo.rows0.shape[0] == B * N:
+            s.rows0 = geo.rows0                   # packed by the geometry pass (PointNet2._input_only)
+        else:
+            s.rows0 = ops.pack_rows(cloud, xyz)
         s.ext1, s.arg1, s.x1 = e(B * M1, 16), e(B * M1, 16, dt=I32), e(B * M1, 16)
         ops.sa_forward(self._sa1_desc(s), training)
         s.ext2, s.arg2, s.x2 = e(B * M2, 32), e(B * M2, 32, dt=I32), e(B * M2, 32)

@@ -13,9 +13,12 @@ class _PlotProject(torch.autograd.Function):
     gradients."""
 
     @staticmethod
-    def forward(ctx, pred_pointwise, clouds_dev, diam_pix):
+    def forward(ctx, pred_pointwise, clouds_dev, diam_pix, pix=None):
         B, _, N = clouds_dev.shape
-        pred, pix, arg, nocc = ops.plot_project_forward(pred_pointwise.contiguous(), clouds_dev, diam_pix)
+        if pix is not None:          # the ids were computed ahead of time (hip_ops.plot_pixels: they depend on x, y only)
+            pred, pix, arg, nocc = ops.plot_project_forward_pix(pred_pointwise.contiguous(), pix, B, N, diam_pix)
+        else:
+            pred, pix, arg, nocc = ops.plot_project_forward(pred_pointwise.contiguous(), clouds_dev, diam_pix)
         ctx.save_for_backward(arg, nocc, pix)
         ctx.dims = (B, N, int(diam_pix))
         return pred
@@ -24,7 +27,18 @@ class _PlotProject(torch.autograd.Function):
     def backward(ctx, dpred):
         arg, nocc, pix = ctx.saved_tensors
         B, N, D = ctx.dims
-        return ops.plot_project_backward(dpred.contiguous().float(), arg, nocc, pix, B, N, D), None, None
+        return ops.plot_project_backward(dpred.contiguous().float(), arg, nocc, pix, B, N, D), None, None, None
+
+
+# The reference calls `project_to_plotwise_coverages(pred_pointwise, clouds, args)` with the very CPU tensor it just gave to
+# `PointNet2.forward` (learning/train.py:53-56): the forward remembers its upload here (one entry, weakly referenced host
+# tensor), so the unchanged call does not copy 21 MB a second time.
+_LAST_UPLOAD = [None, None]          # [weakref to the host tensor, its device copy]
+
+
+def remember_upload(host, dev_tensor):
+    import weakref
+    _LAST_UPLOAD[0], _LAST_UPLOAD[1] = weakref.ref(host), dev_tensor
 
 
 def _clouds_on_device(clouds, device, model_cache=None):
@@ -32,13 +46,20 @@ def _clouds_on_device(clouds, device, model_cache=None):
         return clouds.float().contiguous()
     if model_cache is not None and model_cache[0] is clouds:
         return model_cache[1]
+    ref, dev_t = _LAST_UPLOAD
+    if ref is not None and ref() is clouds and dev_t is not None and dev_t.device == torch.device(device):
+        _LAST_UPLOAD[0] = _LAST_UPLOAD[1] = None      # used once: do not keep the batch alive
+        return dev_t
     return clouds.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
 
 
-def project_to_plotwise_coverages(pred_pointwise, clouds, args, model=None):
+def project_to_plotwise_coverages(pred_pointwise, clouds, args, model=None, geometry=None):
     """pred_pointwise (B*N,4) on the device, clouds (B,10,N) (CPU, as the DataLoader hands them, or device) ->
     (B,4) [low_veg, bare_soil, med_veg, high_veg], differentiable w.r.t. pred_pointwise.
-    `model` (optional): the PointNet2 whose forward already uploaded `clouds`, to skip a second H2D copy."""
+    `model` (optional): the PointNet2 whose forward already uploaded `clouds`, to skip a second H2D copy.
+    `geometry` (optional, additive): the handle of a geometry pass that ran with `model.p2_diam_pix = args.diam_pix`
+    (PointNet2._geometry): the pixel id of every point is already there (it depends on the plot's x, y only), and the
+    projection is two launches instead of three."""
     if not pred_pointwise.is_cuda:
         raise StrataHipError("project_to_plotwise_coverages needs pred_pointwise on a HIP device: no CPU fallback")
     cache = getattr(model, "_last_cloud_dev", None) if model is not None else None
@@ -46,7 +67,11 @@ def project_to_plotwise_coverages(pred_pointwise, clouds, args, model=None):
         clouds_dev = _clouds_on_device(clouds, pred_pointwise.device, cache)
         if cache is not None:
             model._last_cloud_dev = None          # used once: do not keep the batch's host and device clouds alive
-        return _PlotProject.apply(pred_pointwise, clouds_dev, args.diam_pix)
+        pix = getattr(geometry, "p2_pix", None) if geometry is not None else None
+        if pix is not None and (getattr(geometry, "p2_diam_pix", None) != int(args.diam_pix) or
+                                pix.numel() != clouds_dev.shape[0] * clouds_dev.shape[2]):
+            pix = None                            # ids of another grid or batch: recompute
+        return _PlotProject.apply(pred_pointwise, clouds_dev, args.diam_pix, pix)
 
 
 def project_to_2d_rasters(cloud, coverages_pointwise, args):

@@ -154,7 +154,8 @@ def self_test(comm: RcclComm, graph: bool = True):
         if graph:
             buf = torch.empty(4096, device=dev)
             src = torch.full((4096,), float(r + 1), device=dev)
-            side = torch.cuda.Stream(dev)
+            from .hip_ops import shared_stream           # (no stream of its own: streams are a per-process resource, hip_ops.shared_stream)
+            side = shared_stream(dev, "capture")
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 torch.add(src, 0.0, out=buf)                 # (a kernel, not a copy: captured memcpy / memset nodes are avoided everywhere)

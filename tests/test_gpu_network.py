@@ -122,6 +122,35 @@ def test_pixel_indices_bit_exact_and_p2_gradient():
         assert np.array_equal(np.nan_to_num(got), np.nan_to_num(ref))     # maxima of identical fp32 values: exact
 
 
+def test_projection_from_precomputed_pixel_ids_is_the_same_projection():
+    """sn2_plot_pixels + sn2_plot_project_forward_pix (the ids computed ahead, per-slice key tables, no atomics across
+    workgroups) == sn2_plot_project_forward, bit for bit: pixel ids, arg-max points, occupied-pixel counts, plot-wise
+    coverages and the gradient -- on quantised values (many exact ties: first point wins) and several plot sizes."""
+    for B, N in ((3, 5000), (2, 32768), (5, 700)):
+        args = make_args(subsample_size=N)
+        d = make_batch(B, N, first_plot=40)
+        g = torch.Generator().manual_seed(5)
+        pw = ((torch.rand(B * N, 4, generator=g) * 8).floor() / 8).cuda()
+        clouds_dev = d["cloud"].cuda()
+        pred0, pix0, arg0, nocc0 = ops.plot_project_forward(pw, clouds_dev, args.diam_pix)
+        mm, pix = ops.plot_pixels(clouds_dev, args.diam_pix)
+        pred1, pix1, arg1, nocc1 = ops.plot_project_forward_pix(pw, pix, B, N, args.diam_pix)
+        assert torch.equal(pix, pix0) and torch.equal(arg1, arg0) and torch.equal(nocc1, nocc0) and torch.equal(pred1, pred0)
+        ref = projection.p2_pixel_ids(d["cloud"], args.diam_pix)
+        assert torch.equal(pix.cpu(), (ref[:, 0] * args.diam_pix + ref[:, 1]).reshape(-1).int())
+        # through the autograd node, with a geometry handle that carries the ids
+        from types import SimpleNamespace
+        geo = SimpleNamespace(p2_pix=pix, p2_diam_pix=args.diam_pix)
+        a = pw.clone().requires_grad_(True)
+        b = pw.clone().requires_grad_(True)
+        wgt = torch.rand(B, 4, generator=g).cuda()
+        (project_to_plotwise_coverages(a, clouds_dev, args, geometry=geo) * wgt).sum().backward()
+        (project_to_plotwise_coverages(b, clouds_dev, args) * wgt).sum().backward()
+        assert torch.equal(a.grad, b.grad)
+        geo_other = SimpleNamespace(p2_pix=pix, p2_diam_pix=args.diam_pix + 1)        # ids of another grid: ignored
+        assert torch.equal(project_to_plotwise_coverages(pw, clouds_dev, args, geometry=geo_other), pred0)
+
+
 @pytest.mark.parametrize("B,N,ratio1,r1,r2", [(2, 3000, 0.1, 1.0, 2.0), (1, 8192, 0.125, 1.0, 2.0),
                                                (1, 10000, 0.25, 2 ** 0.5, 8 ** 0.5)])
 def test_forward_backward_vs_oracle_other_sizes(B, N, ratio1, r1, r2):

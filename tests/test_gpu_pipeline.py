@@ -12,11 +12,15 @@ from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_ba
 pytestmark = pytest.mark.gpu
 
 
-def _setup(N, B, depth, n_slots=None, lr=1e-3):
+def _setup(N, B, depth, n_slots=None, lr=1e-3, input_only=False):
+    """input_only: the geometry passes also compute the projection's pixel ids (`model.p2_diam_pix`; the row packing moves there
+    whenever a pass is handed the batch's cloud) and the feature step projects from them -- bench.py's configuration."""
     args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
     model = PointNet2(args)
     model.load_state_dict(network.init_state_dict(5))
     model = model.cuda().train()
+    if input_only:
+        model.p2_diam_pix = args.diam_pix
     flatten_parameters(model)
     # eps = 1e-3, not Adam's 1e-8: the two loops compared here differ in the order of a few fp32 atomic adds, and with the
     # default eps the FIRST update of a weight is lr * g / (|g| + eps) -- rounding noise on a gradient of ~1e-8 moves that
@@ -36,7 +40,7 @@ def _setup(N, B, depth, n_slots=None, lr=1e-3):
         if geo is not None:
             cd["geometry"] = geo
         cov, proba = model(cd)
-        pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
+        pred = project_to_plotwise_coverages(cov, inp["cloud"], args, geometry=geo if input_only else None)
         loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
         loss.backward()
         return loss
@@ -110,7 +114,9 @@ def test_pipeline_in_the_headline_mode_matches_plain_loop():
     hipGraph per slot, Adam in the same graph -- on tiny plots, for more steps than there are slots (every slot is reused: its
     tables are overwritten by a later pass while earlier feature passes are still queued).  Learning rate 0 (the optimiser
     kernel still runs and counts): every loss is a function of that step's batch and tables only, so the pipelined loop must
-    reproduce the plain loop to 1e-6 at EVERY step; a stale, late or misplaced table shows as 1e-2 and more."""
+    reproduce the plain loop to 1e-6 at EVERY step; a stale, late or misplaced table shows as 1e-2 and more.
+    The pipelined side runs as bench.py does: the geometry passes also pack the level-0 rows and compute the projection's pixel
+    ids (input-only pieces of the feature pass), and the passes are issued with a phase; the plain loop does neither."""
     N, B, depth, G = 4096, 2, 3, 8
     n_slots = G * depth + G
     steps = n_slots + 2 * G + 3
@@ -121,9 +127,10 @@ def test_pipeline_in_the_headline_mode_matches_plain_loop():
         opt.step()
         ref.append(float(l.detach()))
     assert np.ptp(ref[:n_slots]) > 1e-3               # the slots hold different batches: their losses tell them apart
-    model2, opt2, slots2, fstep2 = _setup(N, B, depth, n_slots, lr=0.0)
-    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=True, group=G)
-    assert pipe.group == G and pipe.slots == 32 and pipe.ahead == G * depth
+    model2, opt2, slots2, fstep2 = _setup(N, B, depth, n_slots, lr=0.0, input_only=True)
+    pipe = TrainPipeline(model2, opt2, fstep2, slots2, depth=depth, use_graph=True, group=G, phase=3)
+    assert pipe.group == G and pipe.slots == 32 and pipe.ahead == G * depth - 3 and pipe.input_only
+    assert all(g.p2_pix is not None for g in pipe.geo)
     pipe.capture()
     model2.load_state_dict(network.init_state_dict(5))
     opt2.reset()
