@@ -279,6 +279,11 @@ typedef struct sn2_head {
     int act_bf16;                   /* non-zero: the rows of f and dy are bfloat16 (as sn2_fp.act_bf16 of the block that wrote f) */
 } sn2_head;
 int sn2_head_forward(const sn2_head *p, void *stream);
+/* EVAL only: the per-point layer (p: the 34 + 8 -> 34 block with its 3-NN table, source-side workspace p->src_ws required) and
+ * the head (hd: f / f_stride unused -- the rows never leave the CU; fa, fc = p->blk.a, p->blk.c; no dropout, fp32 rows) in one
+ * pass: fp_forward(p, eval) + head_forward(hd) without the (B*N, 36) activation buffer between them (model/point_net2.py:139-151
+ * under model.eval(), predict.py:96-126).  Same operations in the same order as the two calls: the same bits. */
+int sn2_fp_head_eval(const sn2_fp *p, const sn2_head *hd, void *stream);
 int sn2_head_backward(const sn2_head *p, void *stream);
 /* After sn2_head_backward: the gradients of the BatchNorm whose output the head reads (FP1's), obtained from lin1's weight
  * and bias gradients instead of a pass over all rows (derivation in fp.hip).  gamma, beta, mean, invstd: that BatchNorm's

@@ -1,11 +1,13 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of ANY bench.py invocation: `bash scripts/kstats.sh OUTDIR [bench flags]` (on the GPU box).
+# rocprofv3 kernel statistics of ANY bench.py invocation: `bash scripts/kstats.sh OUTDIR [bench flags]` (on the GPU box;
+# SN2_KSTATS_PROG=scripts/bench_inference.py profiles that program instead).
 # Writes OUTDIR/kstats.csv (the --stats summary) and prints the kernels by total time.  The program follows "--" directly.
 out=$1; shift
 root=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $root/$out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof -- python3 $root/bench.py "$@" > $root/$out/prof.log 2>&1 || { tail -20 $root/$out/prof.log; exit 1; }
+prog=${SN2_KSTATS_PROG:-bench.py}      # another program of the repository, e.g. scripts/bench_inference.py
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof -- python3 $root/$prog "$@" > $root/$out/prof.log 2>&1 || { tail -20 $root/$out/prof.log; exit 1; }
 cd $root
 find $out/prof -name "*kernel_stats.csv" | xargs -I{} cp {} $out/kstats.csv
 rm -rf $out/prof

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sn2_plot_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "sn2_plot_max_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_head_forward": [POINTER(Head), c_void_p],
+    "sn2_fp_head_eval": [POINTER(FP), POINTER(Head), c_void_p],
     "sn2_fp_bn_sums": [POINTER(FP), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_head_bn_sums": [POINTER(Head), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_head_backward": [POINTER(Head), c_void_p],

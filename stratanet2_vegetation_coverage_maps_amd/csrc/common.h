@@ -56,6 +56,13 @@ static inline void sn2_fill_words(void* p, uint32_t v, size_t nwords, hipStream_
 }
 #endif
 
+// One-workgroup-per-plot kernels (the sorts): 1024 threads per plot are the shortest pass for a few plots (a training batch),
+// but a 1024-thread workgroup needs a CU with sixteen free wave slots AT ONCE, and beside full-chip kernels of four-wave
+// workgroups (which take every slot the moment it frees up) it starves: in the parcel loop (256 plots per launch, four passes
+// in flight) the target sort of the 3-NN search took 0.82 ms instead of 0.03, the spatial sort 0.46 instead of 0.06.  With
+// many plots the chip is full anyway: 256 threads per plot.
+static inline bool sn2_small_sort_wg(int B) { return B > 32; }
+
 // compute units of the current device (256 on MI355X), for the grids of the persistent kernels
 static inline int sn2_cu_count() {
     static int n = 0;

@@ -2087,6 +2087,149 @@ __global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const floa
     }
 }
 
+// EVAL: the per-point layer FP1 (source-side form: fp_fwd_rows_kernel's row side) and the head in ONE kernel.  An eval pass keeps
+// nothing for a backward, so the 144-byte rows of h1 need not exist: a wave computes 63 consecutive rows (nine groups of seven,
+// nine lanes per row as in fp_fwd_rows_kernel) straight into the LDS tile head_fwd_mfma_kernel reads its rows from, and runs
+// that kernel's turn on it (row 63 of the tile is padding).  Same operations in the same order as the two kernels: the same
+// bits.  Saves the write and the read of h1 (parcel inference: 740 MB per launch of 256 plots) and a launch.
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256, 2) void fp_head_eval_kernel(int R, int R_per_plot, int S_per_plot, int skip_stride,
+                                                              const float* __restrict__ T, const int* __restrict__ knn_idx,
+                                                              const float* __restrict__ knn_w, const float* __restrict__ skip,
+                                                              const float* __restrict__ Wg, const float* __restrict__ biasg,
+                                                              const float* __restrict__ fa, const float* __restrict__ fc,
+                                                              const float* __restrict__ W1, const float* __restrict__ b1,
+                                                              const float* __restrict__ W2, const float* __restrict__ b2,
+                                                              float* __restrict__ cov, float* __restrict__ proba) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 3, ROWS = G * 9;
+    static_assert(CO == 34 && HS == 36 && G == 7 && ROWS == 63, "the head reads rows of 36 floats, 63 per turn");
+    static_assert(CB > 0 && CB % 4 == 0, "skip quads");
+    __shared__ float4 s_t[4 * HEAD_T_QUADS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* st4 = s_t + wave * HEAD_T_QUADS;
+    float* st = reinterpret_cast<float*>(st4);
+    float* zt = st;                    // [64][20] after lin1 has read the rows
+    float* sc = st + 64 * 20;          // [64][8]
+    const int q = lane % QH, g = lane / QH;
+    const bool on = lane < G * QH;
+    const int n = lane & 15, kq = lane >> 4;
+    // the row side's weights (fp_fwd_rows_kernel) and the head's (head_fwd_mfma_kernel), in registers for the whole kernel
+    float wB[4][CB], b4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int o = 4 * q + t;
+        b4[t] = o < CO ? biasg[o] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) wB[t][k] = o < CO ? Wg[o * CI + CA + k] : 0.f;
+    }
+    float w1[9], ak[9], ck[9], w2[4];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+        const int k = 4 * ks + kq;
+        w1[ks] = k < 34 ? W1[n * 34 + k] : 0.f;
+        ak[ks] = k < 34 ? fa[k] : 0.f;
+        ck[ks] = k < 34 ? fc[k] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w2[ks] = n < 5 ? W2[n * 16 + 4 * ks + kq] : 0.f;
+    const float bias1 = b1[n], bias2 = n < 5 ? b2[n] : 0.f;
+    const long n_turns = ((long)R + ROWS - 1) / ROWS;
+    for (long turn = (long)blockIdx.x * 4 + wave; turn < n_turns; turn += (long)gridDim.x * 4) {
+        const long r0 = turn * ROWS;
+        // ---- FP1, rows r0 .. r0 + 62 -> the tile (a group of seven rows per step, U groups' loads in flight)
+#pragma unroll 1
+        for (int g0 = 0; g0 < 9; g0 += U) {
+            FpRowIn<QB> in[U];
+            float4 ta[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) in[u] = fp_row_in<QB>(r0 + (long)(g0 + u) * G + g, on, R, knn_idx, knn_w, skip, skip_stride);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned base = (in[u].rr / (unsigned)R_per_plot) * (unsigned)S_per_plot;
+                ta[u][0] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i0) * HS)[q];
+                ta[u][1] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i1) * HS)[q];
+                ta[u][2] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i2) * HS)[q];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w0 = in[u].w0, wa = in[u].w1, wb = in[u].w2;
+                const float inv = 1.0f / ((w0 + wa) + wb);
+                const float4 a = ta[u][0], b = ta[u][1], c = ta[u][2];
+                float v[4] = {((a.x * w0 + b.x * wa) + c.x * wb) * inv, ((a.y * w0 + b.y * wa) + c.y * wb) * inv,
+                              ((a.z * w0 + b.z * wa) + c.z * wb) * inv, ((a.w * w0 + b.w * wa) + c.w * wb) * inv};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float acc = v[t] + b4[t];
+#pragma unroll
+                    for (int b2q = 0; b2q < QB; ++b2q) {
+                        acc = fmaf(wB[t][4 * b2q + 0], in[u].sk[b2q].x, acc);
+                        acc = fmaf(wB[t][4 * b2q + 1], in[u].sk[b2q].y, acc);
+                        acc = fmaf(wB[t][4 * b2q + 2], in[u].sk[b2q].z, acc);
+                        acc = fmaf(wB[t][4 * b2q + 3], in[u].sk[b2q].w, acc);
+                    }
+                    v[t] = (in[u].valid && 4 * q + t < CO) ? fmaxf(acc, 0.f) : 0.f;
+                }
+                if (on) st4[((g0 + u) * G + g) * QH + q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (lane < QH) st4[ROWS * QH + lane] = make_float4(0.f, 0.f, 0.f, 0.f);      // row 63: padding
+        WAVE_LDS_SYNC();
+        // ---- the head on the tile: head_fwd_mfma_kernel's turn
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = f32x4{bias1, bias1, bias1, bias1};
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                const float v = st[(16 * t + n) * 36 + 4 * ks + kq];
+                const float a = (4 * ks + kq < 34) ? fmaf(ak[ks], v, ck[ks]) : 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w1[ks], acc[t], 0, 0, 0);
+            }
+        }
+        WAVE_LDS_SYNC();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zt[(16 * t + 4 * kq + j) * 20 + n] = fmaxf(acc[t][j], 0.f);
+        WAVE_LDS_SYNC();
+        f32x4 s2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s2[t] = f32x4{bias2, bias2, bias2, bias2};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[(16 * t + n) * 20 + 4 * ks + kq], w2[ks], s2[t], 0, 0, 0);
+        }
+        if (n < 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[(16 * t + 4 * kq + j) * 8 + n] = s2[t][j];
+        }
+        WAVE_LDS_SYNC();
+        const long r = r0 + lane;
+        const float4 s03 = *reinterpret_cast<const float4*>(&sc[lane * 8]);
+        const float s4 = sc[lane * 8 + 4];
+        WAVE_LDS_SYNC();
+        const float sv[4] = {s03.x, s03.y, s03.z, s03.w};
+        const float m = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        float e[4], den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            e[i] = expf(sv[i] - m);
+            den += e[i];
+        }
+        float pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pr[i] = e[i] / den;
+        const float dens = 1.0f / (1.0f + expf(-s4));
+        if (lane < ROWS && r < R) {
+            reinterpret_cast<float4*>(proba)[r] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+            reinterpret_cast<float4*>(cov)[r] = make_float4(pr[0] * dens, pr[1] * dens, pr[2] * dens, pr[3] * dens);
+        }
+    }
+}
+
 constexpr int HEAD_BWD_THREADS = 256;
 constexpr int HEAD_BWD_LDS_FLOATS = OuterAcc<16, 35, 32>::LDS_FLOATS;   // >= OuterAcc<16, 17, 32>::LDS_FLOATS
 template <bool BF>
@@ -2293,6 +2436,32 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     hipLaunchKernelGGL(kf, dim3(pick_grid(p->R * grid_mult, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
                        p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba, p->drop_mask,
                        p->drop_mask ? p->drop_scale : 1.f);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_fp_head_eval(const sn2_fp* p, const sn2_head* hd, void* stream) {
+    // (neither p->h nor hd->f is read: the rows stay in LDS)
+    if (!p || !hd || p->B <= 0 || p->R_per_plot <= 0 || p->S_per_plot <= 0 || !p->src || !p->blk.W || !p->blk.b || !p->skip ||
+        !p->blk.a || !p->blk.c || (p->src_stride & 3) || p->src_stride < p->ca || p->blk.cin != p->ca + p->cb)
+        return SN2_EINVAL;
+    if (hd->R <= 0 || hd->cin != 34 || !hd->fa || !hd->fc || !hd->W1 || !hd->b1 || !hd->W2 || !hd->b2) return SN2_EINVAL;
+    if (!hd->coverages || !hd->proba || hd->drop_mask || hd->act_bf16 || p->act_bf16) return SN2_EINVAL;
+    if (!(p->knn_idx && p->ca == 34 && p->cb == 8 && p->blk.cout == 34 && hd->R == p->B * p->R_per_plot)) return SN2_ELIMIT;
+    if (!(p->src_ws && (p->skip_stride & 3) == 0 && p->src_stride >= 36 && (long)hd->R * 3 < (1L << 31))) return SN2_ELIMIT;
+    hipStream_t st = (hipStream_t)stream;
+    const int R = hd->R, n_src = p->B * p->S_per_plot;
+    // the layer's BatchNorm on its running statistics -> (a, c) = what the head applies to the rows (hd->fa, hd->fc name the
+    // same two vectors: p->blk.a, p->blk.c)
+    SN2_TRY(sn2_bn_finalize(&p->blk, 0, nullptr, R, 0, st));
+    hipLaunchKernelGGL((fp_src_table_kernel<34, 8, 34>), dim3(sn2_cdiv(n_src, 64)), dim3(256), 0, st, n_src, p->src_stride, p->src,
+                       p->src_a, p->src_c, p->blk.W, p->src_ws);
+    const long turns = ((long)R + 62) / 63;
+    int grid = sn2_cdiv(turns, 4);
+    const int cap = 4 * sn2_cu_count();
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL((fp_head_eval_kernel<34, 8, 34>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
+                       p->skip_stride, (const float*)p->src_ws, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.b, hd->fa, hd->fc,
+                       hd->W1, hd->b1, hd->W2, hd->b2, hd->coverages, hd->proba);
     SN2_RETURN_LAUNCH();
 }
 

@@ -162,12 +162,11 @@ constexpr int FPS_XCHG_WORDS = 4096, FPS_CTL_WORDS = 32;
 // all 32 points of a thread in registers at once spill at 1024 threads).  What is left (61 us) are the LDS atomics: 55 % of a
 // plot's points are ground points in a few cell layers, and a wave's adds onto one counter serialise.
 // rank (or NULL): rank[plot * N + i] = sorted position of point i -- the inverse of `order` (sn2_fp.row_perm)
-template <int U>
-__global__ __launch_bounds__(1024) void spatial_order_chunk_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
-                                                                   float4* __restrict__ sorted, int* __restrict__ grid,
-                                                                   unsigned* __restrict__ xchg, unsigned* __restrict__ ctl,
-                                                                   int* __restrict__ rank) {
-    constexpr int NT = 1024;
+template <int U, int NT>
+__global__ __launch_bounds__(NT) void spatial_order_chunk_kernel(const float* __restrict__ pos, int N, int* __restrict__ order,
+                                                                 float4* __restrict__ sorted, int* __restrict__ grid,
+                                                                 unsigned* __restrict__ xchg, unsigned* __restrict__ ctl,
+                                                                 int* __restrict__ rank) {
     __shared__ int s_hist[ORDER_CELLS];
     __shared__ float s_mm[6][NT / 64];
     __shared__ int s_wsum[NT / 64];
@@ -281,10 +280,12 @@ __global__ __launch_bounds__(1024) void spatial_order_chunk_kernel(const float* 
 static void launch_spatial_order(const float* pos, int B, int N, int* order, float4* sorted, int* grid, unsigned* xchg,
                                  unsigned* ctl, hipStream_t st) {
     int* rank = reinterpret_cast<int*>(ctl + FPS_CTL_WORDS);          // the last B*N words of the workspace
-    if (N <= 8 * 1024)
-        hipLaunchKernelGGL(spatial_order_chunk_kernel<8>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl, rank);
+    if (sn2_small_sort_wg(B) && N <= 16 * 1024)          // many plots: 256 threads per plot (common.h)
+        hipLaunchKernelGGL((spatial_order_chunk_kernel<16, 256>), dim3(B), dim3(256), 0, st, pos, N, order, sorted, grid, xchg, ctl, rank);
+    else if (N <= 8 * 1024)
+        hipLaunchKernelGGL((spatial_order_chunk_kernel<8, 1024>), dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl, rank);
     else
-        hipLaunchKernelGGL(spatial_order_chunk_kernel<16>, dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl, rank);
+        hipLaunchKernelGGL((spatial_order_chunk_kernel<16, 1024>), dim3(B), dim3(1024), 0, st, pos, N, order, sorted, grid, xchg, ctl, rank);
 }
 
 // canonical, monotone lower bound of sn2_d2(p, c) over all p inside the box [lo, hi]
@@ -1847,6 +1848,10 @@ constexpr int GQ_LIST = 512;
 constexpr int GQ_DENSE = SN2_GQ_DENSE;   // hits beyond which the bitmap path takes over from the rank sort (measured: switching at 192
                                          // instead of 512 made the query slower at both sizes, 0.30 vs 0.26 ms at 8 x 131 072, 0.075 vs 0.054 at 16 x 32 768)
 static_assert(GQ_DENSE <= GQ_LIST, "the list holds the sparse balls");
+#ifndef SN2_GQ_BM_CAND
+#define SN2_GQ_BM_CAND 160
+#endif
+constexpr int GQ_BM_WORDS = 512, GQ_BM_CAND = SN2_GQ_BM_CAND;   // bitmap first: plots of <= 16 384 points, more candidates than this
 
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __restrict__ src, int B, int N,
                                                               const float* __restrict__ cpos, int M, float r, float r2,
@@ -1956,7 +1961,12 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
                 }
             }
         };
-        if (T <= 64) turn(std::integral_constant<int, 1>{}, 0);
+        // Small plots with many candidates (the parcel loop: 10 000 points, r = sqrt 2: ~500 candidates and ~150 hits per centroid)
+        // go to the bitmap at once: it is N / 32 words (5 trips of the wave to clear, 5 to read) whatever the count, while
+        // rank-sorting h hits is h^2 / 64 steps -- 1.3 ms of the 5.5 ms a launch of 256 plots takes went into those sorts --, and
+        // deciding it before the first walk saves the second one.  Same lists: ascending original index either way.
+        if (nwords <= GQ_BM_WORDS && T > GQ_BM_CAND) dense = true;
+        else if (T <= 64) turn(std::integral_constant<int, 1>{}, 0);
         else if (T <= 128) turn(std::integral_constant<int, 2>{}, 0);
         else
             for (int t0 = 0; t0 < T && !dense; t0 += 64 * GQ_INFLIGHT) turn(std::integral_constant<int, GQ_INFLIGHT>{}, t0);
@@ -2445,11 +2455,11 @@ __global__ __launch_bounds__(1024) void nn_target_sort_kernel(const float* __res
 
 // nn_target_sort_kernel with U loads per coordinate in flight (the loop form spends a trip of dependent loads per point and
 // pass: 54 us at T = 32 768); same keys, same tables
-template <int U>
-__global__ __launch_bounds__(1024) void nn_target_sort_chunk_kernel(const float* __restrict__ dst, int T, const int* __restrict__ hdr,
+template <int U, int NT>
+__global__ __launch_bounds__(NT) void nn_target_sort_chunk_kernel(const float* __restrict__ dst, int T, const int* __restrict__ hdr,
                                                                     int* __restrict__ order, float4* __restrict__ sorted) {
     __shared__ int s_hist[NN_GMAX * NN_GMAX + 1];
-    __shared__ int s_wsum[16];
+    __shared__ int s_wsum[NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* dx = dst + (size_t)b * 3 * T;
     const float* dy = dx + T;
@@ -2465,23 +2475,29 @@ __global__ __launch_bounds__(1024) void nn_target_sort_chunk_kernel(const float*
         cy = (vy < 0.f || cy < 0) ? 0 : (cy > G - 1 ? G - 1 : cy);
         return cy * G + ((cy & 1) ? G - 1 - cx : cx);
     };
-    for (int i = tid; i <= G * G; i += 1024) s_hist[i] = 0;
+    for (int i = tid; i <= G * G; i += NT) s_hist[i] = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < T; i0 += 1024 * U) {
+    for (int i0 = 0; i0 < T; i0 += NT * U) {
         float vx[U], vy[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 1024 + tid, ii = i < T ? i : T - 1;
+            const int i = i0 + u * NT + tid, ii = i < T ? i : T - 1;
             vx[u] = dx[ii]; vy[u] = dy[ii];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (i0 + u * 1024 + tid < T) atomicAdd(&s_hist[key_of(vx[u], vy[u])], 1);
+            if (i0 + u * NT + tid < T) atomicAdd(&s_hist[key_of(vx[u], vy[u])], 1);
     }
     __syncthreads();
-    {   // exclusive scan over the <= 1024 cells: one cell per thread, wave scan, 16 wave totals
-        const int v = tid < G * G ? s_hist[tid] : 0;
-        int incl = v;
+    {   // exclusive scan over the <= 1024 cells: CPT consecutive cells per thread, wave scan, NT / 64 wave totals
+        constexpr int CPT = (NN_GMAX * NN_GMAX + NT - 1) / NT;
+        int v[CPT], sum = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            v[c] = tid * CPT + c < G * G ? s_hist[tid * CPT + c] : 0;
+            sum += v[c];
+        }
+        int incl = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o);
@@ -2489,24 +2505,28 @@ __global__ __launch_bounds__(1024) void nn_target_sort_chunk_kernel(const float*
         }
         if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
-        int run = incl - v;
+        int run = incl - sum;
         for (int k = 0; k < wave; ++k) run += s_wsum[k];
         __syncthreads();
-        if (tid < G * G) s_hist[tid] = run;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (tid * CPT + c < G * G) s_hist[tid * CPT + c] = run;
+            run += v[c];
+        }
     }
     __syncthreads();
     int* ob = order + (size_t)b * T;
     float4* sb = sorted + (size_t)b * T;
-    for (int i0 = 0; i0 < T; i0 += 1024 * U) {
+    for (int i0 = 0; i0 < T; i0 += NT * U) {
         float vx[U], vy[U], vz[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 1024 + tid, ii = i < T ? i : T - 1;
+            const int i = i0 + u * NT + tid, ii = i < T ? i : T - 1;
             vx[u] = dx[ii]; vy[u] = dy[ii]; vz[u] = dz[ii];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 1024 + tid;
+            const int i = i0 + u * NT + tid;
             if (i < T) {
                 const int p = atomicAdd(&s_hist[key_of(vx[u], vy[u])], 1);
                 ob[p] = i;
@@ -2528,10 +2548,12 @@ extern "C" int sn2_three_nn_xy(const float* src_soa, int B, int S, const float* 
     int* hdr = reinterpret_cast<int*>(sorted + (size_t)B * T);
     int* order = hdr + (size_t)B * NN_HDR;
     hipLaunchKernelGGL(nn_grid_build_kernel, dim3(B), dim3(256), 0, st, src_soa, S, G, tbl, hdr);
-    if (T <= 8 * 1024)
-        hipLaunchKernelGGL(nn_target_sort_chunk_kernel<8>, dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
+    if (sn2_small_sort_wg(B) && T <= 16 * 1024)        // many plots: 256 threads per plot (common.h)
+        hipLaunchKernelGGL((nn_target_sort_chunk_kernel<16, 256>), dim3(B), dim3(256), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
+    else if (T <= 8 * 1024)
+        hipLaunchKernelGGL((nn_target_sort_chunk_kernel<8, 1024>), dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
     else
-        hipLaunchKernelGGL(nn_target_sort_chunk_kernel<16>, dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
+        hipLaunchKernelGGL((nn_target_sort_chunk_kernel<16, 1024>), dim3(B), dim3(1024), 0, st, dst_soa, T, (const int*)hdr, order, sorted);
     const size_t lds = (size_t)S * 16 + (size_t)(G * G + 1) * 4;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&three_nn_grid_kernel),

@@ -100,10 +100,12 @@ class PinnedRing:
         self.events = [None] * slots
         self.k = 0
 
-    def upload(self, t: torch.Tensor, stream=None, dtype=None) -> torch.Tensor:
-        """CPU tensor -> new device tensor of `dtype` (default: its own) with the same shape, copied asynchronously on
-        `stream` (default: torch's current stream).  The result is safe to use on that stream (record_stream / events for
-        others are the caller's business)."""
+    def upload(self, t: torch.Tensor, stream=None, dtype=None, out=None) -> torch.Tensor:
+        """CPU tensor -> device tensor of `dtype` (default: its own) with the same shape, copied asynchronously on `stream`
+        (default: torch's current stream).  The result is safe to use on that stream; events for others are the caller's
+        business.  out: the device tensor to fill -- allocate it on the stream that will CONSUME it (a 21 MB block allocated on
+        a side stream and handed to the main stream with record_stream kept the caching allocator from reusing it: a fresh
+        hipMalloc per step, 80 ms instead of 5), and make `stream` wait for whatever last used the block."""
         dtype = dtype or t.dtype
         src = t.detach()
         if src.dtype != dtype:
@@ -120,7 +122,10 @@ class PinnedRing:
         stage.copy_(src)                                      # host memcpy into pinned memory
         st = torch.cuda.current_stream(self.dev) if stream is None else stream
         with torch.cuda.stream(st):
-            out = torch.empty(src.shape, dtype=dtype, device=self.dev)
+            if out is None:
+                out = torch.empty(src.shape, dtype=dtype, device=self.dev)
+            elif out.shape != src.shape or out.dtype != dtype or not out.is_contiguous():
+                raise ValueError("PinnedRing.upload: `out` does not match the source")
             out.copy_(stage, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(st)
@@ -589,19 +594,20 @@ SOURCE_SIDE = True     # False: never hand out src_ws, i.e. every row rebuilds i
 
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
             dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False, interp_index=None,
-            bn_sums_done=None, row_perm=None) -> FP:
+            bn_sums_done=None, row_perm=None, force_src_ws=False) -> FP:
     """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view.
     h of dtype bfloat16 (then dy and du_scratch too): the per-point layer stores its three activation buffers in bfloat16
     (include/strata_hip.h: sn2_fp.act_bf16; BASELINE config 5) -- only the source-side form of a layer of more than
     64 * SN2_STAT_SLOTS rows has those kernels."""
     R = B * R_per_plot
     hs = (block.cout + 3) // 4 * 4
-    AT = BF16 if h.dtype == BF16 else F32         # the storage type of h / dy / du_scratch
+    AT = BF16 if (h is not None and h.dtype == BF16) else F32         # the storage type of h / dy / du_scratch
     n_src_rows = R if knn is None else B * S_per_plot
     src_stride = _chk_rows(src, F32, n_src_rows, ca, "src")
     if src.shape[1] < (ca + 3) // 4 * 4 and src_stride < (ca + 3) // 4 * 4:
         raise ValueError("fp: src rows must be padded to a multiple of 4 floats")
-    _chk(h, AT, (R, hs), "h")
+    if h is not None or not force_src_ws:
+        _chk(h, AT, (R, hs), "h")
     d = FP()
     d.B, d.R_per_plot, d.S_per_plot, d.ca, d.cb = B, R_per_plot, S_per_plot, ca, cb
     d.src, d.src_stride = _ptr(src), src_stride
@@ -641,7 +647,7 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
     d.bn_sums_done = _ptr(bn_sums_done)
     # source-side workspace of the per-point layer (include/strata_hip.h: src_ws); scratch, so one per descriptor
     d._src_ws = None
-    if SOURCE_SIDE and knn is not None and 0 < cb <= 16 and cb % 4 == 0 and R > 64 * _lib.STAT_SLOTS:
+    if SOURCE_SIDE and knn is not None and 0 < cb <= 16 and cb % 4 == 0 and (R > 64 * _lib.STAT_SLOTS or force_src_ws):
         d._src_ws = torch.empty(B * interp_chunks(R_per_plot, S_per_plot) * hs, dtype=F32, device=src.device)
     d.src_ws = _ptr(d._src_ws)
     d.row_perm = None
@@ -714,10 +720,16 @@ def dropout_mask_words(keep: torch.Tensor) -> torch.Tensor:
 
 
 def head_desc(f, fa, fc, lin1, lin2, coverages=None, proba=None, dcov=None, dproba=None, dy=None, grads=None,
-              grad_images=(1, 0), drop_mask=None, drop_p: float = 0.0) -> Head:
-    R = f.shape[0]
-    AT = BF16 if f.dtype == BF16 else F32         # bfloat16 rows of f (and dy): sn2_head.act_bf16
-    _chk(f, AT, (R, 36), "f")
+              grad_images=(1, 0), drop_mask=None, drop_p: float = 0.0, rows: Optional[int] = None) -> Head:
+    """f (R,36): the rows the head reads -- or None with `rows` = R for `fp_head_eval`, whose rows never reach memory."""
+    if f is None:
+        if rows is None or coverages is None:
+            raise ValueError("head_desc: without f the row count and the outputs must be given")
+        R, AT = int(rows), F32
+    else:
+        R = f.shape[0]
+        AT = BF16 if f.dtype == BF16 else F32         # bfloat16 rows of f (and dy): sn2_head.act_bf16
+        _chk(f, AT, (R, 36), "f")
     _chk(fa, F32, (34,), "fa")
     _chk(fc, F32, (34,), "fc")
     _chk(lin1.weight, F32, (16, 34), "lin1.weight")
@@ -780,6 +792,11 @@ def grad_reduce(arena, n_flat: int, images):
     if arena.numel() < replicas * stride:
         raise ValueError("grad_reduce: arena smaller than its images")
     _call("sn2_grad_reduce", _ptr(arena), n_flat, replicas, stride, _stream())
+
+
+def fp_head_eval(d: FP, hd: Head):
+    """include/strata_hip.h: sn2_fp_head_eval -- EVAL: the per-point layer and the head in one pass, no (B*N,36) buffer between."""
+    _call("sn2_fp_head_eval", d, hd, _stream())
 
 
 def head_forward(d: Head):

@@ -164,6 +164,7 @@ class PointNet2(nn.Module):
     # the level-1 FPS kernel when its pass shares the chip with feature kernels (sn2_fps_waves: 8 = one workgroup of 8 waves per plot)
     fps_waves_shared = int(os.environ.get("SN2_FPS_WAVES_SHARED", "8"))
     geometry_fork = True       # `_geometry`: the three independent chains behind the level-1 FPS on three streams
+    fuse_eval_head = os.environ.get("SN2_FUSE_EVAL_HEAD", "1") == "1"     # eval: FP1 + head in one kernel (sn2_fp_head_eval)
     # additive: a geometry pass that is handed the batch's `cloud` also does the two INPUT-only pieces of the feature pass --
     # the level-0 rows (`sn2_pack_rows`: 12 us of the step's critical path at C2) and, when `p2_diam_pix` is set (to
     # args.diam_pix), the pixel ids of `project_to_plotwise_coverages` (project_to_2d.py:16-22: a function of x, y only; 10 us) --
@@ -224,14 +225,19 @@ class PointNet2(nn.Module):
         """`forward` for CPU-resident inputs: same kernels, same results; only the order of uploads and launches differs."""
         ring = ops.pinned_ring(dev)
         cur = torch.cuda.current_stream(dev)
+        # the device copy of `cloud` is allocated HERE, on the stream that consumes it, before anything of this forward is
+        # launched: whatever used the block before lies in front of `start` on this stream
+        cloud_d = torch.empty(cloud.shape, dtype=F32, device=dev)
+        start = torch.cuda.Event()
+        start.record(cur)
         xyz_d, fs = self._stage_positions(cloud_data, dev, ring=ring)
         g = self._geometry(xyz_d, fs, defer_join=True, inverted=self.training)       # launched: the device is busy from here on
         up = ops.shared_stream(dev, "upload")
-        cloud_d = ring.upload(cloud, stream=up, dtype=F32)                             # host memcpy + DMA beside the geometry pass
+        up.wait_event(start)                                                          # not for the geometry pass: only for the block's past
+        ring.upload(cloud, stream=up, dtype=F32, out=cloud_d)                          # host memcpy + DMA beside the geometry pass
         ev = torch.cuda.Event()
         ev.record(up)
         cur.wait_event(ev)
-        cloud_d.record_stream(cur)
         self._last_cloud_dev = (cloud, cloud_d)
         from .project_to_2d import remember_upload
         remember_upload(cloud, cloud_d)              # `project_to_plotwise_coverages(pred, clouds, args)` as the reference calls it
@@ -580,14 +586,21 @@ class PointNet2(nn.Module):
         ops.fp_forward(self._fp3_desc(s), training)
         s.h2 = torch.empty(B * M1, 36, dtype=F32, device=dev)
         ops.fp_forward(self._fp2_desc(s), training)
-        s.h1 = torch.empty(B * N, 36, dtype=self._act_dtype(B * N), device=dev)
         if join is not None:
             cur_stream.wait_stream(join[1])      # chain c: the per-point 3-NN table and its inverted index
-        ops.fp_forward(self._fp1_desc(s), training)
-        # ---- head                                                                  (:141-151)
         cov = torch.empty(B * N, 4, dtype=F32, device=dev)
         proba = torch.empty(B * N, 4, dtype=F32, device=dev)
         s.drop_keep = drop_keep
+        if not training and self.fuse_eval_head and self._act_dtype(B * N) == F32 and ops.SOURCE_SIDE:
+            # EVAL: FP1 and the head (:139-151) in one pass, the (B*N,36) rows of h1 never reach memory (nothing is kept for a backward)
+            s.h1 = None
+            d1 = ops.fp_desc(s.b_fp1, B, N, M1, 34, 8, s.h2, None, src_affine=(s.b_fp2.a, s.b_fp2.c), knn=s.knn1,
+                             skip=s.rows0[:, 0:8], force_src_ws=True)
+            ops.fp_head_eval(d1, ops.head_desc(None, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, rows=B * N))
+            return cov, proba, s
+        s.h1 = torch.empty(B * N, 36, dtype=self._act_dtype(B * N), device=dev)
+        ops.fp_forward(self._fp1_desc(s), training)
+        # ---- head                                                                  (:141-151)
         ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, drop_mask=drop_keep,
                                        drop_p=self.drop))
         return cov, proba, s

@@ -213,7 +213,7 @@ def test_three_nn_matches_oracle(B, S, T, k):
         assert torch.all(w[:, kk:] == 0) and torch.equal(idx[:, kk:], idx[:, :1].expand(-1, 3 - kk))
 
 
-@pytest.mark.parametrize("B,S,T,k", [(2, 1024, 32768, 3), (4, 256, 4096, 3), (2, 2500, 10000, 3), (4, 128, 2051, 2),
+@pytest.mark.parametrize("B,S,T,k", [(2, 1024, 32768, 3), (4, 256, 4096, 3), (2, 2500, 10000, 3), (4, 128, 2051, 2), (40, 625, 2500, 3),
                                      (2, 625, 2500, 1)])
 def test_grid_three_nn_equals_full_scan(B, S, T, k):
     """The grid walk returns the full scan's table bit for bit: same indices (lowest index on ties), same weights.
@@ -237,7 +237,10 @@ def test_grid_three_nn_equals_full_scan(B, S, T, k):
 
 
 @pytest.mark.parametrize("B,N,M,r,cap", [(2, 32768, 1024, 1.0, 2000), (2, 4096, 512, 2 ** 0.5, 2000), (1, 8192, 64, 4.0, 300),
-                                         (2, 5000, 100, 2.0, 2000)])
+                                         (2, 5000, 100, 2.0, 2000),
+                                         # the parcel loop's shape (reference defaults): ~500 candidates and ~150 hits per centroid
+                                         # -> the bitmap-first path; with a cap that bites; 40 plots -> the 256-thread sorts
+                                         (3, 10000, 2500, 2 ** 0.5, 2000), (2, 10000, 300, 2 ** 0.5, 64), (40, 4100, 128, 2.0, 2000)])
 def test_grid_ball_query_equals_full_scan_and_oracle(B, N, M, r, cap):
     """The cell-list ball query (sources sorted by FPS) returns exactly the lists of the full scan: same members, ascending
     source index, same cap behaviour (the r = 4 m case overflows the in-LDS list and takes the fallback)."""
@@ -251,7 +254,7 @@ def test_grid_ball_query_equals_full_scan_and_oracle(B, N, M, r, cap):
     assert torch.equal(cnt_g, cnt_f) and int(tot_g) == int(tot_f)
     mask = torch.arange(nbr_f.shape[1], device=DEV).unsqueeze(0) < cnt_f.unsqueeze(1)
     assert torch.equal(nbr_g[mask], nbr_f[mask])
-    if N <= 8192:
+    if N <= 8192 or (B * M <= 7500 and B <= 3):
         row, col = _oracle_lists(xyz, cs.cpu(), r, cap)
         assert torch.equal(nbr_g.cpu()[mask.cpu()].long(), col)
 
@@ -302,7 +305,7 @@ def test_fps_workspace_is_only_handed_out_when_filled():
         assert torch.equal(idx.cpu().long(), ref)
 
 
-@pytest.mark.parametrize("B,M", [(3, 1024), (2, 2500), (4, 256), (1, 10000), (2, 77)])
+@pytest.mark.parametrize("B,M", [(3, 1024), (2, 2500), (4, 256), (1, 10000), (2, 77), (40, 700)])      # 40 plots: 256 threads per plot
 def test_sa_work_items_order(B, M):
     """sn2_sa_order (the work items of the set-abstraction passes, ranked per plot by neighbour count descending, index
     ascending -- a bitonic sort in LDS) against the rule evaluated on the host (include/strata_hip.h): SOLO centroids (more

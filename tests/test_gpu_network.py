@@ -422,6 +422,39 @@ def test_source_side_form_with_many_tiny_plots():
     assert worst <= 2e-3
 
 
+@pytest.mark.parametrize("B,N", [(3, 24001), (2, 4096), (5, 10000)])
+def test_eval_fused_per_point_layer_and_head(B, N):
+    """Eval mode runs FP1 and the head as ONE kernel (sn2_fp_head_eval: the rows of h1 stay in LDS).  Against the two separate
+    kernels: the same bits where those take the same (source-side) form of FP1 -- more than 65 536 rows --, and equal to
+    rounding (2e-6) below, where the separate path runs FP1 row by row on the matrix cores; the oracle pins both (1e-4).
+    N = 24001 and 10000: a last turn of fewer than 63 rows, plots that are no multiple of 7 rows."""
+    args = make_args(subsample_size=N, ratio1=0.03, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=11)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.long)
+    sd = network.init_state_dict(7)
+    m = _model(args, sd).train()
+    with torch.no_grad():
+        m(d)                                            # running statistics that are not (0, 1)
+    m.eval()
+    sd_now = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    out = {}
+    for fused in (True, False):
+        m.fuse_eval_head = fused
+        with torch.no_grad():
+            cov, proba = m(d)
+        torch.cuda.synchronize()
+        out[fused] = (cov.clone(), proba.clone())
+    m.fuse_eval_head = True
+    if B * N > 65536:
+        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    else:
+        assert float((out[True][0] - out[False][0]).abs().max()) < 2e-6 and float((out[True][1] - out[False][1]).abs().max()) < 2e-6
+    with torch.no_grad():
+        cov_r, proba_r, _ = network.forward(sd_now, d["cloud"], d["xyz"], args, training=False, use_kdtree=True)
+    np.testing.assert_allclose(out[True][0].cpu().numpy(), cov_r.numpy(), atol=TOL, rtol=0)
+    np.testing.assert_allclose(out[True][1].cpu().numpy(), proba_r.numpy(), atol=TOL, rtol=0)
+
+
 def test_last_G_tensor_holds_the_plot_embeddings():
     """`args.log_embeddings` (model/point_net2.py:134-135; read by learning/test.py:105-107): after a forward
     `model.last_G_tensor` is the (B,64) output of the global set-abstraction level -- against the oracle's x3."""
