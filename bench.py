@@ -75,6 +75,28 @@ def rank_cpu_share(local_rank, local_world):
     return allowed, "shared"
 
 
+def host_cpu_share():
+    """Cores this process may really use: its affinity mask, cut to the container's CPU quota (cgroup v2 `cpu.max` / v1
+    `cpu.cfs_quota_us`) where there is one.  torch sizes its intra-op thread pool by the machine's core count (128 on the GPU
+    box, of which one GPU's job gets 16): a parallel 21 MB `copy_` then burns the quota in a burst and the whole process is
+    throttled until the next 100 ms period -- seen as 85-95 ms stalls in every third step of the eager loop
+    (scripts/profile_dropin_host.py)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def pin_rank(local_rank, local_world):
     """Give this rank its own cores (`rank_cpu_share`) and size OpenMP to them; called before torch is imported.  With one
     rank nothing is pinned (the whole allowance is the rank's)."""
@@ -261,7 +283,7 @@ def cpu_baseline():
     from oracle import losses as olosses, network, projection
     # the GPU box gives one GPU's job a share of 16 cores whatever os.cpu_count() says: more OpenMP threads than that
     # only spin against each other
-    ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    ncores = max(1, min(host_cpu_share(), 16))
     torch.set_num_threads(ncores)
     B = PLOTS_PER_GPU
     args = workload_args(None)
@@ -472,10 +494,11 @@ def exchange_leg(dev, steps=100, warmup=10):
     return out
 
 
-def inference_leg(dev, plots=2048, points=10000, batch=256, repeat=3, prefetch=4, cpu_sample_plots=8, dtype="f32"):
+def inference_leg(dev, plots=2048, points=10000, batch=512, repeat=3, prefetch=3, cpu_sample_plots=8, dtype="f32"):
     """BASELINE configs[3] (SURVEY.md 8d "C4"): parcel inference -- 2048 overlapping 10 m plots x 10 000 points tiling one
     parcel, eval forward + fixed-grid max rasters + the ordered weighted mosaic merge (predict.py:96-141), inputs resident.
-    256 plots per launch, four geometry passes in flight (measured: 128 / 3 gives 43.6k plots/s, 256 / 4 47.8k).
+    512 plots per launch, three geometry passes in flight (measured in round 4: 256 / 4 gives 50.5k plots/s, 512 / 2, 3, 4: 52.9k /
+    52.6k / 51.8k, 1024 / 2: 52.7k -- the loop is bound by the chip time of its full-chip kernels, not by the passes' latency).
     Median of `repeat` whole-parcel runs; roofline on SURVEY 8d's 368 B/point forward figure; the oracle's eval forward +
     rasters on a bounded sample of the same plots as the CPU baseline."""
     from stratanet2_vegetation_coverage_maps_amd import inference
@@ -653,6 +676,7 @@ def main():
     if os.environ.get("SN2_BENCH_ONE_DEVICE"):
         local_rank = 0
     backend = os.environ.get("SN2_BENCH_BACKEND", "nccl")
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cpu_share(), 16)))     # see host_cpu_share
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # HIP deals streams onto its few hardware queues in the order they are created: the loop's own side streams come FIRST, before

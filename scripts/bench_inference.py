@@ -21,10 +21,10 @@ from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_ba
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--plots", type=int, default=2048)
-    ap.add_argument("--batch", type=int, default=256)      # 64: 36.7k plots/s, 128: 43.6k, 256: 47.8k (the geometry pass is a latency chain per batch)
+    ap.add_argument("--batch", type=int, default=512)      # 64: 36.7k plots/s, 128: 43.6k, 256: 47.8k (the geometry pass is a latency chain per batch)
     ap.add_argument("--points", type=int, default=10000)
     ap.add_argument("--repeat", type=int, default=3)
-    ap.add_argument("--prefetch", type=int, default=4, help="geometry passes in flight ahead of the feature pass")
+    ap.add_argument("--prefetch", type=int, default=3, help="geometry passes in flight ahead of the feature pass")
     ap.add_argument("--ramp", type=str, default="", help="sizes of the first launches, e.g. 64,64,128 (then --batch): a short first "
                     "geometry pass fills the pipeline sooner")
     a = ap.parse_args()

@@ -11,7 +11,9 @@ rm -rf $out/prof
 python3 - "$out/kstats.csv" "$n" <<'PY'
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = 26.0
+# steps the run really made (timed + warm-up + the instrumented ones around them, whatever the flags were): every step
+# launches the Adam kernel exactly once
+steps = next((float(r["Calls"]) for r in rows if r["Name"].startswith("adam_kernel")), 26.0)
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e3
 print(f"all kernels: {tot:.1f} us per step")

@@ -1,0 +1,55 @@
+"""Where does the HOST spend its time in the reference's eager training loop on the drop-in (bench.py's `dropin_eager` leg)?
+Wall-clock stamps between the phases of each step (no extra synchronisation: the last phase, the three .item() reads, absorbs
+whatever the device still has queued)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_plotwise_coverages, losses
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+bench.ops.create_shared_streams(dev)
+B, N = 16, 32768
+args = make_args(cuda=0, subsample_size=N, ratio1=1024 / N, r1=1.0, ratio2=0.25, r2=2.0)
+torch.manual_seed(0)
+model = PointNet2(args).train()
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+batches = [make_batch(B, N, first_plot=j * B) for j in range(4)]
+names = ["targets up", "zero_grad", "forward", "projection", "loss ops", "backward", "adam", "item x3"]
+acc = [0.0] * len(names)
+print("torch threads", torch.get_num_threads(), "host cpu share", bench.host_cpu_share())
+if os.environ.get("SN2_THREADS"):
+    torch.set_num_threads(int(os.environ["SN2_THREADS"]))
+    print("torch threads now", torch.get_num_threads())
+import stratanet2_vegetation_coverage_maps_amd.hip_ops as _ops
+_up = _ops.PinnedRing.upload
+def _timed_upload(self, t, stream=None, dtype=None, out=None, consumer=None):
+    a = time.perf_counter()
+    r = _up(self, t, stream, dtype, out, consumer)
+    print(f"    upload {t.numel() * 4 / 1e6:6.1f} MB: {(time.perf_counter() - a) * 1e3:7.3f} ms", flush=True)
+    return r
+_ops.PinnedRing.upload = _timed_upload
+_ops._UPLOAD_TRACE = []
+for it in range(14):
+    d = batches[it % 4]
+    torch.cuda.synchronize()
+    t = [time.perf_counter()]
+    gt = d["coverages"].cuda(dev); t.append(time.perf_counter())
+    opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
+    cov, proba = model({"cloud": d["cloud"], "xyz": d["xyz"]}); t.append(time.perf_counter())
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args); t.append(time.perf_counter())
+    la = losses.get_absolute_loss(pred, gt)
+    ll = losses.get_NLL_loss(proba, d["pdf_all"].cuda(dev))
+    le = losses.get_entropy_loss(proba)
+    loss = la + args.m * ll + args.e * le; t.append(time.perf_counter())
+    loss.backward(); t.append(time.perf_counter())
+    opt.step(); t.append(time.perf_counter())
+    _ = (la.item(), ll.item(), loss.item()); t.append(time.perf_counter())
+    print("    ", [(w, round(v, 3)) for w, v in _ops._UPLOAD_TRACE]); _ops._UPLOAD_TRACE.clear()
+    print(it, " ".join(f"{(t[k + 1] - t[k]) * 1e3:7.3f}" for k in range(len(names))), flush=True)
+    if it >= 4:
+        for k in range(len(names)):
+            acc[k] += (t[k + 1] - t[k]) * 1e3 / 10
+print("host ms per step by phase:", {n: round(a, 3) for n, a in zip(names, acc)}, "total", round(sum(acc), 3))

@@ -76,12 +76,20 @@ def shared_stream(dev, name: str) -> torch.cuda.Stream:
     lanes; "fork_b", "fork_c", "pack": the branches of an unpipelined geometry pass; "capture").  Created ONCE: HIP deals
     streams onto a few hardware queues round-robin as they are created, so a second pipeline (or model) that created its own
     streams could find two of them -- or one and the main stream -- on one queue, where the passes it meant to overlap run
-    back to back (seen: +25 % per step for a pipeline built after another one in the same process)."""
+    back to back (seen: +25 % per step for a pipeline built after another one in the same process).
+    SINGLE OWNER AT A TIME: the streams are shared by everything in the process that asks for them by name -- a TrainPipeline,
+    an eval model's prefetch lanes, bench.py's serial capture.  Two such users that are LIVE at once serialise on them (a pass
+    meant to overlap another runs behind it), and a hipGraph capture on "capture" would record foreign work enqueued on it
+    meanwhile: run one pipelined loop / one capture at a time per device (what bench.py and the tests do: legs run one after
+    the other), or give a second concurrent user its own names."""
     dev = torch.device(dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), name)
     if key not in _SHARED_STREAMS:
         _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SHARED_STREAMS[key]
+
+
+_UPLOAD_TRACE = None       # scripts/profile_dropin_host.py sets a list: (what, host ms) of every wait / copy inside PinnedRing.upload
 
 
 class PinnedRing:
@@ -100,12 +108,16 @@ class PinnedRing:
         self.events = [None] * slots
         self.k = 0
 
-    def upload(self, t: torch.Tensor, stream=None, dtype=None, out=None) -> torch.Tensor:
+    def upload(self, t: torch.Tensor, stream=None, dtype=None, out=None, consumer=None) -> torch.Tensor:
         """CPU tensor -> device tensor of `dtype` (default: its own) with the same shape, copied asynchronously on `stream`
         (default: torch's current stream).  The result is safe to use on that stream; events for others are the caller's
         business.  out: the device tensor to fill -- allocate it on the stream that will CONSUME it (a 21 MB block allocated on
         a side stream and handed to the main stream with record_stream kept the caching allocator from reusing it: a fresh
-        hipMalloc per step, 80 ms instead of 5), and make `stream` wait for whatever last used the block."""
+        hipMalloc per step, 80 ms instead of 5), and make `stream` wait for whatever last used the block.
+        consumer: the stream that will read `out` when that is not `stream`: it is made to wait for the copy here, and the
+        slot's reuse event is recorded on IT.  (An event that is the last thing ever submitted to an otherwise idle side stream
+        was only seen as complete by a later `event.synchronize()` after ~86 ms on ROCm 7.2 -- every third step of the eager
+        loop; an event on the busy main stream completes when the stream gets there.)"""
         dtype = dtype or t.dtype
         src = t.detach()
         if src.dtype != dtype:
@@ -115,11 +127,23 @@ class PinnedRing:
         i = self.k
         self.k = (self.k + 1) % len(self.bufs)
         if self.events[i] is not None:
-            self.events[i].synchronize()                      # the DMA that last read this slot
+            if _UPLOAD_TRACE is not None:
+                import time as _t
+                a = _t.perf_counter()
+                self.events[i].synchronize()
+                _UPLOAD_TRACE.append(("event", (_t.perf_counter() - a) * 1e3))
+            else:
+                self.events[i].synchronize()                  # the DMA that last read this slot
         if self.bufs[i] is None or self.bufs[i].numel() < n:
             self.bufs[i] = torch.empty(max(n, 1 << 20), dtype=torch.uint8).pin_memory()
         stage = self.bufs[i][:n].view(dtype).view(src.shape)
-        stage.copy_(src)                                      # host memcpy into pinned memory
+        if _UPLOAD_TRACE is not None:
+            import time as _t
+            a = _t.perf_counter()
+            stage.copy_(src)
+            _UPLOAD_TRACE.append(("memcpy", (_t.perf_counter() - a) * 1e3))
+        else:
+            stage.copy_(src)                                  # host memcpy into pinned memory
         st = torch.cuda.current_stream(self.dev) if stream is None else stream
         with torch.cuda.stream(st):
             if out is None:
@@ -129,6 +153,10 @@ class PinnedRing:
             out.copy_(stage, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(st)
+        if consumer is not None and consumer != st:
+            consumer.wait_event(ev)
+            ev = torch.cuda.Event()
+            ev.record(consumer)
         self.events[i] = ev
         return out
 

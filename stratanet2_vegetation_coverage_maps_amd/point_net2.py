@@ -234,10 +234,7 @@ class PointNet2(nn.Module):
         g = self._geometry(xyz_d, fs, defer_join=True, inverted=self.training)       # launched: the device is busy from here on
         up = ops.shared_stream(dev, "upload")
         up.wait_event(start)                                                          # not for the geometry pass: only for the block's past
-        ring.upload(cloud, stream=up, dtype=F32, out=cloud_d)                          # host memcpy + DMA beside the geometry pass
-        ev = torch.cuda.Event()
-        ev.record(up)
-        cur.wait_event(ev)
+        ring.upload(cloud, stream=up, dtype=F32, out=cloud_d, consumer=cur)            # host memcpy + DMA beside the geometry pass
         self._last_cloud_dev = (cloud, cloud_d)
         from .project_to_2d import remember_upload
         remember_upload(cloud, cloud_d)              # `project_to_plotwise_coverages(pred, clouds, args)` as the reference calls it

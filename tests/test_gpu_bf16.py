@@ -75,6 +75,21 @@ def _check(name, args, sd, d, fs, tol_out, tol_grad, act_bf16=False):
           f"  bf16 vs fp32 mode: max |d coverages| = {moved:.2e}")
     assert not fails, "\n".join(fails)
     assert 1e-6 < moved < 1e-1                                      # (3) it is a different precision, and only that
+    # what this run measured, for the recorded ceilings of the callers: outputs, and the worst gradient error as a
+    # fraction of its bound (the stated tolerance, or -- storage rounding -- max(tolerance, 2 x the checker's own distance))
+    meas = {"cov": float((cov.detach().cpu().double() - ref["cov"].double()).abs().max()),
+            "proba": float((proba.detach().cpu().double() - ref["proba"].double()).abs().max())}
+    worst = 0.0
+    for k, p in m.named_parameters():
+        g = ref["grads"][k].double().numpy()
+        err = float(np.abs(p.grad.detach().cpu().double().numpy() - g).max() / np.abs(g).max())
+        bound = tol_grad
+        if act_bf16:
+            bound = max(tol_grad, 2.0 * float(np.abs(ref32["grads"][k].double().numpy() - g).max() / np.abs(g).max()))
+        worst = max(worst, err / bound)
+    meas["grad_over_bound"] = worst
+    print(f"  measured: {meas}")
+    return meas
 
 
 def test_bf16_variant_on_the_well_conditioned_case():
@@ -100,6 +115,12 @@ def test_bf16_variant_at_default_initialisation():
     _check(f"{B} x {N}, default init", args, network.init_state_dict(4), d, fs, tol_out=1e-3, tol_grad=2e-2)
 
 
+# measured by this test on MI355X (pointwise outputs vs the oracle with the same roundings; the worst gradient tensor's error as
+# a fraction of its bound)
+STORAGE_RECORDED = {(1, 131072): {"cov": 4.43e-4, "proba": 5.73e-4, "grad_over_bound": 0.213},
+                    (4, 32768): {"cov": 1.07e-3, "proba": 1.47e-3, "grad_over_bound": 0.241}}
+
+
 @pytest.mark.parametrize("B,N", [(1, 131072), (4, 32768)])
 def test_bf16_activation_storage_on_the_per_point_layer(B, N):
     """BASELINE config 5's plot size (one 131 072-point plot) and the metric's (32 768 points): more than 65 536 rows, so the
@@ -115,8 +136,14 @@ def test_bf16_activation_storage_on_the_per_point_layer(B, N):
     d = make_batch(B, N, first_plot=77)
     fs = torch.tensor([[123 % N] * B, [7] * B])
     d["fps_start"] = fs
-    _check(f"{B} x {N}, bfloat16 activation storage", args, network.init_state_dict(1), d, fs, tol_out=3e-3, tol_grad=2e-2,
-           act_bf16=True)
+    meas = _check(f"{B} x {N}, bfloat16 activation storage", args, network.init_state_dict(1), d, fs, tol_out=3e-3, tol_grad=2e-2,
+                  act_bf16=True)
+    # The stated tolerances above (3e-3; max(2e-2, 2 x checker)) were widened after a first failure in round 3 (1e-3 / 2e-2 flat):
+    # so each measured value is ALSO held to a recorded ceiling = 2 x what this test measured when the tolerance was set
+    # (round 3, gpurun_out/r3e/bf16.log; refreshed in round 4) -- a regression inside the stated tolerance still fails here.
+    rec = STORAGE_RECORDED[(B, N)]
+    for k in ("cov", "proba", "grad_over_bound"):
+        assert meas[k] <= 2.0 * rec[k], f"{k}: measured {meas[k]:.3e}, recorded {rec[k]:.3e} (ceiling 2 x)"
 
 
 def test_bf16_variant_of_the_3sa_architecture():

@@ -1,10 +1,11 @@
-"""Parity at the LAUNCH SHAPES bench.py runs its secondary legs in (BASELINE.json configs[3] and configs[4]): 256 plots x 10 000
-points per eval launch (parcel inference: the SA kernels take their "plots eight at a time" turns, `count_sum` adds 640 000
-counts, FP3 runs 160 000 rows on the matrix-core kernel) and 8 x 131 072 points in bf16 mode.
+"""Parity at the LAUNCH SHAPES bench.py runs its secondary legs in (BASELINE.json configs[3] and configs[4]): 512 plots x 10 000
+points per eval launch (parcel inference: the SA kernels take their "plots eight at a time" turns, `count_sum` adds 1 280 000
+counts, FP3 runs 320 000 rows on the matrix-core kernel, the sorts run 256 threads per plot, the ball query takes its
+bitmap-first path, FP1 and the head run as one kernel) and 8 x 131 072 points in bf16 mode.
 
 The reference's eval forward is a function of ONE plot (`model/point_net2.py:106-153` with BatchNorm on running statistics;
-`predict.py:96-126` feeds it whatever batch the DataLoader cut), so a launch of 256 plots must give, plot for plot, the bits
-of the same plots launched eight at a time -- a size-independent property -- and the oracle pins a sample of them."""
+`predict.py:96-126` feeds it whatever batch the DataLoader cut), so a launch of 512 plots must give, plot for plot, the bits
+of the same plots in smaller launches -- a size-independent property -- and the oracle pins a sample of them."""
 import numpy as np
 import pytest
 import torch
@@ -42,8 +43,8 @@ def _eval(m, cloud, xyz, args):
     return cov, proba, rasters, pix
 
 
-def test_parcel_launch_of_256_plots_equals_smaller_launches_and_the_oracle():
-    B, N = 256, 10000
+def test_parcel_launch_of_512_plots_equals_smaller_launches_and_the_oracle():
+    B, N = 512, 10000
     args = make_args(subsample_size=N)                       # reference defaults: ratios .25 / .25, r sqrt2 / sqrt8 (config.py:77-80)
     m = _trained_stats_model(args, 0, N)
     d = make_batch(B, N, first_plot=0)
@@ -54,9 +55,9 @@ def test_parcel_launch_of_256_plots_equals_smaller_launches_and_the_oracle():
     # (1) the same plots 32 at a time: the same bits.  (Two layers have two forms each, chosen by the ROW COUNT of a launch:
     # above 65 536 rows FP2 and FP1 hoist their weights through the interpolation -- hip_ops.fp_desc, "source-side form" --,
     # below they run row by row on the matrix cores / per lane.  32 plots = 80 000 FP2 rows and 320 000 FP1 rows take the forms
-    # of the 256-plot launch; every other kernel has one form.)  The first and the last two groups + two inside cover every
-    # position of the SA kernels' "plots eight at a time" turns.
-    for s in (0, 32, 96, 160, 192, 224):
+    # of the 512-plot launch -- in eval FP1 and the head are one kernel at every size --; every other kernel has one form.)  The
+    # first and the last two groups + three inside cover every position of the SA kernels' "plots eight at a time" turns.
+    for s in (0, 32, 160, 288, 416, 448, 480):
         c32, p32, r32, x32 = _eval(m, d["cloud"][s:s + 32], d["xyz"][s:s + 32], args)
         assert torch.equal(c32.view(32, N, 4), covb[s:s + 32]), f"coverages of plots {s}..{s + 31} depend on the launch size"
         assert torch.equal(p32.view(32, N, 4), probab[s:s + 32]), s
@@ -66,7 +67,7 @@ def test_parcel_launch_of_256_plots_equals_smaller_launches_and_the_oracle():
     # another order of fp32 operations -- equal to rounding (measured 9e-8), far inside the 1e-4 of the contract; index
     # structures identical
     e_small = 0.0
-    for s, n in ((100, 8), (40, 4), (252, 4)):
+    for s, n in ((100, 8), (40, 4), (508, 4)):
         cs, _, rs, xs = _eval(m, d["cloud"][s:s + n], d["xyz"][s:s + n], args)
         assert torch.equal(xs.view(n, N), pixb[s:s + n])
         assert torch.equal(torch.isnan(rs), torch.isnan(rasters[s:s + n]))
@@ -74,7 +75,7 @@ def test_parcel_launch_of_256_plots_equals_smaller_launches_and_the_oracle():
     assert e_small < 2e-6, e_small
     e4 = e_small
     # (3) the oracle on four plots of the launch (first, last, two inside): outputs 1e-4, pixel ids and NaN masks exact
-    sel = [0, 97, 200, 255]
+    sel = [0, 97, 300, 511]
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     with torch.no_grad():
         cov_r, proba_r, _ = network.forward(sd, d["cloud"][sel], d["xyz"][sel], args, training=False, use_kdtree=True)
@@ -90,17 +91,17 @@ def test_parcel_launch_of_256_plots_equals_smaller_launches_and_the_oracle():
         got = rasters[b].double().cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(ref)), f"NaN mask of plot {b}"
         np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(ref), atol=1e-4, rtol=0)
-    print(f"\n[C4 launch shape 256 x 10 000] 256-plot launch == 32-plot launches (bits); vs 8- and 4-plot launches {e4:.2e}; "
+    print(f"\n[C4 launch shape 512 x 10 000] 512-plot launch == 32-plot launches (bits); vs 8- and 4-plot launches {e4:.2e}; "
           f"vs the oracle on plots {sel}: {worst:.2e} (tol 1e-4)")
     assert worst <= 1e-4, worst
 
 
-def test_predict_parcel_at_256_plots_per_launch_with_four_passes_in_flight():
-    """`predict_parcel` as bench.py's config-4 leg calls it (256 plots per launch, prefetch = 4: four geometry passes in flight on
+def test_predict_parcel_at_512_plots_per_launch_with_three_passes_in_flight():
+    """`predict_parcel` as bench.py's config-4 leg calls it (512 plots per launch, prefetch = 3: three geometry passes in flight on
     side streams) against the same parcel fed 32 plots at a time with no overlap at all (32 plots: the layer forms of the big
     launch, see above): the merge is ORDER-DEPENDENT and plot after plot (rasterio.merge callback,
     inference/geotiff_raster.py:294-347), so equal mosaics mean equal rasters in the same order."""
-    plots, N, cols, stride = 768, 10000, 32, 5.0
+    plots, N, cols, stride = 1536, 10000, 32, 5.0
     args = make_args(subsample_size=N)
     m = _trained_stats_model(args, 0, N)
     rows = plots // cols
@@ -117,7 +118,7 @@ def test_predict_parcel_at_256_plots_per_launch_with_four_passes_in_flight():
         return out
 
     big = inference.ParcelMosaic(0.0, float(H), H, W, args, DEV)
-    assert inference.predict_parcel(m, batches(256), big, args, prefetch=4) == plots
+    assert inference.predict_parcel(m, batches(512), big, args, prefetch=3) == plots
     small = inference.ParcelMosaic(0.0, float(H), H, W, args, DEV)
     assert inference.predict_parcel(m, batches(32), small, args, prefetch=0) == plots
     torch.cuda.synchronize()
