@@ -968,6 +968,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+    if getattr(opt, "comm", None) is not None:
+        import gc
+        pipe = graph = None                    # the graphs that hold the captured collective go first
+        gc.collect()
+        torch.cuda.synchronize()
+        opt.comm.destroy()                     # before torch's own communicator goes (and never from a destructor at exit)
+        opt.comm = None
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -138,8 +138,11 @@ __device__ __forceinline__ bool sa_item(SaItem& it, const int* __restrict__ orde
 }
 
 // PASS 0: statistics of block 0 only (nl == 2);  PASS 1: full forward, statistics of the last block, extremum
-template <int CF, int NL, int C1, int C2, int PASS, bool BF16>
+// STATS = false (an EVAL pass: BatchNorm on its running statistics): no statistic sums -- a sixth of the vector instructions
+// of a step, which is what bounds the parcel loop's SA1 pass (64 M messages per launch)
+template <int CF, int NL, int C1, int C2, int PASS, bool BF16, bool STATS = true>
 __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
+    static_assert(STATS || PASS == 1, "pass 0 IS the statistics pass");
     constexpr int CIN = CF + 3, KB1 = CF / 4 + 1, TO1 = C1 / 16, TO2 = C2 / 16;
     constexpr int CL = NL == 2 ? C2 : C1, TOL = CL / 16, CS = PASS == 0 ? C1 : CL, TOS = CS / 16;
     static_assert(CF % 4 == 0 && C1 % 16 == 0 && C2 % 16 == 0, "tile shapes");
@@ -312,9 +315,11 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
                         const int e = e0 + it.le0 + it.eoff * t;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float h = val[t] ? DL[io][t][r] : 0.f;
-                            ssum[io][r] += h;
-                            ssq[io][r] = fmaf(h, h, ssq[io][r]);
+                            if constexpr (STATS) {
+                                const float h = val[t] ? DL[io][t][r] : 0.f;
+                                ssum[io][r] += h;
+                                ssq[io][r] = fmaf(h, h, ssq[io][r]);
+                            }
                             const float s = sgn[io][r] * DL[io][t][r];
                             if (val[t] && s > best[t][io][r]) {
                                 best[t][io][r] = s;
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
     }
 
     // ---- batch statistics: row sums (over the 16 message lanes), then workgroup slot
-    if (a.slots) {
+    if (STATS && a.slots) {
         // no float atomics here: their order varies from run to run, the BatchNorm statistics with it (1e-7), and now and
         // then a pre-activation next to zero changes sign -- one ReLU mask flip moved a weight gradient by 1 %
         const int wv = threadIdx.x >> 6;
@@ -865,6 +870,13 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
     const int occ = occ_env > 0 ? occ_env : (CF == 8 ? (PASS == 0 ? 4 : 3) : (CF == 16 ? 2 : 1));
     if (blocks > sn2_cu_count() * occ) blocks = sn2_cu_count() * occ;
     if (nblocks_out) *nblocks_out = blocks;
+    if constexpr (PASS == 1) {
+        if (!a.slots) {            // eval: the variant without the statistic sums
+            if (bf16) hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, true, false>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, false, false>), dim3(blocks), dim3(256), 0, st, a);
+            SN2_RETURN_LAUNCH();
+        }
+    }
     if (bf16) hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, true>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, false>), dim3(blocks), dim3(256), 0, st, a);
     SN2_RETURN_LAUNCH();
