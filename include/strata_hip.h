@@ -111,9 +111,7 @@ int sn2_debug_fps_spin_limit(unsigned sweeps);
  * fp32 value of r*r evaluated in double, as torch_cluster compares),
  * ascending j, at most `cap` of them: nbr[(b*M+i)*cap + 0..cnt-1], cnt[b*M+i]. *total = sum of cnt (overwritten).
  * fps_ws: the workspace a bucketed sn2_fps call over the SAME sources left behind (cell lists: ~200 candidates per
- * centroid instead of N), or NULL for the full scan; same result either way.  (With fps_ws the call uses the workspace's
- * exchange area -- only the multi-workgroup FPS kernel reads it, and every FPS pass clears it first -- as scratch for the
- * order it works the centroids in; the tables sn2_fps left there are not touched.) */
+ * centroid instead of N), or NULL for the full scan; same result either way. */
 int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, int M, float r2, int cap,
                    int *nbr, int *cnt, unsigned long long *total, const int *fps_ws, void *stream);
 

@@ -1853,78 +1853,24 @@ static_assert(GQ_DENSE <= GQ_LIST, "the list holds the sparse balls");
 #endif
 constexpr int GQ_BM_WORDS = 512, GQ_BM_CAND = SN2_GQ_BM_CAND;   // bitmap first: plots of <= 16 384 points, more candidates than this
 
-// The order the centroids are WORKED ON (round 4).  They come in FPS order -- every sample as far from the others as possible --,
-// so consecutive waves walked cells at opposite ends of the plot and every candidate point was fetched from L2 again by each
-// of the ~100 centroids whose ball it is near (PMC: 5.2 x the compulsory bytes at C2; 6 GB of L2 reads per parcel launch).
-// One workgroup per plot sorts its centroids by the Morton cell they lie in (a counting sort over the 4096 cells of the
-// sources' grid: the keys need no more resolution than the cells the walk reads); the query kernel then takes centroid
-// perm[k] in turn k, and the four waves of a workgroup -- and the workgroups next to them -- read the same cells while those
-// are in L1 / L2.  The lists do not change: each centroid's list is written to its own row as before.
-// perm lives in the plot's FPS exchange area (FPS_XCHG_WORDS words, free once FPS is done): M <= FPS_XCHG_WORDS.
-__global__ __launch_bounds__(256) void ball_query_order_kernel(const float* __restrict__ cpos, int M, const int* __restrict__ grid,
-                                                               int* __restrict__ perm_all) {
-    __shared__ int s_hist[ORDER_CELLS];
-    __shared__ int s_wsum[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int* gb = grid + (size_t)b * GRID_WORDS;
-    const float* gf = reinterpret_cast<const float*>(gb + ORDER_CELLS + 1);
-    const float lo0 = gf[0], lo1 = gf[1], lo2 = gf[2], sc0 = gf[3], sc1 = gf[4], sc2 = gf[5];
-    const float* cx = cpos + (size_t)b * 3 * M;
-    auto cell_of = [&](int k) -> unsigned {               // the sort's cell function (clamped: a centroid IS a source point)
-        int ix = (int)((cx[k] - lo0) * sc0), iy = (int)((cx[M + k] - lo1) * sc1), iz = (int)((cx[2 * M + k] - lo2) * sc2);
-        ix = ix < 0 ? 0 : (ix > ORDER_GX - 1 ? ORDER_GX - 1 : ix);
-        iy = iy < 0 ? 0 : (iy > ORDER_GX - 1 ? ORDER_GX - 1 : iy);
-        iz = iz < 0 ? 0 : (iz > ORDER_GZ - 1 ? ORDER_GZ - 1 : iz);
-        return morton_cell((unsigned)ix, (unsigned)iy, (unsigned)iz);
-    };
-    for (int i = tid; i < ORDER_CELLS; i += 256) s_hist[i] = 0;
-    __syncthreads();
-    for (int k = tid; k < M; k += 256) atomicAdd(&s_hist[cell_of(k)], 1);
-    __syncthreads();
-    constexpr int PER = ORDER_CELLS / 256;
-    int loc[PER], sum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        loc[k] = s_hist[tid * PER + k];
-        sum += loc[k];
-    }
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int run = incl - sum;
-    for (int k = 0; k < wave; ++k) run += s_wsum[k];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        s_hist[tid * PER + k] = run;
-        run += loc[k];
-    }
-    __syncthreads();
-    int* perm = perm_all + (size_t)b * FPS_XCHG_WORDS;
-    for (int k = tid; k < M; k += 256) perm[atomicAdd(&s_hist[cell_of(k)], 1)] = k;
-}
-
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __restrict__ src, int B, int N,
                                                               const float* __restrict__ cpos, int M, float r, float r2,
                                                               int cap, const int* __restrict__ order,
                                                               const float4* __restrict__ sorted, const int* __restrict__ grid,
                                                               int* __restrict__ nbr, int* __restrict__ cnt,
-                                                              unsigned long long* __restrict__ total,
-                                                              const int* __restrict__ perm) {
+                                                              unsigned long long* __restrict__ total) {
     __shared__ int s_list[4][GQ_LIST];
     extern __shared__ unsigned gq_bits[];              // [4][(N + 31) / 32]: one bit per source point, per wave (dense balls)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int turn = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
-    if (turn >= B * M) return;
+    const int ci = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
+    if (ci >= B * M) return;
     const int nwords = (N + 31) >> 5;
     unsigned* bits = gq_bits + (size_t)wib * nwords;
-    const int b = turn / M;
-    const int m = perm ? __builtin_amdgcn_readfirstlane(perm[(size_t)b * FPS_XCHG_WORDS + (turn - b * M)]) : turn - b * M;
-    const int ci = b * M + m;
+    // (Round 4 tried working the centroids in the order of their Morton cells instead of FPS order -- consecutive waves then
+    // walk the same cells while those are in L1 / L2 --: no gain at 16 x 32 768 (step 0.7661 against 0.7656 ms) and a small loss
+    // in the parcel loop (51.2 against 52.2 k plots/s): the kernel is bound by its instructions per candidate, not by where the
+    // candidates come from.)
+    const int b = ci / M, m = ci - b * M;
     const float cx = cpos[((size_t)b * 3 + 0) * M + m], cy = cpos[((size_t)b * 3 + 1) * M + m],
                 cz = cpos[((size_t)b * 3 + 2) * M + m];
     const int* gb = grid + (size_t)b * GRID_WORDS;
@@ -2155,16 +2101,8 @@ extern "C" int sn2_ball_query(const float* src_soa, int B, int N, const float* c
         const size_t lds = (size_t)4 * ((N + 31) / 32) * sizeof(unsigned);       // the dense-ball bitmaps: 64 KB at N = 131 072
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ball_query_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        // the centroids in the order of their cells (ball_query_order_kernel); the permutation goes into the FPS exchange area of
-        // the workspace, which is free between two FPS passes
-        int* perm = nullptr;
-        static const bool no_order = getenv("SN2_GQ_NO_ORDER") != nullptr;       // (diagnostic switch)
-        if (M <= FPS_XCHG_WORDS && M >= 64 && !no_order) {
-            perm = const_cast<int*>(grid) + (size_t)B * GRID_WORDS;
-            hipLaunchKernelGGL(ball_query_order_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cpos_soa, M, grid, perm);
-        }
         hipLaunchKernelGGL(ball_query_grid_kernel, dim3(sn2_cdiv((long)B * M, 4)), dim3(256), lds, (hipStream_t)stream, src_soa,
-                           B, N, cpos_soa, M, r, r2, cap, order, sorted, grid, nbr, cnt, total, (const int*)perm);
+                           B, N, cpos_soa, M, r, r2, cap, order, sorted, grid, nbr, cnt, total);
         if (total) hipLaunchKernelGGL(count_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)cnt, B * M, total);
         SN2_RETURN_LAUNCH();
     }
