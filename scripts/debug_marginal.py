@@ -14,6 +14,7 @@ B, N = int(os.environ.get("PLOTS", "16")), int(os.environ.get("POINTS", "32768")
 args = make_args(cuda=0, subsample_size=N, ratio1=1024 / N, r1=1.0, ratio2=0.25, r2=2.0)
 torch.manual_seed(0)
 model = PointNet2(args).train()
+model.p2_diam_pix = args.diam_pix          # as bench.py: the geometry passes also compute the projection's pixel ids
 flatten_parameters(model)
 opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3)
 dev = torch.device("cuda:0")
@@ -30,7 +31,7 @@ def fstep(inp, geo=None):
     opt.zero_grad()
     cd = {"cloud": inp["cloud"], "xyz": inp["xyz"], "fps_start": inp["fps_start"], "geometry": geo}
     cov, proba = model(cd)
-    pred = project_to_plotwise_coverages(cov, inp["cloud"], args)
+    pred = project_to_plotwise_coverages(cov, inp["cloud"], args, geometry=geo)
     loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
     loss.backward()
     return loss
@@ -58,9 +59,10 @@ print(f"all entry points: {base:.4f} ms/step ({pipe.group} batches per geometry 
 if os.environ.get("ONLY_BASE"):
     pipe.drain(); torch.cuda.synchronize(); sys.exit(0)
 real = {}
-groups = [("fps",), ("ball_query",), ("count_sum",), ("sa_order",), ("three_nn",), ("interp_index",),
+groups = [("fps",), ("ball_query",), ("count_sum",), ("sa_order",), ("three_nn",), ("interp_index",), ("pack_rows", "plot_pixels"),
           ("ball_query", "count_sum", "sa_order", "three_nn", "interp_index"),
-          ("fps", "ball_query", "count_sum", "sa_order", "three_nn", "interp_index")]
+          ("fps", "ball_query", "count_sum", "sa_order", "three_nn", "interp_index"),
+          ("fps", "ball_query", "count_sum", "sa_order", "three_nn", "interp_index", "pack_rows", "plot_pixels")]
 for gnames in groups:
     for name in gnames:
         real[name] = getattr(ops, name)

@@ -943,6 +943,9 @@ static int launch_fps_bucket(const float* pos, int B, int N, int M, const int* s
         const size_t lds = fps_spec_lds_bytes<SPW, NW, K>();
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_spec_kernel<SPW, NW, K>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // (Round 4 tried the FPS waves at the highest wave priority, `s_setprio 3`: beside the feature kernels a super-round takes
+        // three times as long as alone, and what the pass costs the step follows the time it is resident -- no effect, 0.7652
+        // against 0.762 ms per step; round 3 had tried the opposite, the feature kernels raised: none either.)
         hipLaunchKernelGGL((fps_spec_kernel<SPW, NW, K>), dim3(B), dim3(NW * 64), lds, st, pos, N, M, start, (const int*)order,
                            sorted, idx, cs, ca, gate, status);
         SN2_RETURN_LAUNCH();
