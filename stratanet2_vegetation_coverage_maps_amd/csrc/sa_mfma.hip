@@ -138,8 +138,9 @@ __device__ __forceinline__ bool sa_item(SaItem& it, const int* __restrict__ orde
 }
 
 // PASS 0: statistics of block 0 only (nl == 2);  PASS 1: full forward, statistics of the last block, extremum
-// STATS = false (an EVAL pass: BatchNorm on its running statistics): no statistic sums -- a sixth of the vector instructions
-// of a step, which is what bounds the parcel loop's SA1 pass (64 M messages per launch)
+// STATS = false (an EVAL pass: BatchNorm on its running statistics, nothing kept for a backward): no statistic sums and no
+// arg-max slots (`arg` only says whether the centroid has neighbours) -- a quarter of the vector instructions of a step, which is what bounds the parcel
+// loop's SA1 pass (64 M messages per launch)
 template <int CF, int NL, int C1, int C2, int PASS, bool BF16, bool STATS = true>
 __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
     static_assert(STATS || PASS == 1, "pass 0 IS the statistics pass");
@@ -321,9 +322,13 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
                                 ssq[io][r] = fmaf(h, h, ssq[io][r]);
                             }
                             const float s = sgn[io][r] * DL[io][t][r];
-                            if (val[t] && s > best[t][io][r]) {
-                                best[t][io][r] = s;
-                                barg[t][io][r] = e;
+                            if constexpr (STATS) {
+                                if (val[t] && s > best[t][io][r]) {
+                                    best[t][io][r] = s;
+                                    barg[t][io][r] = e;
+                                }
+                            } else {                     // eval: nobody routes a gradient, the slot of the extremum is not kept
+                                best[t][io][r] = fmaxf(best[t][io][r], val[t] ? s : -INFINITY);
                             }
                         }
                     }
@@ -337,10 +342,14 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
                     for (int io = 0; io < TOL; ++io)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const bool take = best[t][io][r] > best[0][io][r] ||
-                                              (best[t][io][r] == best[0][io][r] && barg[t][io][r] < barg[0][io][r]);
-                            best[0][io][r] = take ? best[t][io][r] : best[0][io][r];
-                            barg[0][io][r] = take ? barg[t][io][r] : barg[0][io][r];
+                            if constexpr (STATS) {
+                                const bool take = best[t][io][r] > best[0][io][r] ||
+                                                  (best[t][io][r] == best[0][io][r] && barg[t][io][r] < barg[0][io][r]);
+                                best[0][io][r] = take ? best[t][io][r] : best[0][io][r];
+                                barg[0][io][r] = take ? barg[t][io][r] : barg[0][io][r];
+                            } else {
+                                best[0][io][r] = fmaxf(best[0][io][r], best[t][io][r]);
+                            }
                         }
             }
             const int W = it.W;
@@ -355,9 +364,13 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float m = seg_max(best[t][io][r], W);
-                        const unsigned am = seg_min_u32(best[t][io][r] == m ? (unsigned)barg[t][io][r] : 0xFFFFFFFFu, W);
                         ev[r] = it.ln[t] > 0 ? sgn[io][r] * m : 0.f;
-                        av[r] = it.ln[t] > 0 ? (int)am : -1;
+                        if constexpr (STATS) {
+                            const unsigned am = seg_min_u32(best[t][io][r] == m ? (unsigned)barg[t][io][r] : 0xFFFFFFFFu, W);
+                            av[r] = it.ln[t] > 0 ? (int)am : -1;
+                        } else {
+                            av[r] = it.ln[t] > 0 ? 0 : -1;       // eval: only "has neighbours" (what sa_finalize_kernel asks)
+                        }
                     }
                     if (writer && it.ln[t] >= 0) {
                         const size_t o = (size_t)it.lc[t] * CL + 16 * io + 4 * q;
