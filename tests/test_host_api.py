@@ -114,3 +114,55 @@ def test_bench_starts_its_own_ranks():
     rc, out, err = _run_clean([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
                               {"SN2_BENCH_LAUNCH_CHECK": "fail"})
     assert rc == 3
+
+
+def test_bench_gives_a_timed_region_its_share_of_geometry():
+    """bench.py: the batches a geometry pass covers divide the timed step count (so the region launches exactly `steps` batches'
+    worth of FPS / ball query / 3-NN), and the phase puts the region's last pass G - 1 steps before its end; TrainPipeline
+    turns the phase into how far ahead the passes run.  (CPU: arithmetic only.)"""
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.pipe_group_for(200) == 8 and bench.pipe_group_for(20) == 5 and bench.pipe_group_for(100) == 5
+    assert bench.pipe_group_for(50) == 5 and bench.pipe_group_for(21) == 7 and bench.pipe_group_for(13) == 8   # a prime: no divisor
+    for warmup, steps in ((5, 20), (20, 200), (10, 100), (6, 50), (0, 8)):
+        G = bench.pipe_group_for(steps)
+        ph = bench.pipe_phase_for(G, warmup, steps)
+        assert 0 <= ph < G
+        # passes are issued at the end of the steps that complete batch numbers = ph (mod G): the last one inside the region
+        issued = [d for d in range(warmup + 1, warmup + steps + 1) if d % G == ph]
+        assert len(issued) == steps // G and warmup + steps - issued[-1] == G - 1
+    assert bench.host_cpu_share() >= 1
+
+
+def test_pipeline_phase_sets_how_far_ahead_the_passes_run():
+    from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
+    G, depth = 5, 3
+
+    class _Model:                                  # (no device work in the constructor beyond buffer allocation: stub it)
+        def alloc_geometry_pair(self, B, N, dev, group=2):
+            return object(), tuple(object() for _ in range(group))
+
+    slots = [{"xyz": torch.zeros(2, 3, 8), "fps_start": torch.zeros(2, 2, dtype=torch.int32)} for _ in range(G * depth + G)]
+    import stratanet2_vegetation_coverage_maps_amd.hip_ops as ops
+    real = ops.shared_stream
+    ops.shared_stream = lambda dev, name: None     # CPU: no streams
+    try:
+        ev = torch.cuda.Event
+        torch.cuda.Event = lambda *a, **k: None
+        try:
+            for phase in range(G):
+                p = TrainPipeline(_Model(), None, None, slots, depth=depth, group=G, phase=phase)
+                assert p.phase == phase and p.ahead == G * depth - phase
+                # the issue rule of TrainPipeline._run_ahead, replayed on the host
+                issued, at = 0, []
+                while issued + G <= 0 + p.ahead:
+                    issued += G
+                for done in range(1, 4 * G + 1):
+                    while issued + G <= done + p.ahead:
+                        issued += G
+                        at.append(done)
+                assert all(d % G == phase for d in at) and len(at) >= 3
+        finally:
+            torch.cuda.Event = ev
+    finally:
+        ops.shared_stream = real
