@@ -230,7 +230,7 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
 # entry point -> the kernel that dominates it (names as rocprofv3 prints them, see profiles/*_pmc_traffic.json)
 DOMINANT_KERNEL = {
     "sn2_fps:N=32768": "fps_cluster_kernel<8, 8, 8, true>", "sn2_ball_query:N=32768": "ball_query_grid_kernel",
-    "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>",
+    "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false, true>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>",
     "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34, false>",
     "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512, false>",
     "sn2_head_forward": "head_fwd_mfma_kernel<false>", "sn2_head_backward": "head_bwd_kernel<false>",

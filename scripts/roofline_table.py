@@ -47,11 +47,11 @@ sqm = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in sq.items()}
 rows0, cpos = 48 * R, 16 * M1 * B
 K = collections.OrderedDict()
 K["ball_query_grid_kernel"] = ("radius ball query, level 1", 16 * R + 12 * M1 * B + 4 * E1 + 4 * M1 * B, None, 0)
-K["sa_mfma_fwd_kernel<8, 2, 16, 16, 0, false>"] = ("SA1 statistics pass (gather + layer 1)", 4 * E1 + rows0 + cpos, 48 * E1, 2 * 11 * 16 * E1)
-K["sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false>"] = ("SA1 forward (gather + MLP + BN + max)", 4 * E1 + rows0 + cpos + 128 * M1 * B, 48 * E1, 864 * E1)
+K["sa_mfma_fwd_kernel<8, 2, 16, 16, 0, false, true>"] = ("SA1 statistics pass (gather + layer 1)", 4 * E1 + rows0 + cpos, 48 * E1, 2 * 11 * 16 * E1)
+K["sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false, true>"] = ("SA1 forward (gather + MLP + BN + max)", 4 * E1 + rows0 + cpos + 128 * M1 * B, 48 * E1, 864 * E1)
 K["sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>"] = ("SA1 backward, layer 2", 4 * E1 + rows0 + cpos + 128 * M1 * B, 48 * E1, (864 + 512 + 512) * E1)
 K["sa_mfma_bwd_kernel<8, 2, 16, 16, 3, false>"] = ("SA1 backward, layer 1", 4 * E1 + rows0 + cpos + 128 * M1 * B, 48 * E1, (864 + 512 + 352) * E1)
-K["sa_mfma_fwd_kernel<16, 1, 32, 32, 1, false>"] = ("SA2 forward", 4 * E2 + 80 * M1 * B + 16 * M2 * B + 256 * M2 * B, 80 * E2, 1216 * E2)
+K["sa_mfma_fwd_kernel<16, 1, 32, 32, 1, false, true>"] = ("SA2 forward", 4 * E2 + 80 * M1 * B + 16 * M2 * B + 256 * M2 * B, 80 * E2, 1216 * E2)
 K["sa_mfma_bwd_kernel<16, 1, 32, 32, 3, false>"] = ("SA2 backward", 4 * E2 + 80 * M1 * B + 16 * M2 * B + 256 * M2 * B, (80 + 64) * E2, (1216 + 1216 + 1024) * E2)
 K["scatter_max_kernel<0>"] = ("plot-wise projection: scatter-max", (8 + 16 + 4) * R + 24 * 400 * B, None, 0)
 K["fp_fwd_rows_kernel<34, 8, 34, false>"] = ("FP1 forward, row pass (source-side form)", (24 + 32 + 144) * R, 3 * 144 * R, 0)
