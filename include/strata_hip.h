@@ -88,6 +88,8 @@ int sn2_fps(const float *pos_soa, int B, int N, int M, const int *start, int *id
  * multi-workgroup kernel wherever the batch fits the chip (B * P workgroups resident at once), else one workgroup of 16 waves
  * per plot.  16 / 8: one workgroup of 16 / 8 waves per plot (8: a 9 % longer pass that leaves half of each occupied CU to
  * concurrent kernels: the setting of a pipelined loop where the pass runs beside another batch's feature kernels).
+ * 4: four waves per plot, for passes over hundreds of plots of at most 16 384 points (two or more FPS workgroups per CU:
+ * parcel inference); larger plots take 8.
  * 32 + P / 64 + P, P = 2, 4, 8: P workgroups of 16 / 8 waves per plot (each owns every P-th bucket of the plot's Morton order;
  * one exchange of tagged 8-byte granules through L2 per super-round; falls back to 16 when B * P workgroups do not fit).
  * 1: one sample per arg-max round (round 1's kernel, kept for cross-checks and timing comparisons).

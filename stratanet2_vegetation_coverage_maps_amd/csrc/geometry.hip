@@ -1715,7 +1715,7 @@ extern "C" int sn2_fps_status(const float* pos_soa, int B, int N, int M, const i
                               float* cpos_aos, int* order_ws, int waves, unsigned* status, void* stream) {
     if (!pos_soa || !idx || !cpos_soa || !cpos_aos || B <= 0 || N <= 0 || M <= 0 || M > N) return SN2_EINVAL;
     bool cluster = waves == 34 || waves == 36 || waves == 40 || waves == 66 || waves == 68 || waves == 72;
-    if (waves != 0 && waves != 16 && waves != 8 && waves != 1 && !cluster) return SN2_EINVAL;
+    if (waves != 0 && waves != 16 && waves != 8 && waves != 4 && waves != 1 && !cluster) return SN2_EINVAL;
     if (waves == 0) {
         // the shortest pass: several workgroups per plot wherever that fits (measured at 16 x 32 768 -> 1024: 8 workgroups of 8
         // waves 0.87 ms, 4 of 8 0.99, the single workgroup 1.24; scripts/time_fps_cluster.py)
@@ -1729,7 +1729,12 @@ extern "C" int sn2_fps_status(const float* pos_soa, int B, int N, int M, const i
     }
     const bool spec = waves != 1;      // 1: the one-sample-per-round kernel (round 1's; cross-checks and timing comparisons)
     hipStream_t st = (hipStream_t)stream;
-    if (order_ws && N > 2048 && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
+    // Many small plots (the parcel loop's level 2: 256 .. 512 plots of 2 500 points -> 625): the bucketed kernel has 40 buckets to
+    // prune among and takes 2 us per sample with 16 waves per plot (1.1 ms at half of every CU's wave slots); the brute-force
+    // kernel with the plot's points in the registers of FOUR waves takes the whole plot per round and is shorter.  Mirrored by
+    // hip_ops.fps_fills_ws (no workspace is filled then: the ball query behind it scans the plot).
+    const bool many_small = N <= 4096 && B > 32;
+    if (order_ws && N > 2048 && !many_small && M > 16 && (((size_t)B * N) % 4 == 0) && (((size_t)order_ws) % 16 == 0)) {
         // 32 + P / 64 + P: P = 2, 4 or 8 workgroups of 16 / 8 waves per plot (fps_cluster_kernel); needs at least two buckets
         // per wave and all B * P workgroups resident at once, else the single-workgroup kernel below runs
         if (cluster) {
@@ -1754,6 +1759,13 @@ extern "C" int sn2_fps_status(const float* pos_soa, int B, int N, int M, const i
         // waves = 8: half the waves per plot.  Alone the pass is 9 % slower (1.37 vs 1.26 ms at 32 x 32 768: fewer loads in
         // flight), but it leaves half of its CU's wave slots to whatever else runs: beside the feature pass of a pipelined
         // training loop the STEP is 2.4 % shorter (0.918 vs 0.940 ms; 4 waves: 2.07 ms alone, 0.922 ms per step).
+        // waves = 4 (plots of at most 16 384 points): half the wave slots again, for passes that share the chip with MANY other
+        // workgroups (the parcel loop: 512 plots per launch = two FPS workgroups per CU); larger plots take the 8-wave kernel
+        if (waves == 4 && N <= 16384) {
+            if (N <= 8192) return launch_fps_bucket<32, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+            return launch_fps_bucket<64, 4>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
+        }
+        if (waves == 4) waves = 8;
         if (waves == 8 && N <= 32768) {
             if (N <= 4096) return launch_fps_bucket<8, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
             if (N <= 8192) return launch_fps_bucket<16, 8>(pos_soa, B, N, M, start, order_ws, idx, cpos_soa, cpos_aos, st);
@@ -1766,6 +1778,7 @@ extern "C" int sn2_fps_status(const float* pos_soa, int B, int N, int M, const i
     if (N <= 512) return launch_fps<2, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 1024) return launch_fps<4, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 2048) return launch_fps<2, 1024>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
+    if (N <= 4096 && many_small) return launch_fps<16, 256>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 4096) return launch_fps<4, 1024>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 8192) return launch_fps<8, 1024>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);
     if (N <= 16384) return launch_fps<16, 1024>(pos_soa, B, N, M, start, idx, cpos_soa, cpos_aos, st);

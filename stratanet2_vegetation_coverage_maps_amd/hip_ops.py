@@ -252,7 +252,8 @@ def fps_fills_ws(B: int, N: int, m: int) -> bool:
     """Whether sn2_fps takes its bucketed path for these sizes, i.e. FILLS the workspace (Morton order, sorted table, cell
     starts) that ball_query / three_nn may then walk.  Must mirror the condition in csrc/geometry.hip (sn2_fps): handing
     those kernels a workspace nobody filled would send them through garbage cell lists."""
-    return N > 2048 and m > 16 and (B * N) % 4 == 0 and N <= 131072
+    many_small = N <= 4096 and B > 32          # sn2_fps_status: many small plots take the brute-force kernel (no tables)
+    return N > 2048 and not many_small and m > 16 and (B * N) % 4 == 0 and N <= 131072
 
 
 _FPS_STATUS = {}          # device index -> [status word (1,) int32 on the device, count already reported]
@@ -300,8 +301,9 @@ def fps(pos_soa: torch.Tensor, m: int, start: Optional[torch.Tensor] = None, buc
         return_ws: bool = False, out=None, waves: int = 0):
     """pos_soa (B,3,N) -> idx (B,m) int32 local indices, cpos_soa (B,3,m), cpos_aos (B*m,4).
     waves: which bucketed kernel (include/strata_hip.h: sn2_fps_waves): 0 = the shortest pass (several workgroups per plot
-    where the batch fits the chip), 16 / 8 = one workgroup of 16 / 8 waves per plot (8 = the pass that shares its CUs with
-    concurrent kernels, what the pipelined training loop asks for), 32 + P / 64 + P = P workgroups of 16 / 8 waves per plot,
+    where the batch fits the chip), 16 / 8 / 4 = one workgroup of 16 / 8 / 4 waves per plot (8 = the pass that shares its CUs with
+    concurrent kernels, what the pipelined training loop asks for; 4 = the same for passes over hundreds of small plots, the
+    parcel loop; plots of more than 16 384 points take 8), 32 + P / 64 + P = P workgroups of 16 / 8 waves per plot,
     1 = the one-sample-per-round kernel; same indices whichever runs.
     bucketed=False forces the brute-force kernel (same result; kept for cross-checks).  return_ws=True also returns
     the spatial-order workspace (or None), which `ball_query` over the same points can reuse.

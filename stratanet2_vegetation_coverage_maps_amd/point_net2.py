@@ -163,6 +163,10 @@ class PointNet2(nn.Module):
     mma_dtype = "fp32"
     # the level-1 FPS kernel when its pass shares the chip with feature kernels (sn2_fps_waves: 8 = one workgroup of 8 waves per plot)
     fps_waves_shared = int(os.environ.get("SN2_FPS_WAVES_SHARED", "8"))
+    # ... and with MANY plots in the pass (more than 32: the parcel loop's 512 per launch = two FPS workgroups per CU) 4 waves per
+    # plot where the kernel has that form (plots of at most 16 384 points; larger ones take 8): under that much concurrency the pass
+    # itself is shorter with fewer waves (4.1 against 5.1 ms per 512 plots of 10 000 points) and the loop 2.6 % faster
+    fps_waves_many = int(os.environ.get("SN2_FPS_WAVES_MANY", "4"))
     geometry_fork = True       # `_geometry`: the three independent chains behind the level-1 FPS on three streams
     fuse_eval_head = os.environ.get("SN2_FUSE_EVAL_HEAD", "1") == "1"     # eval: FP1 + head in one kernel (sn2_fp_head_eval)
     # additive: a geometry pass that is handed the batch's `cloud` also does the two INPUT-only pieces of the feature pass --
@@ -358,7 +362,7 @@ class PointNet2(nn.Module):
         fork = self.geometry_fork if fork is None else fork
         cur = torch.cuda.current_stream(dev)
         ops.fps(xyz, M1, fps_start[0], out=(g.idx1, g.pos1_soa, g.pos1_aos, g.ws1),
-                waves=self.fps_waves_shared if shared else 0)
+                waves=(self.fps_waves_many if B > 32 else self.fps_waves_shared) if shared else 0)
         if fork:
             sb, sc = ops.shared_stream(dev, "fork_b"), ops.shared_stream(dev, "fork_c")
             sb.wait_stream(cur)

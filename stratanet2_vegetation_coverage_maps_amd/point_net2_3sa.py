@@ -184,7 +184,7 @@ class PointNet2ThreeSA(PointNet2):
             ws = getattr(g, f"ws{lvl}")
             cs = getattr(g, f"pos{lvl}_soa")
             ops.fps(src, M, fps_start[lvl - 1], out=(getattr(g, f"idx{lvl}"), cs, getattr(g, f"pos{lvl}_aos"), ws),
-                    waves=self.fps_waves_shared if (shared and lvl == 1) else 0)
+                    waves=(self.fps_waves_many if B > 32 else self.fps_waves_shared) if (shared and lvl == 1) else 0)
             ops.ball_query(src, cs, mod.r, cap, getattr(g, f"tot{lvl}"), fps_ws=ws,
                            out=(getattr(g, f"nbr{lvl}"), getattr(g, f"cnt{lvl}")))
             ops.sa_order(getattr(g, f"cnt{lvl}"), B, M, out=getattr(g, f"ord{lvl}"))

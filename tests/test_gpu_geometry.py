@@ -16,7 +16,7 @@ def _pos(B, N, first=0):
     return d["xyz"], d["cloud"]
 
 
-@pytest.mark.parametrize("B,N,M", [(1, 4096, 1024), (2, 2048, 256), (3, 1000, 250), (2, 200, 50), (2, 5000, 313),
+@pytest.mark.parametrize("B,N,M", [(1, 4096, 1024), (2, 2048, 256), (3, 1000, 250), (2, 200, 50), (2, 5000, 313), (40, 2500, 625),
                                    (1, 32768, 256), (2, 16384, 128), (2, 1024, 256), (1, 300, 300)])
 def test_fps_matches_oracle_exactly(B, N, M):
     xyz, _ = _pos(B, N, first=7)
@@ -48,6 +48,8 @@ def test_bucketed_fps_equals_brute_force_and_oracle(B, N, M):
     # same workspace for the ball query behind it
     i_8, cs_8, _, ws8 = ops.fps(dev, M, start.to(DEV, torch.int32), waves=8, return_ws=True)
     assert torch.equal(i_8, i_f) and torch.equal(cs_8, cs_f)
+    i_4, cs_4, _ = ops.fps(dev, M, start.to(DEV, torch.int32), waves=4)       # four waves per plot (the parcel loop; > 16 384 points: 8)
+    assert torch.equal(i_4, i_f) and torch.equal(cs_4, cs_f)
     i_1, cs_1, _ = ops.fps(dev, M, start.to(DEV, torch.int32), waves=1)       # one sample per arg-max round (round 1's kernel)
     assert torch.equal(i_1, i_f) and torch.equal(cs_1, cs_f)
     i_16, cs_16, _ = ops.fps(dev, M, start.to(DEV, torch.int32), waves=16)    # one workgroup of 16 waves per plot
