@@ -1876,12 +1876,21 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __res
                                                               int cap, const int* __restrict__ order,
                                                               const float4* __restrict__ sorted, const int* __restrict__ grid,
                                                               int* __restrict__ nbr, int* __restrict__ cnt,
-                                                              unsigned long long* __restrict__ total) {
+                                                              unsigned long long* __restrict__ total, int xcd_aware) {
     __shared__ int s_list[4][GQ_LIST];
     extern __shared__ unsigned gq_bits[];              // [4][(N + 31) / 32]: one bit per source point, per wave (dense balls)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int ci = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
-    if (ci >= B * M) return;
+    // XCD-aware placement (round 4): workgroups go to the eight XCDs round-robin, and every XCD has its own L2 -- with the
+    // centroids dealt out in index order all eight L2s fetched every plot's sorted table (PMC: 5.2 x the compulsory bytes at
+    // 16 x 32 768).  Plot b is worked on by the workgroups of XCD b % 8 only: workgroup w = (XCD w & 7, turn w >> 3), the turns
+    // of an XCD walk its plots one after the other, (M + 3) / 4 workgroups of four centroids per plot.
+    // (xcd_aware = 0: fewer plots than that balances -- a single plot would run on one XCD --: workgroup w takes plot w / bpp)
+    const int bpp = (M + 3) >> 2;
+    const int turn = xcd_aware ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int pb = xcd_aware ? (int)(blockIdx.x & 7u) + 8 * (turn / bpp) : turn / bpp;
+    const int pm = (turn % bpp) * 4 + wib;
+    if (pb >= B || pm >= M) return;
+    const int ci = __builtin_amdgcn_readfirstlane(pb * M + pm);
     const int nwords = (N + 31) >> 5;
     unsigned* bits = gq_bits + (size_t)wib * nwords;
     // (Round 4 tried working the centroids in the order of their Morton cells instead of FPS order -- consecutive waves then
@@ -2119,8 +2128,14 @@ extern "C" int sn2_ball_query(const float* src_soa, int B, int N, const float* c
         const size_t lds = (size_t)4 * ((N + 31) / 32) * sizeof(unsigned);       // the dense-ball bitmaps: 64 KB at N = 131 072
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ball_query_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        hipLaunchKernelGGL(ball_query_grid_kernel, dim3(sn2_cdiv((long)B * M, 4)), dim3(256), lds, (hipStream_t)stream, src_soa,
-                           B, N, cpos_soa, M, r, r2, cap, order, sorted, grid, nbr, cnt, total);
+        // grid: eight XCDs x the plots of the fullest XCD x the workgroups of a plot (ball_query_grid_kernel: placement)
+        // (plots per XCD must balance: a multiple of 8 plots, or so many that the remainder does not matter)
+        static const bool gq_no_xcd = getenv("SN2_GQ_NO_XCD") != nullptr;        // (diagnostic switch)
+        const int xcd_aware = (!gq_no_xcd && (B % 8 == 0 || B >= 64)) ? 1 : 0;
+        const long gq_blocks = xcd_aware ? 8L * sn2_cdiv(B, 8) * sn2_cdiv(M, 4) : (long)B * sn2_cdiv(M, 4);
+        if (gq_blocks >= (1L << 31)) return SN2_ELIMIT;
+        hipLaunchKernelGGL(ball_query_grid_kernel, dim3((unsigned)gq_blocks), dim3(256), lds, (hipStream_t)stream, src_soa,
+                           B, N, cpos_soa, M, r, r2, cap, order, sorted, grid, nbr, cnt, total, xcd_aware);
         if (total) hipLaunchKernelGGL(count_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)cnt, B * M, total);
         SN2_RETURN_LAUNCH();
     }
