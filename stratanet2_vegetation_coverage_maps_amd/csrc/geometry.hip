@@ -2303,16 +2303,27 @@ extern "C" int sn2_debug_nn_stamps(unsigned long long* out, int n) {
 __global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __restrict__ tbl, const int* __restrict__ hdr, int S,
                                                             int T, int k, const int* __restrict__ dst_order,
                                                             const float4* __restrict__ dst_sorted,
-                                                            int* __restrict__ idx, float* __restrict__ w) {
+                                                            int* __restrict__ idx, float* __restrict__ w, int B, int gx) {
     extern __shared__ __attribute__((aligned(16))) float4 s_tbl[];      // S entries, then the cell starts
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    // XCD-aware placement (as ball_query_grid_kernel): with B = 0 the grid is (gx, plots) as before; with B > 0 it is one-
+    // dimensional, workgroup w = (XCD w & 7, turn w >> 3), and plot b is worked on by XCD b % 8 only -- the results go to the
+    // targets' ORIGINAL rows, 24 bytes each into lines that ten waves share, and only waves behind the same L2 merge them
+    // there before they are written back
+    int b = blockIdx.y, bx = blockIdx.x;
+    if (B > 0) {
+        const int turn = (int)(blockIdx.x >> 3);
+        b = (int)(blockIdx.x & 7u) + 8 * (turn / gx);
+        bx = turn % gx;
+        if (b >= B) return;
+    }
+    const int lane = threadIdx.x & 63;
     const int* hb = hdr + (size_t)b * NN_HDR;
     const int G = __builtin_amdgcn_readfirstlane(hb[NN_GMAX * NN_GMAX + 1 + 5]);
     int* s_cell = reinterpret_cast<int*>(s_tbl + S);
     for (int i = threadIdx.x; i < S; i += 256) s_tbl[i] = tbl[(size_t)b * S + i];
     for (int i = threadIdx.x; i <= G * G; i += 256) s_cell[i] = hb[i];
     __syncthreads();
-    const int p = blockIdx.x * 256 + threadIdx.x;                        // sorted position
+    const int p = bx * 256 + threadIdx.x;                                // sorted position
     if (p - lane >= T) return;                                           // whole wave past the end
     const bool valid = p < T;
     const float* hf = reinterpret_cast<const float*>(hb + NN_GMAX * NN_GMAX + 1);
@@ -2409,7 +2420,7 @@ __global__ __launch_bounds__(256) void three_nn_grid_kernel(const float4* __rest
     {
         unsigned long long t_end;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
-        const int wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+        const int wid = (b * gx + bx) * 4 + (threadIdx.x >> 6);
         if (lane == 0 && wid < 16384) {
             g_nn_dbg[4 * wid + 0] = t_end - t_begin;
             g_nn_dbg[4 * wid + 1] = n_cand;
@@ -2595,8 +2606,16 @@ extern "C" int sn2_three_nn_xy(const float* src_soa, int B, int S, const float* 
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&three_nn_grid_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(three_nn_grid_kernel, dim3(sn2_cdiv(T, 256), B), dim3(256), lds, st, (const float4*)tbl,
-                       (const int*)hdr, S, T, k, (const int*)order, (const float4*)sorted, idx, w);
+    {
+        const int gx = sn2_cdiv(T, 256);
+        static const bool no_xcd = getenv("SN2_NN_NO_XCD") != nullptr;      // (diagnostic switch)
+        if (!no_xcd && (B % 8 == 0 || B >= 64))      // plots balance over the XCDs: XCD-aware placement
+            hipLaunchKernelGGL(three_nn_grid_kernel, dim3(8 * sn2_cdiv(B, 8) * gx), dim3(256), lds, st, (const float4*)tbl,
+                               (const int*)hdr, S, T, k, (const int*)order, (const float4*)sorted, idx, w, B, gx);
+        else
+            hipLaunchKernelGGL(three_nn_grid_kernel, dim3(gx, B), dim3(256), lds, st, (const float4*)tbl,
+                               (const int*)hdr, S, T, k, (const int*)order, (const float4*)sorted, idx, w, 0, gx);
+    }
     SN2_RETURN_LAUNCH();
 }
 
@@ -2617,7 +2636,7 @@ extern "C" int sn2_three_nn(const float* src_soa, int B, int S, const float* dst
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(three_nn_grid_kernel, dim3(sn2_cdiv(T, 256), B), dim3(256), lds, st, (const float4*)tbl,
                            (const int*)hdr, S, T, k, dst_fps_ws, reinterpret_cast<const float4*>(dst_fps_ws + (size_t)B * T),
-                           idx, w);
+                           idx, w, 0, sn2_cdiv(T, 256));
         SN2_RETURN_LAUNCH();
     }
     dim3 grid(sn2_cdiv(T, 256), B);
