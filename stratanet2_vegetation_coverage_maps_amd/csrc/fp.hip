@@ -1981,8 +1981,8 @@ constexpr int HEAD_T_QUADS = 64 * 9;   // a wave's 64 consecutive rows of 36 flo
 //   -> scores to LDS [64][8] -> one row per lane: softmax, sigmoid, two coalesced float4 stores.
 // 52 MFMAs per 64 rows instead of 624 FMA instructions per row-lane fed by scalar weight loads.  It is NOT faster than that
 // form (24-28 us for 92 MB either way: the kernel streams at 3.3-3.8 TB/s and fp32 MFMA has the packed-VALU rate, 2 x the
-// scalar-operand FMA rate); it frees the VALU and scalar cache for whatever runs beside it.  The backward keeps its
-// row-per-lane form: 188 padded MFMAs per 64 rows would take as long as its 1250 FMAs per row do now.
+// scalar-operand FMA rate); it frees the VALU and scalar cache for whatever runs beside it.  The backward
+// (head_bwd_mfma_kernel, round 4) is built the same way.
 template <bool BF>
 __global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
                                                             const float* __restrict__ fc, const float* __restrict__ W1,
@@ -2016,7 +2016,9 @@ __global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const floa
             for (int k = 0; k < 9; ++k) {
                 const int e = lane + 64 * k;
                 // quad e of the wave's 64 consecutive rows: 16 bytes of fp32 or 8 bytes of bfloat16, contiguous either way
-                t[k] = e < lim ? row_quad_ld<BF>(f, (size_t)r0, 36, e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                // (unconditional loads from a clamped address: a load under a divergent branch is waited for at the join)
+                const float4 v = row_quad_ld<BF>(f, (size_t)r0, 36, e < lim ? e : 0);
+                t[k] = e < lim ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) st4[lane + 64 * k] = t[k];
@@ -2230,110 +2232,442 @@ __global__ __launch_bounds__(256, 2) void fp_head_eval_kernel(int R, int R_per_p
     }
 }
 
-constexpr int HEAD_BWD_THREADS = 256;
-constexpr int HEAD_BWD_LDS_FLOATS = OuterAcc<16, 35, 32>::LDS_FLOATS;   // >= OuterAcc<16, 17, 32>::LDS_FLOATS
+// The head backward on the matrix cores (round 4; rows of exactly 36 floats).  Its predecessor gave every lane one row: ~1900
+// FMA instructions per row, a third of them on the two weight-gradient outer products through an LDS transposition, behind
+// 144-byte strided row loads and stores (64 lines per instruction): 57 us for 168 MB.  Here a wave takes 64 consecutive rows
+// per turn, as head_fwd_mfma_kernel does, and every contraction is a chain of 16x16x4 tiles fed from three LDS regions:
+//   st [64][36]  y = fa f + fc (applied once, on the way in from the coalesced float4 loads; column 34 := 1 -- the bias
+//                column of [y | 1] --, column 35 := 0); at the end of the turn the d rows, stored coalesced the same way
+//   zt [64][20]  z1 = dropout(relu(lin1)) for lin2 and dW2, then d pre-activation of lin1 for dW1 and the d rows
+//   sc [64][12]  the five scores, then their gradients (softmax / sigmoid backward with one row per lane), columns 5..7 zero
+//   lin1 36 + lin2 16 + dW2 16 + d pre 8 + dW1 48 + d rows 48 = 172 tiles per 64 rows; dW1 | db1 and dW2 stay in
+//   accumulators for the whole kernel, db2 is a per-lane sum; the next turn's rows and gradients are requested before the
+//   current turn's arithmetic.
+// LDS traffic, not the matrix cores, is what the layout is about (ds_read_b32 / ds_write_b32: 32 banks, lanes 0..31 and
+// 32..63 apart; ds_read_b64: 64 banks):
+//   * a tile's k index is free as long as both operands agree.  Where a lane's operand runs along a ROW (lin1, lin2, d pre,
+//     d rows: lane (n, kq) = row n of the tile) steps 2p and 2p+1 take columns 8p + 2kq and 8p + 2kq + 1: ONE ds_read_b64
+//     per two tiles, conflict-free at the even strides 36 / 20 / 12 (the plain 4 ks + kq columns are 2-way, 4-way at 12);
+//   * where it runs along a COLUMN (dW2, dW1: lane (n, kq) = column n) step s takes rows 16 (s / 4) + s % 4 + 4 kq: lanes
+//     kq and kq + 1 are four rows = 16 banks apart at every stride.
+//   * the per-lane weight operands (30 floats) live in a table of float4 per (quad, lane), read phase by phase: held in
+//     registers for the whole loop they left no room beside the prefetched rows (spills, and a spill's reload waits for the
+//     prefetch with it).
+// Operands are read in batches in front of their tiles (sched_barrier: left alone the scheduler puts every read right in front
+// of its tile and pays the LDS latency 170 times per turn).
+// Same sums as the row-per-lane form up to fp32 re-association.
+#ifdef SN2_HB_STAMPS
+// diagnostic build only (never shipped): phase stamps of wave 0 of one workgroup of head_bwd_mfma_kernel, second turn
+__device__ unsigned long long g_hb_dbg[16];
+extern "C" int sn2_debug_hb_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hb_dbg), sizeof(g_hb_dbg));
+}
+#define HSTAMP(i)                                                                                   \
+    if (blockIdx.x == 37 && threadIdx.x == 0 && turn_no == 1) {                                     \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        g_hb_dbg[i] = t_;                                                                           \
+    }
+#else
+#define HSTAMP(i)
+#endif
+// one ds_read_b64 (left to the compiler two of them at nearby offsets become a ds_read2_b64: banked like ds_read_b32, 4 x the
+// cycles).  The compiler does not count this read: the caller waits (HB_WAIT_B64) before the first use.
+typedef float hb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hb_f32x2 lds_read_b64(const float* p) {
+    hb_f32x2 v;
+    const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+constexpr int HB_ST = 64 * 36, HB_ZT = 64 * 20, HB_SC = 64 * 12;
+constexpr int HB_WAVE_FLOATS = HB_ST + HB_ZT + HB_SC + 64;      // + the rows' dropout words
+#ifndef SN2_HB_DIAG
+#define SN2_HB_DIAG 0      /* timing experiments (scripts/time_head_bwd.py): 1 = no d-row stores, 2 = no arithmetic (rows in, rows out) */
+#endif
+constexpr int HB_DIAG = SN2_HB_DIAG;
+constexpr int HB_CQ = 8;                                        // float4 quads of per-lane weight operands (one table per workgroup)
+constexpr int HB_TAB_FLOATS = HB_CQ * 64 * 4 + 18 * 4;          // + fa, fc as nine quads each
+constexpr int HB_RED = 16 * 35 + 5 * 16 + 5;                    // a wave's weight-gradient image: dW1 | db1, dW2, db2
 template <bool BF>
-__global__ __launch_bounds__(HEAD_BWD_THREADS) void head_bwd_kernel(int R, int f_stride, const float* __restrict__ f,
-                                                       const float* __restrict__ fa, const float* __restrict__ fc,
-                                                       const float* __restrict__ W1g, const float* __restrict__ b1,
-                                                       const float* __restrict__ W2g, const float* __restrict__ b2,
-                                                       const float* __restrict__ dcov, const float* __restrict__ dproba,
-                                                       float* __restrict__ dy, float* __restrict__ dW1,
-                                                       float* __restrict__ db1, float* __restrict__ dW2,
-                                                       float* __restrict__ db2, int rep_k, int rep_stride,
-                                                       const int* __restrict__ drop_mask, float drop_scale) {
-    using Acc2 = OuterAcc<16, 17, 32>;  // rows 0..4 = d scores, rest zero;  Q = [z1 | 1]
-    using Acc1 = OuterAcc<16, 35, 32>;  // d pre-activation of lin1;          Q = [y | 1]
-    // 4 waves per workgroup, 4 workgroups per CU (4 waves per SIMD: the row loads are 144-byte strided, only occupancy
-    // hides them; 1024-thread workgroups took 82 us, 256-thread ones 74: the hardware balances workgroups); the two
-    // accumulators take turns in one 10 KB staging region per wave
+__global__ __launch_bounds__(256, 2) void head_bwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
+                                                            const float* __restrict__ fc, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ W2,
+                                                            const float* __restrict__ b2, const float* __restrict__ dcov,
+                                                            const float* __restrict__ dproba, float* __restrict__ dy,
+                                                            float* __restrict__ dW1, float* __restrict__ db1,
+                                                            float* __restrict__ dW2, float* __restrict__ db2, int rep_k,
+                                                            int rep_stride, const int* __restrict__ drop_mask, float drop_scale) {
+    typedef hb_f32x2 f32x2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lds2 = smem + (threadIdx.x >> 6) * HEAD_BWD_LDS_FLOATS;
-    float* lds1 = lds2;
-    Acc2 acc2;
-    Acc1 acc1;
-    acc2.init(lds2);
-    acc1.init(lds1);
-    const long nthreads = (long)gridDim.x * HEAD_BWD_THREADS;
-    const long rounds = (R + nthreads - 1) / nthreads;
-    for (long it = 0; it < rounds; ++it) {
-        const long r = it * nthreads + (long)blockIdx.x * HEAD_BWD_THREADS + threadIdx.x;
-        const bool valid = r < R;
-        const size_t rr = valid ? (size_t)r : 0;
-        const cfp W1 = opaque(as_const(W1g)), W2 = opaque(as_const(W2g));
-        HeadOut o;
-        head_row<BF>(f, f_stride, opaque(as_const(fa)), opaque(as_const(fc)), W1, opaque(as_const(b1)), W2,
-                     opaque(as_const(b2)), rr, o, drop_mask, drop_scale);
-        float gc[4] = {0.f, 0.f, 0.f, 0.f}, gp[4] = {0.f, 0.f, 0.f, 0.f};
-        if (dcov) {
-            const float4 v = reinterpret_cast<const float4*>(dcov)[rr];
-            gc[0] = v.x; gc[1] = v.y; gc[2] = v.z; gc[3] = v.w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* st = smem + wave * HB_WAVE_FLOATS;
+    float4* st4 = reinterpret_cast<float4*>(st);
+    float* zt = st + HB_ST;
+    float* sc = zt + HB_ZT;
+    int* mk = reinterpret_cast<int*>(sc + HB_SC);
+    const int n = lane & 15, kq = lane >> 4;
+    float* tab = smem + 4 * HB_WAVE_FLOATS;
+    // ---- the weight operands of lane (n, kq) -> the table
+    if (wave == 0) {
+        float c[4 * HB_CQ];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {                        // lin1: B[k][n] = W1[n][k], k = 8 pp + 2 kq (+ 1)
+            c[2 * pp] = W1[n * 34 + 8 * pp + 2 * kq];
+            c[2 * pp + 1] = W1[n * 34 + 8 * pp + 2 * kq + 1];
         }
-        if (dproba) {
-            const float4 v = reinterpret_cast<const float4*>(dproba)[rr];
-            gp[0] = v.x; gp[1] = v.y; gp[2] = v.z; gp[3] = v.w;
+        c[8] = kq < 2 ? W1[n * 34 + 32 + kq] : 0.f;             // ... and the ninth step: k = 32 + kq
+        c[9] = b1[n];
+        c[10] = n < 5 ? b2[n] : 0.f;
+        c[11] = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                        // lin2: B[k][n] = W2[n][k]
+            c[12 + 2 * pp] = n < 5 ? W2[n * 16 + 8 * pp + 2 * kq] : 0.f;
+            c[13 + 2 * pp] = n < 5 ? W2[n * 16 + 8 * pp + 2 * kq + 1] : 0.f;
         }
-        float dp[4], dot = 0.f, ddens = 0.f;
+        c[16] = 2 * kq < 5 ? W2[(2 * kq) * 16 + n] : 0.f;       // d pre: B[i][j] = W2[i][j], i = 2 kq (+ 1)
+        c[17] = 2 * kq + 1 < 5 ? W2[(2 * kq + 1) * 16 + n] : 0.f;
+        c[18] = c[19] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dp[i] = fmaf(gc[i], o.dens, gp[i]);
-            ddens = fmaf(gc[i], o.p[i], ddens);
-            dot = fmaf(dp[i], o.p[i], dot);
-        }
-        float ds[16];
+        for (int ct = 0; ct < 3; ++ct)                          // d rows: B[j][col] = W1[j][col], j = 8 pp + 2 kq (+ 1)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ds[i] = valid ? o.p[i] * (dp[i] - dot) : 0.f;
-        ds[4] = valid ? ddens * o.dens * (1.f - o.dens) : 0.f;
-#pragma unroll
-        for (int i = 5; i < 16; ++i) ds[i] = 0.f;
-        acc2.add(lds2, ds, o.z1);
-        float dpre[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) a = fmaf(W2[i * 16 + j], ds[i], a);
-            // through the dropout (kept: x scale) and the ReLU: z1 > 0 exactly where the channel is kept AND active
-            dpre[j] = o.z1[j] > 0.f ? a * drop_scale : 0.f;
-        }
-        acc1.add(lds1, dpre, o.y);
-        if (valid) {
-#pragma unroll
-            for (int k4 = 0; k4 < 36; k4 += 4) {
-                float v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float a = 0.f;
-                    if (k4 + t < 34) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) a = fmaf(W1[j * 34 + k4 + t], dpre[j], a);
-                    }
-                    v[t] = a;
-                }
-                row_quad_st<BF>(dy, rr, f_stride, k4 / 4, v[0], v[1], v[2], v[3]);
+            for (int pp = 0; pp < 2; ++pp) {
+                const int col = 16 * ct + n;
+                c[20 + 4 * ct + 2 * pp] = col < 34 ? W1[(8 * pp + 2 * kq) * 34 + col] : 0.f;
+                c[21 + 4 * ct + 2 * pp] = col < 34 ? W1[(8 * pp + 2 * kq + 1) * 34 + col] : 0.f;
             }
+        float4* ct4 = reinterpret_cast<float4*>(tab);
+#pragma unroll
+        for (int q = 0; q < HB_CQ; ++q) ct4[q * 64 + lane] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+        if (lane < 36) {                                        // [y | 1 | 0]: fa = 0 and fc = 1 in column 34, both 0 in column 35
+            tab[HB_CQ * 256 + lane] = lane < 34 ? fa[lane] : 0.f;
+            tab[HB_CQ * 256 + 36 + lane] = lane < 34 ? fc[lane] : (lane == 34 ? 1.f : 0.f);
         }
     }
-    // workgroup-level reduction, then one global atomic per element and workgroup
-    float* red = smem;
-    constexpr int N2 = 16 * 17, N1 = 16 * 35;
     __syncthreads();
-    static_assert(N2 + N1 <= HEAD_BWD_LDS_FLOATS, "a wave's two images fit its staging region");
-    acc2.store_slab(lds2);
-    acc1.store_slab(lds2 + N2);
-    __syncthreads();
-    for (int i = threadIdx.x; i < N2 + N1; i += HEAD_BWD_THREADS) {
-        float v = 0.f;
+    const float4* ctab = reinterpret_cast<const float4*>(tab) + lane;
+    const float4* fa4 = reinterpret_cast<const float4*>(tab + HB_CQ * 256);
+    const float4* fc4 = fa4 + 9;
+    const int lane9 = lane % 9;
+    const int nn = n < 8 ? n : 5;                               // lanes n >= 8 of dW2's A operand read a zero column
+    f32x4 dw1acc[3], dw2acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < HEAD_BWD_THREADS / 64; ++w) v += red[w * HEAD_BWD_LDS_FLOATS + i];
+    for (int ct = 0; ct < 3; ++ct) dw1acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const long stride = (long)gridDim.x * 256;
+    long r0 = ((long)blockIdx.x * 4 + wave) * 64;
+    float4 t[9], gc = make_float4(0.f, 0.f, 0.f, 0.f), gp = gc;
+    int keep = 0xFFFF;
+    // (a gradient or mask that is absent is loaded from the rows instead -- 16 valid bytes per row -- and dropped at its use:
+    // a load under a branch, even a uniform one, is waited for where the branch joins, which would end the prefetch; for the
+    // same reason the rows past the end are loaded from a clamped address: finite values whose d scores are zero)
+    const float4* gcp = reinterpret_cast<const float4*>(dcov ? dcov : f);
+    const float4* gpp = reinterpret_cast<const float4*>(dproba ? dproba : f);
+    const int* kp = drop_mask ? drop_mask : reinterpret_cast<const int*>(f);
+    auto request = [&](long q0) {               // the rows of a turn, one row's incoming gradients and dropout word per lane
+        const long lim = (R - q0) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int e = lane + 64 * k;
+            t[k] = row_quad_ld<BF>(f, (size_t)q0, 36, e < lim ? e : 0);
+        }
+        const long r = q0 + lane;
+        const size_t rr = r < R ? (size_t)r : 0;
+        gc = gcp[rr];
+        gp = gpp[rr];
+        keep = kp[rr];
+    };
+    if (r0 < R) request(r0);
+    int turn_no = -1;
+    for (; r0 < R; r0 += stride) {
+        ++turn_no;
+        HSTAMP(0)
+        // ---- quad e = lane + 64 k of the tile is quad (lane + k) % 9 of its row
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int q9 = lane9 + k < 9 ? lane9 + k : lane9 + k - 9;
+            const float4 a4 = fa4[q9], c4 = fc4[q9], v = t[k];
+            float4 y = make_float4(fmaf(a4.x, v.x, c4.x), fmaf(a4.y, v.y, c4.y), fmaf(a4.z, v.z, c4.z), fmaf(a4.w, v.w, c4.w));
+            if (q9 == 8) y.z = 1.f, y.w = 0.f;                  // (whatever the rows' padding holds)
+            st4[lane + 64 * k] = y;
+        }
+        if (drop_mask) mk[lane] = keep;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gcv = dcov ? gc : zero4, gpv = dproba ? gp : zero4;
+        const bool valid = r0 + lane < R;
+        WAVE_LDS_SYNC();
+        HSTAMP(1)
+        if (!(HB_DIAG & 2)) {
+        // ---- lin1, ReLU, dropout (z[tt][j]: row 16 tt + 4 kq + j, hidden channel n)
+#pragma unroll
+        for (int tp = 0; tp < 4; tp += 2) {
+            f32x2 av[2][4];
+            float as[2];
+            f32x4 z[2];
+            const float4 q0 = ctab[0], q1 = ctab[64], q2 = ctab[128];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+                    av[tt][pp] = lds_read_b64(&st[(16 * (tp + tt) + n) * 36 + 8 * pp + 2 * kq]);
+                as[tt] = st[(16 * (tp + tt) + n) * 36 + 32 + kq];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[0][2]), "+v"(av[0][3]), "+v"(av[1][0]), "+v"(av[1][1]), "+v"(av[1][2]), "+v"(av[1][3]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const float w1p[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) z[tt] = f32x4{q2.y, q2.y, q2.y, q2.y};
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        z[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt][pp][h], w1p[2 * pp + h], z[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) z[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[tt], q2.x, z[tt], 0, 0, 0);
+            int kw[2][4];
+            if (drop_mask) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) kw[tt][j] = mk[16 * (tp + tt) + 4 * kq + j];
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float zz = fmaxf(z[tt][j], 0.f);
+                    if (drop_mask) zz = ((kw[tt][j] >> n) & 1) ? zz * drop_scale : 0.f;
+                    zt[(16 * (tp + tt) + 4 * kq + j) * 20 + n] = zz;
+                }
+        }
+        WAVE_LDS_SYNC();
+        HSTAMP(2)
+        // ---- lin2 -> scores
+        {
+            f32x2 zv[4][2];
+            f32x4 s2[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) zv[tt][pp] = lds_read_b64(&zt[(16 * tt + n) * 20 + 8 * pp + 2 * kq]);
+            const float4 w2q = ctab[3 * 64];
+            const float bias2 = ctab[2 * 64].z;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zv[0][0]), "+v"(zv[0][1]), "+v"(zv[1][0]), "+v"(zv[1][1]), "+v"(zv[2][0]), "+v"(zv[2][1]), "+v"(zv[3][0]), "+v"(zv[3][1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const float w2p[4] = {w2q.x, w2q.y, w2q.z, w2q.w};
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) s2[tt] = f32x4{bias2, bias2, bias2, bias2};
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        s2[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[tt][pp][h], w2p[2 * pp + h], s2[tt], 0, 0, 0);
+            if (n < 8) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sc[(16 * tt + 4 * kq + j) * 12 + n] = s2[tt][j];
+            }
+        }
+        WAVE_LDS_SYNC();
+        HSTAMP(3)
+        // ---- one row per lane: softmax, sigmoid and their backward -> d scores
+        {
+            const float4 s03 = *reinterpret_cast<const float4*>(&sc[lane * 12]);
+            const float s4 = sc[lane * 12 + 4];
+            const float sv[4] = {s03.x, s03.y, s03.z, s03.w};
+            const float m = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+            float e[4], den = 0.f, pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                e[i] = expf(sv[i] - m);
+                den += e[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pr[i] = e[i] / den;
+            const float dens = 1.0f / (1.0f + expf(-s4));
+            const float gcs[4] = {gcv.x, gcv.y, gcv.z, gcv.w}, gps[4] = {gpv.x, gpv.y, gpv.z, gpv.w};
+            float dp[4], dot = 0.f, ddens = 0.f, ds[5];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dp[i] = fmaf(gcs[i], dens, gps[i]);
+                ddens = fmaf(gcs[i], pr[i], ddens);
+                dot = fmaf(dp[i], pr[i], dot);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ds[i] = valid ? pr[i] * (dp[i] - dot) : 0.f;
+            ds[4] = valid ? ddens * dens * (1.f - dens) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) dsum[i] += ds[i];
+            WAVE_LDS_SYNC();
+            *reinterpret_cast<float4*>(&sc[lane * 12]) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+            *reinterpret_cast<float4*>(&sc[lane * 12 + 4]) = make_float4(ds[4], 0.f, 0.f, 0.f);
+        }
+        WAVE_LDS_SYNC();
+        HSTAMP(4)
+        // ---- dW2[i][j] += sum_rows d score[row][i] z1[row][j]   (step s: rows 16 (s / 4) + s % 4 + 4 kq)
+        f32x4 dpre[4];
+        {
+            f32x4 odd = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float da[8], zb[8];
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const int sidx = 8 * half + s8, row0 = 16 * (sidx >> 2) + (sidx & 3);
+                    da[s8] = sc[(row0 + 4 * kq) * 12 + nn];
+                    zb[s8] = zt[(row0 + 4 * kq) * 20 + n];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8 += 2) {
+                    dw2acc = __builtin_amdgcn_mfma_f32_16x16x4f32(da[s8], zb[s8], dw2acc, 0, 0, 0);
+                    odd = __builtin_amdgcn_mfma_f32_16x16x4f32(da[s8 + 1], zb[s8 + 1], odd, 0, 0, 0);
+                }
+            }
+            HSTAMP(5)
+            // ---- d pre-activation of lin1 = (d scores W2) through the dropout and the ReLU (z1 > 0: kept AND active)
+            f32x2 dv[4];
+            float zm[4][4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                dv[tt] = lds_read_b64(&sc[(16 * tt + n) * 12 + 2 * kq]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zm[tt][j] = zt[(16 * tt + 4 * kq + j) * 20 + n];
+            }
+            const float4 c4 = ctab[4 * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) dpre[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) dpre[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[tt][h], h ? c4.y : c4.x, dpre[tt], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dw2acc[j] += odd[j];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dpre[tt][j] = zm[tt][j] > 0.f ? dpre[tt][j] * drop_scale : 0.f;
+        }
+        WAVE_LDS_SYNC();                        // dW2 has read z1: its region takes d pre
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zt[(16 * tt + 4 * kq + j) * 20 + n] = dpre[tt][j];
+        WAVE_LDS_SYNC();
+        HSTAMP(6)
+        // (the next turn's rows are requested here, in front of the two longest tile chains, not at the top of the turn: a dozen
+        // vector-memory instructions in front of lin1's LDS reads held those back -- 50.4 -> 48.8 us)
+        if (r0 + stride < R) request(r0 + stride);
+        // ---- dW1 | db1 += d pre^T [y | 1]   (the tile's columns 35.. feed accumulator columns nobody reads)
+#pragma unroll
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            float pa[4], yv[4][3];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int row = 16 * quarter + s4 + 4 * kq;
+                pa[s4] = zt[row * 20 + n];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) yv[s4][ct] = st[row * 36 + 16 * ct + n];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) dw1acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4], yv[s4][ct], dw1acc[ct], 0, 0, 0);
+        }
+        WAVE_LDS_SYNC();                        // dW1 has read the rows: their region takes the d rows
+        HSTAMP(7)
+        // ---- d rows = d pre W1
+        {
+            f32x2 pv[4][2];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) pv[tt][pp] = lds_read_b64(&zt[(16 * tt + n) * 20 + 8 * pp + 2 * kq]);
+            float w1b[3][4];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const float4 v = ctab[(5 + ct) * 64];
+                w1b[ct][0] = v.x, w1b[ct][1] = v.y, w1b[ct][2] = v.z, w1b[ct][3] = v.w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0][0]), "+v"(pv[0][1]), "+v"(pv[1][0]), "+v"(pv[1][1]), "+v"(pv[2][0]), "+v"(pv[2][1]), "+v"(pv[3][0]), "+v"(pv[3][1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 o[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int ct = 0; ct < 3; ++ct)
+                            o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[tt][pp][h], w1b[ct][2 * pp + h], o[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    if (16 * ct + n < 36) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st[(16 * tt + 4 * kq + j) * 36 + 16 * ct + n] = o[ct][j];
+                    }
+                }
+            }
+        }
+        }
+        WAVE_LDS_SYNC();
+        HSTAMP(8)
+        if (!(HB_DIAG & 1)) {
+            const long lim = (R - r0) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int e = lane + 64 * k;
+                const float4 v = st4[e];
+                if (e < lim) row_quad_st<BF>(dy, (size_t)r0, 36, e, v.x, v.y, v.z, v.w);
+            }
+        }
+        WAVE_LDS_SYNC();
+        HSTAMP(9)
+    }
+    // ---- the wave's weight-gradient image -> LDS, summed over the workgroup's waves, one atomic per element and workgroup
+    __syncthreads();
+    float* img_w = smem + wave * HB_WAVE_FLOATS;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const int col = 16 * ct + n;
+        if (col < 35) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) img_w[(4 * kq + j) * 35 + col] = dw1acc[ct][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * kq + j < 5) img_w[16 * 35 + (4 * kq + j) * 16 + n] = dw2acc[j];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float v = dsum[i];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0) img_w[16 * 35 + 5 * 16 + i] = v;
+    }
+    __syncthreads();
+    const int img = sn2_grad_image(rep_k, rep_stride);
+    for (int i = threadIdx.x; i < HB_RED; i += 256) {
+        const float v = (smem[i] + smem[HB_WAVE_FLOATS + i]) + (smem[2 * HB_WAVE_FLOATS + i] + smem[3 * HB_WAVE_FLOATS + i]);
         if (v == 0.f) continue;
-        const int img = sn2_grad_image(rep_k, rep_stride);
-        if (i < N2) {
-            const int o = i / 17, k = i - o * 17;
-            if (o < 5) SN2_FLUSH_ADD(k < 16 ? &dW2[img + o * 16 + k] : &db2[img + o], v);
+        if (i < 16 * 35) {
+            const int oo = i / 35, k = i - oo * 35;
+            SN2_FLUSH_ADD(k < 34 ? &dW1[img + oo * 34 + k] : &db1[img + oo], v);
+        } else if (i < 16 * 35 + 5 * 16) {
+            SN2_FLUSH_ADD(&dW2[img + (i - 16 * 35)], v);
         } else {
-            const int j = i - N2, o = j / 35, k = j - o * 35;
-            SN2_FLUSH_ADD(k < 34 ? &dW1[img + o * 34 + k] : &db1[img + o], v);
+            SN2_FLUSH_ADD(&db2[img + (i - 16 * 35 - 5 * 16)], v);
         }
     }
 }
@@ -2492,14 +2826,14 @@ extern "C" int sn2_fp_bn_sums(const sn2_fp* p, const float* gamma, const float* 
 extern "C" int sn2_head_backward(const sn2_head* p, void* stream) {
     SN2_TRY(check_head(p));
     if (!p->dy || !p->dW1 || !p->db1 || !p->dW2 || !p->db2) return SN2_EINVAL;
-    static_assert(OuterAcc<16, 17, 32>::LDS_FLOATS <= HEAD_BWD_LDS_FLOATS, "shared staging region");
-    constexpr size_t lds_bytes = (size_t)HEAD_BWD_LDS_FLOATS * 4 * (HEAD_BWD_THREADS / 64);
-    auto kb = p->act_bf16 ? &head_bwd_kernel<true> : &head_bwd_kernel<false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    int grid = pick_grid(p->R, HEAD_BWD_THREADS, 1);
-    if (grid > 1024 * grid_mult) grid = 1024 * grid_mult;
-    hipLaunchKernelGGL(kb, dim3(grid), dim3(HEAD_BWD_THREADS), lds_bytes, (hipStream_t)stream, p->R, p->f_stride, p->f,
-                       p->fa, p->fc, p->W1, p->b1, p->W2, p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2,
-                       p->db2, p->grad_replicas, p->grad_replica_stride, p->drop_mask, p->drop_mask ? p->drop_scale : 1.f);
+    constexpr size_t lds_m = ((size_t)HB_WAVE_FLOATS * 4 + HB_TAB_FLOATS) * 4;      // 79 136 bytes: two workgroups per CU
+    auto km = p->act_bf16 ? &head_bwd_mfma_kernel<true> : &head_bwd_mfma_kernel<false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(km), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    int gm = sn2_cdiv(sn2_cdiv(p->R, 64), 4);
+    const int cap = 2 * sn2_cu_count() * grid_mult;
+    if (gm > cap) gm = cap;
+    hipLaunchKernelGGL(km, dim3(gm), dim3(256), lds_m, (hipStream_t)stream, p->R, p->f, p->fa, p->fc, p->W1, p->b1, p->W2,
+                       p->b2, p->dcoverages, p->dproba, p->dy, p->dW1, p->db1, p->dW2, p->db2, p->grad_replicas,
+                       p->grad_replica_stride, p->drop_mask, p->drop_mask ? p->drop_scale : 1.f);
     SN2_RETURN_LAUNCH();
 }
