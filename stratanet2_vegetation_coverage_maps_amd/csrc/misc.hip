@@ -21,7 +21,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
     double acc = 0.0;
     if (training && g < G) {
         int k = g;
-        for (; k + 7 * G < nslots; k += 8 * G) {      // eight independent loads in flight, added in slot order
+        // all of a thread's loads in flight at once, added in slot order (1024 slots of 32 floats: 32 loads per thread; eight at
+        // a time were four dependent round trips to L2 / HBM, the kernel's whole duration)
+        for (; k + 31 * G < nslots; k += 32 * G) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = slots[(size_t)(k + u * G) * W2 + col];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += (double)v[u];
+        }
+        for (; k + 7 * G < nslots; k += 8 * G) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = slots[(size_t)(k + u * G) * W2 + col];

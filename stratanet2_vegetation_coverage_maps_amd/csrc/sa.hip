@@ -39,14 +39,14 @@ __global__ __launch_bounds__(256) void sa_bwd_prep_kernel(const float* __restric
     const int o = threadIdx.x % C, g = threadIdx.x / C, G = 256 / C;
     float sb = 0.f, sg = 0.f;
     const float mu = mean[o], is = invstd[o];
-    // four rows per turn, all twelve loads issued before the first use (one dependent arg -> dout, ext chain per row was
+    // eight rows per turn, all 24 loads issued before the first use (one dependent arg -> dout, ext chain per row was
     // 8 round trips = 9.6 us for 16 384 rows)
     const int step = gridDim.x * G;
-    for (int r0 = blockIdx.x * G + g; g < G && r0 < rows; r0 += 4 * step) {
-        int ar[4];
-        float dv[4], ev[4];
+    for (int r0 = blockIdx.x * G + g; g < G && r0 < rows; r0 += 8 * step) {
+        int ar[8];
+        float dv[8], ev[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int r = r0 + u * step;
             const size_t i = (size_t)(r < rows ? r : r0) * C + o;
             ar[u] = r < rows ? arg[i] : -1;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void sa_bwd_prep_kernel(const float* __restric
             ev[u] = ext[i];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
             if (ar[u] >= 0) {
                 sb += dv[u];
                 sg = fmaf(dv[u], (ev[u] - mu) * is, sg);
@@ -109,7 +109,8 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
     const sn2_block* last = &p->blk[NL - 1];
     const int rows = p->B * p->M, C = last->cout;
     int pb = sn2_cdiv(rows, 256 / C);
-    if (pb > 256) pb = 256;
+    static const int pb_cap = getenv("SN2_PREP_WGS") ? atoi(getenv("SN2_PREP_WGS")) : 256;      // (experiment switch)
+    if (pb > pb_cap) pb = pb_cap;
     hipLaunchKernelGGL(sa_bwd_prep_kernel, dim3(pb), dim3(256), 0, st, p->dout, p->ext, p->arg, last->mean, last->invstd,
                        rows, C, last->dgamma, last->dbeta);
     if constexpr (NL == 2) SN2_TRY((sa_mfma_launch_bwd<CF, NL, C1, C2, 2>(p, st)));
