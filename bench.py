@@ -412,6 +412,8 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
                       "fps_start": torch.zeros(n_fps, B, dtype=torch.int32, device=dev),
                       "gt": host["coverages"].to(dev), "pdf": host["pdf_all"].to(dev)})
 
+    seed = torch.ones((), dtype=torch.float64, device=dev)      # d loss / d loss, made once: `loss.backward()` fills a new one per step
+
     def feature_step(inp, geo=None):
         """zero_grad -> forward -> plot-wise projection -> loss -> backward (everything but exchange + Adam)"""
         opt.zero_grad(set_to_none=True)
@@ -421,7 +423,7 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
         cov, proba = model(cd)
         pred = project_to_plotwise_coverages(cov, inp["cloud"], args, geometry=geo)
         loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
-        loss.backward()
+        loss.backward(gradient=seed)
         return loss
 
     return SimpleNamespace(args=args, model=model, opt=opt, slots=slots, feature_step=feature_step, n_fps=n_fps,
@@ -832,6 +834,7 @@ def main():
     log(f"timed region: {elapsed / a.steps * 1e3:.3f} ms/step" + ("" if drain_ms is None else f" (of which the final drain: {drain_ms:.3f} ms in total)"))
     if pipe is not None:
         ops.fps_gave_up(dev)                     # (the region is over: reading the status word costs nothing now)
+        ops.global_level_gave_up(dev)
     loss_value = float(loss.item())
     if tdom is None:
         # graph replays / side streams cannot carry the event records: time the dominant entry point over 5 unpipelined

@@ -265,6 +265,25 @@ int sn2_plot_max_forward(const float *h, const float *a, const float *c, int B, 
                          int *arg, void *stream);
 int sn2_plot_max_backward(const float *dout, const int *arg, int B, int R_per_plot, int C, float *dy, void *stream);
 
+/* The reference architecture's global level in ONE launch, TRAINING mode (round 4): SA3 = MLP[35,64] on cat[x2, pos2]
+ * (model/point_net2.py:133, 37-42), its BatchNorm, the plot's max (:39), FP3 = MLP[96,64] on cat[plot feature, x2] (:137,
+ * 62-67) and its BatchNorm -- what sn2_fp_forward(sa3, 1), sn2_plot_max_forward and sn2_fp_forward(fp3, 1) do in five launches,
+ * with the same staging, tiles and per-64-row statistics; only the two BatchNorms' sums cross workgroups (one workgroup of 16
+ * waves per plot, 8-byte {tag, value} granules, every workgroup finalises the statistics itself in a fixed order).
+ *   sa3, fp3: the descriptors the separate calls take (sa3: ca 32, cb 3, no 3-NN table, src = x2 (B*M2,32), skip = pos2 (B*M2,4);
+ *             fp3: ca 64, cb 32, S_per_plot 1, src = x3, its 3-NN table, skip = x2; both cout 64, h_stride 64, fp32 operands);
+ *             blk.stat_slots is not used;  x3 (B,64), arg3 (B,64): the plot feature and the rows attaining it;
+ *   xchg: SN2_GLOBAL_XCHG_WORDS(B) 64-bit words and ctl: 2 words, BOTH ZERO-FILLED ONCE and then left to the library; launches
+ *         that share them must be on one stream.  ctl[1] counts waits that gave up (spin limit: a workgroup was not resident
+ *         within ~0.2 s): the statistics of that launch are WRONG -- read it where the host synchronises anyway and fail.
+ * SN2_ELIMIT for other shapes, bfloat16 operands or more than 28 plots: use the separate calls. */
+#define SN2_GLOBAL_XCHG_WORDS(B) ((size_t)2 * (size_t)(B) * 4 * 128)
+int sn2_global_level_forward(const sn2_fp *sa3, const sn2_fp *fp3, float *x3, int *arg3, unsigned long long *xchg,
+                             unsigned *ctl, void *stream);
+/* tests only: the sweeps (~1 us each, default 2^18; 0 = back to it) an exchange wait of sn2_global_level_forward makes before
+ * it gives up */
+int sn2_debug_global_spin_limit(unsigned sweeps);
+
 /* ---- pointwise head: lin1+ReLU, lin2, softmax/sigmoid/product -- model/point_net2.py:141-151 ----------------
  * f (R,34) pre-BN with affine (fa,fc); coverages (R,4), proba (R,4). */
 typedef struct sn2_head {

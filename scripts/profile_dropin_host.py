@@ -53,3 +53,39 @@ for it in range(14):
         for k in range(len(names)):
             acc[k] += (t[k + 1] - t[k]) * 1e3 / 10
 print("host ms per step by phase:", {n: round(a, 3) for n, a in zip(names, acc)}, "total", round(sum(acc), 3))
+if os.environ.get("SN2_CPROFILE"):
+    # where inside python: cProfile over ten more steps (forward + projection + backward only), top functions by own time
+    import cProfile, pstats
+    _ops.PinnedRing.upload = _up
+    pr = cProfile.Profile()
+    # the backward runs on the autograd engine's thread: profile it there
+    from stratanet2_vegetation_coverage_maps_amd import point_net2 as _pn
+    pb = cProfile.Profile()
+    _bw = _pn.PointNet2._backward_impl
+    def _bw_prof(self, s, dcov, dproba):
+        pb.enable()
+        try:
+            return _bw(self, s, dcov, dproba)
+        finally:
+            pb.disable()
+    _pn.PointNet2._backward_impl = _bw_prof
+    for it in range(10):
+        d = batches[it % 4]
+        gt = d["coverages"].cuda(dev)
+        opt.zero_grad(set_to_none=True)
+        pr.enable()
+        cov, proba = model({"cloud": d["cloud"], "xyz": d["xyz"]})
+        pred = project_to_plotwise_coverages(cov, d["cloud"], args)
+        pr.disable()
+        loss = losses.get_absolute_loss(pred, gt) + args.m * losses.get_NLL_loss(proba, d["pdf_all"].cuda(dev)) + args.e * losses.get_entropy_loss(proba)
+        pr.enable()
+        loss.backward()
+        pr.disable()
+        opt.step()
+        torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(25)
+    print("---- the network's backward (engine thread)")
+    pstats.Stats(pb).sort_stats("tottime").print_stats(25)
+    print("---- by cumulative time")
+    pstats.Stats(pb).sort_stats("cumtime").print_stats(25)

@@ -77,6 +77,8 @@ SIGNATURES = {
     "sn2_fp_backward": [POINTER(FP), c_void_p],
     "sn2_plot_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "sn2_plot_max_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sn2_global_level_forward": [POINTER(FP), POINTER(FP), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sn2_debug_global_spin_limit": [ctypes.c_uint],
     "sn2_head_forward": [POINTER(Head), c_void_p],
     "sn2_fp_head_eval": [POINTER(FP), POINTER(Head), c_void_p],
     "sn2_fp_bn_sums": [POINTER(FP), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

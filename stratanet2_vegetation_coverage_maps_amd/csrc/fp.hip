@@ -1363,6 +1363,394 @@ __global__ __launch_bounds__(256) void fp_fwd_split_kernel(int R, int R_per_plot
     }
 }
 
+// ---------------------------------------------------------------------------------------------- the global level, forward
+// SA3 (MLP[35,64] on cat[x2, pos2]) -> its BatchNorm -> the plot's max -> FP3 (MLP[96,64] on cat[plot feature, x2]) -> its
+// BatchNorm, TRAINING mode, in ONE launch (round 4).  As separate launches these are fp_fwd_split_kernel<32,3,64>, bn_finalize,
+// plot_max, fp_fwd_split_kernel<64,32,64>, bn_finalize: 30 us for 4096 rows of 64 channels, each launch a dependent round trip.
+// Here one workgroup of 16 waves owns a PLOT: four groups of four waves run the 64-row blocks of the split kernel side by
+// side (same staging, same tiles, same per-block statistics), the max of the plot and the plot feature never leave the
+// workgroup, and only the two BatchNorm statistics cross workgroups -- through 8-byte {tag, value} granules as the
+// multi-workgroup FPS exchanges its records (agent-scope relaxed stores and loads, the data is its own flag):
+//   every group publishes its 2 x 64 sums; after SA3 every workgroup sweeps all B x 4 x 128 granules until the tags match and
+//   finalises the statistics ITSELF (fp64, fixed order: the same a, c in every workgroup); after FP3 only workgroup 0 waits,
+//   finalises and writes the block's a, c, mean, invstd and running statistics (workgroup 0 does that for SA3 too).
+// The tag is (launch epoch, phase); the epoch lives in ctl[0] and is advanced by workgroup 0 at the very end (every workgroup
+// has read it before anyone can pass the first exchange).  Residency: B workgroups of 1024 threads; a wait is bounded
+// (spin_limit sweeps), a workgroup whose wait runs out counts it in ctl[1] and carries on with whatever it has (wrong
+// statistics, no hang): the host reads ctl[1] where it synchronises anyway (hip_ops.global_level_gave_up) and raises.
+#ifdef SN2_GL_STAMPS
+// diagnostic build only (never shipped): phase stamps of thread 0 of workgroup 0 of global_level_fwd_kernel
+__device__ unsigned long long g_gl_dbg[16];
+extern "C" int sn2_debug_gl_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gl_dbg), sizeof(g_gl_dbg));
+}
+#define GSTAMP(i)                                                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                                      \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        g_gl_dbg[i] = t_;                                                                           \
+    }
+#else
+#define GSTAMP(i)
+#endif
+typedef unsigned long long gl_u64;
+constexpr int GL_GROUPS = 4, GL_QS = OuterAcc<16, 36>::QS;       // 48: the staged rows [x2 (32) | pos2 (3) | 1] of SA3; FP3 reads the first 32
+constexpr int GL_W3 = 64 * 35 + 64, GL_WF = 64 * 96 + 64;         // the two layers' [W | bias], copied into LDS once per workgroup
+constexpr int GL_FIXED_FLOATS = GL_GROUPS * 64 * GL_QS + GL_GROUPS * 128 + 128 + 64 + 2 * 1024 + 2 * 8 * 128 + GL_W3 + GL_WF;
+constexpr int GL_MAX_PLOTS = 28;                                  // + B * 4 * 128 floats of collected granules: 155 KB at 28 plots
+static_assert((GL_FIXED_FLOATS + GL_MAX_PLOTS * GL_GROUPS * 128) * 4 <= 160 * 1024, "LDS");
+
+// one 64-row block of a split layer on a group of four waves: fp_fwd_split_kernel's tiles (wave g: output channels
+// [16 g, 16 g + 16)), accumulators started at `init`, rows past R_lim masked; adds the block's statistics of channel
+// 16 g + cc to (ssum, ssq); V: the block's outputs (row 16 t + 4 qq + j of the block, channel 16 g + cc) stay with the caller
+template <int KB>
+__device__ __forceinline__ void gl_block_tiles(const float* s_q, int QS, int lane, int g, long row0, long R_lim,
+                                               const float (&Wb)[KB], float init, float* __restrict__ h, int h_stride,
+                                               float& ssum, float& ssq, f32x4 (&V)[4]) {
+    const int qq = lane >> 4, cc = lane & 15, o = 16 * g + cc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) V[t] = f32x4{init, init, init, init};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            V[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_q[(16 * t + cc) * QS + 4 * kb + qq], Wb[kb], V[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long row = row0 + 16 * t + 4 * qq + j;
+            const float v = row < R_lim ? fmaxf(V[t][j], 0.f) : 0.f;
+            V[t][j] = v;
+            ssum += v;
+            ssq = fmaf(v, v, ssq);
+            if (row < R_lim) h[(size_t)row * h_stride + o] = v;
+        }
+}
+
+struct GlLayer {
+    const float *W, *bias, *gamma, *beta;
+    float *running_mean, *running_var, *a, *c, *mean, *invstd;
+    long long* nbt;
+    float* h;
+};
+struct GlArgs {
+    int B, M2;
+    const float* x2;        // (B*M2, 32)
+    const float* pos2;      // (B*M2, 4)
+    const int* knn_idx;     // FP3's table (B*M2, 3): every entry names the plot's one source
+    const float* knn_w;
+    float* x3;              // (B, 64)
+    int* arg3;
+    GlLayer sa3, fp3;
+    gl_u64* xchg;           // [2 phases][B * 4 groups][128]
+    unsigned* ctl;          // [0] epoch of the last finished launch, [1] waits that gave up (sticky)
+    unsigned spin_limit;
+};
+
+// all granules of a phase -> s_x (floats), every thread its share, eight loads in flight, swept until every tag matches (or
+// the limit runs out)
+__device__ __forceinline__ bool gl_collect(const gl_u64* gx, int n, unsigned tag, float* s_x, unsigned spin_limit) {
+    bool ok = true;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+        gl_u64 v[8];
+        unsigned spins = 0;
+        bool all;
+        do {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 1024;
+                v[u] = __hip_atomic_load(gx + (i < n ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            all = true;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) all = all && (unsigned)(v[u] >> 32) == tag;
+            if (!all) __builtin_amdgcn_s_sleep(2);
+        } while (!all && ++spins < spin_limit);
+        if (!all) ok = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < n) s_x[i0 + u * 1024] = __uint_as_float((unsigned)v[u]);
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8), g = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    float* s_q = gl_smem + grp * 64 * GL_QS;                     // the group's staged rows
+
+    float* s_red = gl_smem + GL_GROUPS * 64 * GL_QS;             // [4 groups][sum(64) | sumsq(64)]
+    float* s_ac = s_red + GL_GROUPS * 128;                       // a[64] | c[64] of SA3's BatchNorm
+    float* s_x3 = s_ac + 128;
+    float* s_mv = s_x3 + 64;                                     // [1024] the max's partial values ...
+    int* s_mi = reinterpret_cast<int*>(s_mv + 1024);             // ... and rows
+    double* s_d = reinterpret_cast<double*>(s_mi + 1024);        // [8][128] partial sums of a finalisation
+    float* s_w3 = reinterpret_cast<float*>(s_d + 8 * 128);       // SA3's [W (64 x 35) | bias (64)]
+    float* s_wf = s_w3 + GL_W3;                                  // FP3's [W (64 x 96) | bias (64)]
+    float* s_x = s_wf + GL_WF;                                   // [B * 4 * 128] the collected granules of an exchange
+    __shared__ unsigned s_epoch;
+    __shared__ int s_fail;
+    const int b = blockIdx.x, B = A.B, M2 = A.M2;
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(&A.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        s_fail = 0;
+    }
+    const long row_lo = (long)b * M2, R_lim = row_lo + M2;
+    const int nblk = (M2 + 63) >> 6, trips = (nblk + GL_GROUPS - 1) / GL_GROUPS;
+    const int qq = lane >> 4, cc = lane & 15, o = 16 * g + cc;
+    const int n_gran = B * GL_GROUPS * 128;
+    const double n_rows = (double)B * (double)M2;
+    __syncthreads();
+    const unsigned epoch = s_epoch;
+    // Both layers' weights come in once per workgroup, coalesced, and the lanes take their tile operands from LDS: sixteen
+    // waves each fetching their own (output, k) elements straight from memory were ~400 cache lines per wave through the CU's
+    // one address unit -- half of the kernel's first phase.
+    for (int i = tid; i < 64 * 35; i += 1024) s_w3[i] = A.sa3.W[i];
+    for (int i = tid; i < 64 * 96 / 4; i += 1024) reinterpret_cast<float4*>(s_wf)[i] = reinterpret_cast<const float4*>(A.fp3.W)[i];
+    if (tid < 64) s_w3[64 * 35 + tid] = A.sa3.bias[tid], s_wf[64 * 96 + tid] = A.fp3.bias[tid];
+    f32x4 V3[4];                                                 // SA3's outputs of the group's (last) block: the max reads them
+#pragma unroll
+    for (int t = 0; t < 4; ++t) V3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    GSTAMP(0)
+    // ================================================================ SA3: [x2 (32) | pos2 (3) | 1] -> 64
+    {
+        constexpr int CA = 32, CB = 3, CI = CA + CB, CK = CI + 1, KB = (CK + 3) / 4, QS = OuterAcc<16, CK>::QS;
+        float Wb[KB];
+        float ssum = 0.f, ssq = 0.f;
+        for (int it = 0; it < trips; ++it) {
+            const int blk = it * GL_GROUPS + grp;
+            const long r0 = row_lo + (long)blk * 64;
+            if (blk < nblk) {
+                stage_inputs<CA, CB, false>(s_q, QS, g, lane, r0, (int)R_lim, M2, M2, A.x2, 32, nullptr, nullptr, nullptr, nullptr,
+                                            A.pos2, 4);
+                if (g == 2) {
+#pragma unroll
+                    for (int k = CK; k < 4 * KB; ++k) s_q[lane * QS + k] = 0.f;
+                }
+            }
+            __syncthreads();
+            if (it == 0) {                       // (the weights' copy is complete behind the same barrier)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int k = 4 * kb + qq;
+                    Wb[kb] = k < CI ? s_w3[o * CI + k] : (k == CI ? s_w3[64 * CI + o] : 0.f);
+                }
+            }
+            if (blk < nblk) gl_block_tiles<KB>(s_q, QS, lane, g, r0, R_lim, Wb, 0.f, A.sa3.h, 64, ssum, ssq, V3);
+            __syncthreads();
+        }
+        ssum += __shfl_xor(ssum, 16);
+        ssq += __shfl_xor(ssq, 16);
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (qq == 0) {
+            s_red[grp * 128 + o] = ssum;
+            s_red[grp * 128 + 64 + o] = ssq;
+        }
+    }
+    __syncthreads();
+    GSTAMP(1)
+    // ---- publish the four groups' sums, collect everybody's, finalise SA3's BatchNorm (every workgroup for itself)
+    {
+        gl_u64* gx = A.xchg;
+        const unsigned tag = epoch * 2u + 0u;
+        if (tid < GL_GROUPS * 128)
+            __hip_atomic_store(gx + (size_t)b * GL_GROUPS * 128 + tid, ((gl_u64)tag << 32) | (gl_u64)__float_as_uint(s_red[tid]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!gl_collect(gx, n_gran, tag, s_x, A.spin_limit)) s_fail = 1;
+        __syncthreads();
+        GSTAMP(2)
+        {
+            // column col of the 128, sixteen threads each: partial sums over every sixteenth publisher, then the sixteen in order
+            const int col = tid & 127, part = tid >> 7;          // 8 parts x 128 columns
+            double acc = 0.0;
+            for (int w = part; w < B * GL_GROUPS; w += 8) acc += (double)s_x[w * 128 + col];
+            s_d[part * 128 + col] = acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int part = 0; part < 8; ++part) s1 += s_d[part * 128 + tid], s2 += s_d[part * 128 + 64 + tid];
+            float aa, cc2, mean, invstd;
+            sn2_bn_from_sums(s1, s2, n_rows, A.sa3.gamma[tid], A.sa3.beta[tid], b == 0 ? &A.sa3.running_mean[tid] : nullptr,
+                             b == 0 ? &A.sa3.running_var[tid] : nullptr, aa, cc2, mean, invstd);
+            s_ac[tid] = aa;
+            s_ac[64 + tid] = cc2;
+            if (b == 0) {
+                A.sa3.a[tid] = aa, A.sa3.c[tid] = cc2, A.sa3.mean[tid] = mean, A.sa3.invstd[tid] = invstd;
+                if (tid == 0 && A.sa3.nbt) *A.sa3.nbt += 1;
+            }
+        }
+        __syncthreads();
+    }
+    GSTAMP(3)
+    // ================================================================ the plot's max of a h + c (first row wins ties)
+    if (trips == 1) {
+        // the group's block is still in registers (V3[t][j]: row 16 t + 4 qq + j of block grp, channel o): rows in ascending
+        // order per lane, then the four row quarters (qq) of the channel, then the four groups -- ties to the lower row
+        const float aa = s_ac[o], cc2 = s_ac[64 + o];
+        float best = -INFINITY;
+        int bi = 0x7FFFFFFF;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = grp * 64 + 16 * t + 4 * qq + j;
+                const float y = fmaf(aa, V3[t][j], cc2);
+                if (r < M2 && y > best) best = y, bi = r;
+            }
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            const float v = __shfl_xor(best, m);
+            const int i = __shfl_xor(bi, m);
+            if (v > best || (v == best && i < bi)) best = v, bi = i;
+        }
+        if (qq == 0) s_mv[grp * 64 + o] = best, s_mi[grp * 64 + o] = bi;
+        __syncthreads();
+        if (tid < 64) {
+            best = s_mv[tid], bi = s_mi[tid];
+            for (int k2 = 1; k2 < GL_GROUPS; ++k2) {
+                const float v = s_mv[k2 * 64 + tid];
+                const int i = s_mi[k2 * 64 + tid];
+                if (v > best || (v == best && i < bi)) best = v, bi = i;
+            }
+            A.x3[(size_t)b * 64 + tid] = best;
+            A.arg3[(size_t)b * 64 + tid] = bi;
+            s_x3[tid] = best;
+        }
+        __syncthreads();
+    } else {
+        const int ch = tid & 63, rg = tid >> 6;                  // 16 row groups
+        const float aa = s_ac[ch], cc2 = s_ac[64 + ch];
+        float best = -INFINITY;
+        int bi = 0x7FFFFFFF;
+        const float* hb = A.sa3.h + (size_t)row_lo * 64 + ch;
+        int r = rg;
+        for (; r + 7 * 16 < M2; r += 8 * 16) {                   // eight row loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = hb[(size_t)(r + u * 16) * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float y = fmaf(aa, v[u], cc2);
+                if (y > best) best = y, bi = r + u * 16;
+            }
+        }
+        for (; r < M2; r += 16) {
+            const float y = fmaf(aa, hb[(size_t)r * 64], cc2);
+            if (y > best) best = y, bi = r;
+        }
+        s_mv[tid] = best;
+        s_mi[tid] = bi;
+        __syncthreads();
+        if (tid < 64) {
+            for (int k2 = 1; k2 < 16; ++k2) {
+                const float v = s_mv[k2 * 64 + ch];
+                const int i = s_mi[k2 * 64 + ch];
+                if (v > best || (v == best && i < bi)) best = v, bi = i;
+            }
+            A.x3[(size_t)b * 64 + ch] = best;
+            A.arg3[(size_t)b * 64 + ch] = bi;
+            s_x3[ch] = best;
+        }
+        __syncthreads();
+    }
+    GSTAMP(4)
+    // ================================================================ FP3: [plot feature (64) | x2 (32) | 1] -> 64
+    {
+        // Every row of the plot interpolates the plot's ONE source: the 64 interpolated inputs are the plot feature x3[b] for
+        // all of them (knn_interpolate with k = 1: x w / w), so their part of the layer is one vector per plot,
+        // pv = b + W[:, 0:64] x3[b], and the rows contract their 32 skip channels only -- 8 k-steps instead of 25 and no
+        // dependent gather in the staging.  (The separate kernel rebuilds x w / w per row: equal to x3 to an ulp.)
+        constexpr int CA = 64, CB = 32, CI = CA + CB, KB = CB / 4, QS = OuterAcc<16, 36>::QS;
+        float* s_pv = s_mv;                                      // [64]
+        {
+            const int oo = tid >> 4, part = tid & 15;            // output oo, inputs 4 part .. 4 part + 3
+            const float4 w4 = *reinterpret_cast<const float4*>(s_wf + oo * CI + 4 * part);
+            const float4 u4 = *reinterpret_cast<const float4*>(s_x3 + 4 * part);
+            float acc = ((w4.x * u4.x + w4.y * u4.y) + w4.z * u4.z) + w4.w * u4.w;
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+            if (part == 0) s_pv[oo] = acc + s_wf[64 * CI + oo];
+        }
+        float Wb[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) Wb[kb] = s_wf[o * CI + CA + 4 * kb + qq];
+        float ssum = 0.f, ssq = 0.f;
+        f32x4 Vf[4];
+        for (int it = 0; it < trips; ++it) {
+            const int blk = it * GL_GROUPS + grp;
+            const long r0 = row_lo + (long)blk * 64;
+            if (blk < nblk && trips > 1) {
+                // the skip rows: eight lanes per row, one float4 each; 32 rows per pass of the group's 256 threads
+                // (one trip: the group's tile still holds them -- SA3 staged x2 into the same columns, row stride QS)
+                const int t256 = tid & 255;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int row = pass * 32 + (t256 >> 3), q8 = t256 & 7;
+                    const long r = r0 + row;
+                    const size_t rr = r < R_lim ? (size_t)r : (size_t)(R_lim - 1);
+                    *reinterpret_cast<float4*>(&s_q[row * QS + 4 * q8]) = reinterpret_cast<const float4*>(A.x2 + rr * 32)[q8];
+                }
+            }
+            __syncthreads();
+            if (blk < nblk) gl_block_tiles<KB>(s_q, QS, lane, g, r0, R_lim, Wb, s_pv[o], A.fp3.h, 64, ssum, ssq, Vf);
+            __syncthreads();
+        }
+        ssum += __shfl_xor(ssum, 16);
+        ssq += __shfl_xor(ssq, 16);
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (qq == 0) {
+            s_red[grp * 128 + o] = ssum;
+            s_red[grp * 128 + 64 + o] = ssq;
+        }
+    }
+    __syncthreads();
+    GSTAMP(5)
+    {
+        gl_u64* gx = A.xchg + n_gran;
+        const unsigned tag = epoch * 2u + 1u;
+        if (tid < GL_GROUPS * 128)
+            __hip_atomic_store(gx + (size_t)b * GL_GROUPS * 128 + tid, ((gl_u64)tag << 32) | (gl_u64)__float_as_uint(s_red[tid]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != 0) {
+            if (tid == 0 && s_fail) atomicAdd(&A.ctl[1], 1u);
+            return;
+        }
+        if (!gl_collect(gx, n_gran, tag, s_x, A.spin_limit)) s_fail = 1;
+        __syncthreads();
+        GSTAMP(6)
+        {
+            const int col = tid & 127, part = tid >> 7;
+            double acc = 0.0;
+            for (int w = part; w < B * GL_GROUPS; w += 8) acc += (double)s_x[w * 128 + col];
+            s_d[part * 128 + col] = acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int part = 0; part < 8; ++part) s1 += s_d[part * 128 + tid], s2 += s_d[part * 128 + 64 + tid];
+            float aa, cc2, mean, invstd;
+            sn2_bn_from_sums(s1, s2, n_rows, A.fp3.gamma[tid], A.fp3.beta[tid], &A.fp3.running_mean[tid], &A.fp3.running_var[tid],
+                             aa, cc2, mean, invstd);
+            A.fp3.a[tid] = aa, A.fp3.c[tid] = cc2, A.fp3.mean[tid] = mean, A.fp3.invstd[tid] = invstd;
+            if (tid == 0 && A.fp3.nbt) *A.fp3.nbt += 1;
+        }
+        __syncthreads();
+        GSTAMP(7)
+        if (tid == 0) {
+            if (s_fail) atomicAdd(&A.ctl[1], 1u);
+            __hip_atomic_store(&A.ctl[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 #ifdef SN2_SPLIT_STAMPS
 // diagnostic build only (never shipped): phase stamps of thread 0 of one workgroup of fp_bwd_split_kernel<64, 32, 64>
 __device__ unsigned long long g_split_dbg[16];
@@ -2764,6 +3152,51 @@ int check_head(const sn2_head* p) {
 }
 
 }  // namespace
+
+// sweeps (~1 us each) before an exchange wait of global_level_fwd_kernel gives up; tests shorten it to provoke a give-up
+static unsigned g_gl_spin_limit = 1u << 18;
+extern "C" int sn2_debug_global_spin_limit(unsigned sweeps) {       // (0 = back to the default)
+    g_gl_spin_limit = sweeps ? sweeps : (1u << 18);
+    return 0;
+}
+
+extern "C" int sn2_global_level_forward(const sn2_fp* sa3, const sn2_fp* fp3, float* x3, int* arg3, unsigned long long* xchg,
+                                        unsigned* ctl, void* stream) {
+    if (!sa3 || !fp3 || !x3 || !arg3 || !xchg || !ctl) return SN2_EINVAL;
+    const int B = sa3->B, M2 = sa3->R_per_plot;
+    // the two layers of the reference architecture's global level, fp32, training mode (both BatchNorms take batch statistics)
+    if (!(B > 0 && M2 > 0 && fp3->B == B && fp3->R_per_plot == M2 && sa3->S_per_plot == M2 && fp3->S_per_plot == 1)) return SN2_EINVAL;
+    if (!(sa3->ca == 32 && sa3->cb == 3 && sa3->blk.cin == 35 && sa3->blk.cout == 64 && fp3->ca == 64 && fp3->cb == 32 &&
+          fp3->blk.cin == 96 && fp3->blk.cout == 64))
+        return SN2_ELIMIT;
+    if (sa3->blk.mma_bf16 || fp3->blk.mma_bf16 || sa3->act_bf16 || fp3->act_bf16) return SN2_ELIMIT;
+    if (sa3->knn_idx || sa3->src_a || !fp3->knn_idx || !fp3->knn_w || fp3->src_a) return SN2_EINVAL;
+    if (!sa3->src || sa3->src_stride != 32 || !sa3->skip || sa3->skip_stride != 4 || !sa3->h || sa3->h_stride != 64) return SN2_EINVAL;
+    if (fp3->src != x3 || fp3->src_stride != 64 || fp3->skip != sa3->src || fp3->skip_stride != 32 || !fp3->h || fp3->h_stride != 64)
+        return SN2_EINVAL;
+    if (B > GL_MAX_PLOTS || (long)B * M2 >= (1L << 31) / 64) return SN2_ELIMIT;
+    for (const sn2_block* k : {&sa3->blk, &fp3->blk})
+        if (!k->W || !k->b || !k->gamma || !k->beta || !k->running_mean || !k->running_var || !k->a || !k->c || !k->mean || !k->invstd)
+            return SN2_EINVAL;
+    GlArgs A;
+    A.B = B, A.M2 = M2;
+    A.x2 = sa3->src, A.pos2 = sa3->skip, A.knn_idx = fp3->knn_idx, A.knn_w = fp3->knn_w, A.x3 = x3, A.arg3 = arg3;
+    auto layer = [](const sn2_fp* p) {
+        GlLayer l;
+        l.W = p->blk.W, l.bias = p->blk.b, l.gamma = p->blk.gamma, l.beta = p->blk.beta;
+        l.running_mean = p->blk.running_mean, l.running_var = p->blk.running_var;
+        l.a = p->blk.a, l.c = p->blk.c, l.mean = p->blk.mean, l.invstd = p->blk.invstd;
+        l.nbt = p->blk.num_batches_tracked, l.h = p->h;
+        return l;
+    };
+    A.sa3 = layer(sa3), A.fp3 = layer(fp3);
+    A.xchg = xchg, A.ctl = ctl;
+    A.spin_limit = g_gl_spin_limit;
+    const size_t lds = ((size_t)GL_FIXED_FLOATS + (size_t)B * GL_GROUPS * 128) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&global_level_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(global_level_fwd_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, A);
+    SN2_RETURN_LAUNCH();
+}
 
 extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     SN2_TRY(check_head(p));

@@ -50,29 +50,20 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
             s2 += s_part[gg * W2 + C + o];
         }
     }
-    const int j = 0;
-    const float eps = 1e-5f, mom = 0.1f;
-    if (!live || j != 0) return;
+    if (!live) return;
     if (training && o == 0 && num_batches_tracked) *num_batches_tracked += 1;   // BatchNorm1d's counter: once per training forward
-    float mean, invstd;
+    float mean, invstd, aa, cc;
     if (training) {
-        double n = count_dev ? (double)(*count_dev) : (double)count_imm;
-        if (n < 1.0) n = 1.0;
-        const double m = s1 / n;
-        double var = s2 / n - m * m;
-        if (var < 0.0) var = 0.0;
-        mean = (float)m;
-        invstd = 1.0f / sqrtf((float)var + eps);
-        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-        running_mean[o] = (1.f - mom) * running_mean[o] + mom * mean;
-        running_var[o] = (1.f - mom) * running_var[o] + mom * (float)unbiased;
+        const double n = count_dev ? (double)(*count_dev) : (double)count_imm;
+        sn2_bn_from_sums(s1, s2, n, gamma[o], beta[o], &running_mean[o], &running_var[o], aa, cc, mean, invstd);
     } else {
         mean = running_mean[o];
-        invstd = 1.0f / sqrtf(running_var[o] + eps);
+        invstd = 1.0f / sqrtf(running_var[o] + 1e-5f);
+        aa = gamma[o] * invstd;
+        cc = beta[o] - mean * aa;
     }
-    const float aa = gamma[o] * invstd;
     a[o] = aa;
-    c[o] = beta[o] - mean * aa;
+    c[o] = cc;
     mean_out[o] = mean;
     invstd_out[o] = invstd;
 }

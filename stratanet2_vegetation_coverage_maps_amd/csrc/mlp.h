@@ -57,6 +57,27 @@ __device__ __forceinline__ f32x4 contract(f32x4 acc, FA a, FB b) {
 
 // out[o] = (relu) ( b[o] + sum_k W[o*CI+k] * in[k] ).  W, b are wave-uniform constant-address-space pointers (common.h):
 // the loads are s_load_dwordx* and the FMAs take SGPR operands.
+// ---- BatchNorm1d from the sums of a batch (torch defaults: eps 1e-5, momentum 0.1, biased variance to normalise, unbiased
+// variance into running_var -- model/point_net2.py:45-53): one channel.  Used by bn_finalize_kernel (misc.hip) and by the
+// kernels that finalise their own statistics (fp.hip: global_level_fwd_kernel).
+__device__ __forceinline__ void sn2_bn_from_sums(double s1, double s2, double n, float gamma, float beta, float* running_mean,
+                                                 float* running_var, float& a, float& c, float& mean, float& invstd) {
+    const float eps = 1e-5f, mom = 0.1f;
+    if (n < 1.0) n = 1.0;
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    invstd = 1.0f / sqrtf((float)var + eps);
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    if (running_mean) {
+        *running_mean = (1.f - mom) * *running_mean + mom * mean;
+        *running_var = (1.f - mom) * *running_var + mom * (float)unbiased;
+    }
+    a = gamma * invstd;
+    c = beta - mean * a;
+}
+
 template <int CI, int CO, bool RELU>
 __device__ __forceinline__ void dense(cfp W, cfp b, const float (&in)[CI], float (&out)[CO]) {
 #pragma unroll

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import FP, SA, Block, Head, check
+from ._lib import FP, SA, Block, Head, StrataHipError, check
 
 I32, F32, F64, I64, BF16 = torch.int32, torch.float32, torch.float64, torch.int64, torch.bfloat16
 
@@ -731,6 +731,51 @@ def plot_max_forward(h, a, c, B, R_per_plot, C):
     arg = torch.empty(B, C, dtype=I32, device=h.device)
     _call("sn2_plot_max_forward", _ptr(h), _ptr(a), _ptr(c), B, R_per_plot, C, _ptr(out), _ptr(arg), _stream())
     return out, arg
+
+
+_GLOBAL_WS = {}          # device index -> [exchange granules (int64), control words (int32), give-ups seen]
+
+
+def global_level_ws(dev, B: int):
+    """The exchange area and control words of `global_level_forward` on this device (zero-filled once, then the library's).
+    One per device: launches that use it are on one stream at a time (the feature pass's)."""
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    need = 2 * B * 4 * 128
+    ws = _GLOBAL_WS.get(key)
+    if ws is None or ws[0].numel() < need:
+        ws = [torch.zeros(max(need, 2 * 16 * 4 * 128), dtype=I64, device=dev), torch.zeros(2, dtype=I32, device=dev), 0]
+        _GLOBAL_WS[key] = ws
+    return ws
+
+
+def global_level_forward(d_sa3: FP, d_fp3: FP, x3: torch.Tensor, arg3: torch.Tensor):
+    """SA3 -> BatchNorm -> plot max -> FP3 -> BatchNorm in one launch (training mode; include/strata_hip.h).  d_fp3 must have
+    been built with src = x3."""
+    B = d_sa3.B
+    _chk(x3, F32, (B, 64), "x3")
+    _chk(arg3, I32, (B, 64), "arg3")
+    ws = global_level_ws(x3.device, B)
+    _call("sn2_global_level_forward", d_sa3, d_fp3, _ptr(x3), _ptr(arg3), _ptr(ws[0]), _ptr(ws[1]), _stream())
+
+
+def global_level_gave_up(dev) -> int:
+    """Exchange waits of `global_level_forward` that gave up on this device since the process started (a workgroup of the
+    launch was not resident within the spin limit: another process held the device).  The statistics of such a launch are
+    wrong: RAISES when the count grew since the last call.  Reads one device word: call it where the host synchronises anyway
+    (TrainPipeline.drain, after a test); `PointNet2.fuse_global_level = False` runs the level as separate launches."""
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _GLOBAL_WS.get(key)
+    if ws is None:
+        return 0
+    n = int(ws[1][1].item())
+    if n > ws[2]:
+        seen, ws[2] = ws[2], n
+        raise StrataHipError(f"global_level_forward: {n - seen} exchange wait(s) gave up on {dev}: the BatchNorm statistics of "
+                             "those training steps are wrong (the launch's workgroups were not resident together); set "
+                             "PointNet2.fuse_global_level = False where other processes share the device")
+    return n
 
 
 def plot_max_backward(dout, arg, B, R_per_plot, C, dy):

@@ -265,3 +265,4 @@ class TrainPipeline:
             torch.cuda.current_stream(self.dev).wait_stream(st)
         if check:
             ops.fps_gave_up(self.dev)
+            ops.global_level_gave_up(self.dev)      # (raises: the fused global level's statistics exchange gave up)

@@ -169,6 +169,9 @@ class PointNet2(nn.Module):
     fps_waves_many = int(os.environ.get("SN2_FPS_WAVES_MANY", "4"))
     geometry_fork = True       # `_geometry`: the three independent chains behind the level-1 FPS on three streams
     fuse_eval_head = os.environ.get("SN2_FUSE_EVAL_HEAD", "1") == "1"     # eval: FP1 + head in one kernel (sn2_fp_head_eval)
+    # training: SA3, its BatchNorm, the plot max, FP3 and its BatchNorm in one launch (sn2_global_level_forward) instead of five;
+    # its workgroups exchange the batch statistics among themselves -- False where other processes share the device
+    fuse_global_level = os.environ.get("SN2_FUSE_GLOBAL_LEVEL", "1") == "1"
     # additive: a geometry pass that is handed the batch's `cloud` also does the two INPUT-only pieces of the feature pass --
     # the level-0 rows (`sn2_pack_rows`: 12 us of the step's critical path at C2) and, when `p2_diam_pix` is set (to
     # args.diam_pix), the pixel ids of `project_to_plotwise_coverages` (project_to_2d.py:16-22: a function of x, y only; 10 us) --
@@ -578,13 +581,19 @@ class PointNet2(nn.Module):
         ops.sa_forward(self._sa2_desc(s), training)
         # ---- SA3: MLP[35,64] on cat[x2, pos2] -> per-plot max                    (:133, 37-42)
         s.h_sa3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
-        ops.fp_forward(self._sa3_desc(s), training)
-        s.x3, s.arg3 = ops.plot_max_forward(s.h_sa3, s.b_sa3.a, s.b_sa3.c, B, M2, 64)
+        s.h3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
+        if training and self.fuse_global_level and B <= 28 and not (s.b_sa3.mma_bf16 or s.b_fp3.mma_bf16):
+            # ... and its max, FP3 (k=1 from the plot's global feature) and both BatchNorms: one launch  (:133-137)
+            s.x3 = torch.empty(B, 64, dtype=F32, device=dev)
+            s.arg3 = torch.empty(B, 64, dtype=I32, device=dev)
+            ops.global_level_forward(self._sa3_desc(s), self._fp3_desc(s), s.x3, s.arg3)
+        else:
+            ops.fp_forward(self._sa3_desc(s), training)
+            s.x3, s.arg3 = ops.plot_max_forward(s.h_sa3, s.b_sa3.a, s.b_sa3.c, B, M2, 64)
+            # ---- FP3 (k=1 from the plot's global feature at the origin), FP2, FP1 (k=3)   (:137-139, 62-67)
+            ops.fp_forward(self._fp3_desc(s), training)
         if self.log_embeddings:
             self.last_G_tensor = s.x3
-        # ---- FP3 (k=1 from the plot's global feature at the origin), FP2, FP1 (k=3)   (:137-139, 62-67)
-        s.h3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
-        ops.fp_forward(self._fp3_desc(s), training)
         s.h2 = torch.empty(B * M1, 36, dtype=F32, device=dev)
         ops.fp_forward(self._fp2_desc(s), training)
         if join is not None:

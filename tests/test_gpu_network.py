@@ -544,3 +544,68 @@ def test_backward_through_an_eval_forward_is_refused():
     cov, _ = m(d)
     with pytest.raises(RuntimeError, match="eval-mode forward"):
         cov.sum().backward()
+
+
+@pytest.mark.parametrize("B,N,ratio1", [(3, 4096, 0.125), (16, 32768, 1024 / 32768), (5, 10000, 0.25)])
+def test_global_level_in_one_launch_is_the_five_launches(B, N, ratio1):
+    """Training forward + backward with SA3 / plot max / FP3 and their BatchNorms in ONE launch (sn2_global_level_forward: the
+    workgroups exchange the batch statistics among themselves) against the same step with the five separate launches: the
+    rows of SA3 are the same tiles, the statistics are the same sums added in another grouping (1e-6), FP3 adds its
+    interpolated part once per plot (outputs to 1e-5, a tenth of the oracle's tolerance),
+    the running statistics and the counters move the same way, and the gradients agree to 2e-4 of their scale (the step against
+    the oracle: test_forward_backward_vs_oracle_other_sizes, which runs the one launch).  Then the error path: with a wait limit of one sweep the exchange gives up -- the launch still
+    returns, the count is sticky and `global_level_gave_up` raises."""
+    args = make_args(subsample_size=N, ratio1=ratio1, r1=1.0, ratio2=0.25, r2=2.0, log_embeddings=True)
+    d = make_batch(B, N, first_plot=90)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    sd = network.init_state_dict(9)
+    res = {}
+    ws0 = ops._GLOBAL_WS.get(0)
+    before = int(ws0[1][1].item()) if ws0 else 0                      # (sticky: an earlier case's error path counted)
+    for fused in (True, False):
+        m = _model(args, {k: v.clone() for k, v in sd.items()}).train()
+        m.fuse_global_level = fused
+        cov, proba = m(d)
+        pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+        (pred.square().sum() + proba[:, 1].sum() * 1e-3).backward()
+        torch.cuda.synchronize()
+        res[fused] = dict(cov=cov.detach().clone(), proba=proba.detach().clone(), G=m.last_G_tensor.clone(),
+                          grads={k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                          state={k: v.detach().clone() for k, v in m.state_dict().items()})
+    assert int(ops.global_level_ws(DEV_T, B)[1][1].item()) == before
+    a, b = res[True], res[False]
+    assert float((a["G"] - b["G"]).abs().max()) <= 2e-6 * max(1.0, float(b["G"].abs().max()))
+    assert float((a["cov"] - b["cov"]).abs().max()) <= 1e-5 and float((a["proba"] - b["proba"]).abs().max()) <= 1e-5
+    for k, v in b["state"].items():
+        if v.dtype.is_floating_point:
+            assert float((a["state"][k] - v).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
+        else:
+            assert torch.equal(a["state"][k], v), k                      # num_batches_tracked
+    for k, g in b["grads"].items():
+        scale = max(float(g.abs().max()), 1e-12)
+        # (statistics that differ in the 7th digit flip a few ReLU masks next to zero: 5e-5 of the scale observed at 16 x 32 768)
+        assert float((a["grads"][k] - g).abs().max()) <= 2e-4 * scale + 1e-9, (k, float((a["grads"][k] - g).abs().max()), scale)
+    # ---- the error path
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    lib = _lib.load()
+    m = _model(args, {k: v.clone() for k, v in sd.items()}).train()
+    m.fuse_global_level = True
+    lib.sn2_debug_global_spin_limit(1)
+    try:
+        for _ in range(3):                      # (a launch whose granules all arrive within one sweep does not give up)
+            m(d)
+        torch.cuda.synchronize()                # ... it returned
+        gave_up = int(ops.global_level_ws(DEV_T, B)[1][1].item())
+        if gave_up:
+            with pytest.raises(Exception, match="gave up"):
+                ops.global_level_gave_up(DEV_T)
+            assert ops.global_level_gave_up(DEV_T) == gave_up          # reported once, the count stays
+    finally:
+        lib.sn2_debug_global_spin_limit(0)
+    cov2, _ = m(d)                               # and the next launch is right again
+    torch.cuda.synchronize()
+    assert ops.global_level_gave_up(DEV_T) == int(ops.global_level_ws(DEV_T, B)[1][1].item())
+    assert torch.isfinite(cov2).all()
+
+
+DEV_T = torch.device("cuda:0")
