@@ -59,7 +59,10 @@ K["fp_bwd_rows_kernel<34, 8, 34, 512, false>"] = ("FP1 backward, row pass", (288
 K["fp_bwd_src_chunk_kernel<34, 8, 34, false>"] = ("FP1 backward, source pass (rows gathered through the chunked inverted index)", (24 + 136) * R, 2 * 136 * R, 0)
 K["fp_bwd_src_merge_dw_kernel<34, 8, 34>"] = ("FP1 backward, partial rows -> G, dsrc, dW_A", (144 + 144 + 136 + 2 * 136) * M1 * B, None, 0)
 K["head_fwd_mfma_kernel<false>"] = ("head forward (lin1, lin2 on the matrix cores)", (144 + 32) * R, None, 2 * (16 * 35 + 5 * 17) * R)
-K["head_bwd_kernel<false>"] = ("head backward", (144 + 32 + 144) * R, None, 2 * (16 * 35 + 16 * 17) * R)
+K["head_bwd_mfma_kernel<false>"] = ("head backward (six contractions on the matrix cores)", (144 + 32 + 144) * R, None,
+                                     2 * (34 * 16 + 16 * 5 + 5 * 16 + 16 * 34 + 16 * 35 + 5 * 17) * R)
+K["global_level_fwd_kernel"] = ("global level forward: SA3, BatchNorm, plot max, FP3, BatchNorm in one launch",
+                                (128 + 16 + 256 + 256) * M2 * B, None, 2 * (35 * 64 + 33 * 64) * M2 * B)
 K["three_nn_grid_kernel"] = ("3-NN of the N points among the level-1 centroids", 16 * R + 16 * M1 * B + 24 * R, None, 0)
 K["pack_rows_kernel"] = ("row packing", (44 + 48) * R, None, 0)
 
