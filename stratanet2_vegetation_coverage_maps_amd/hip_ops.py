@@ -744,6 +744,10 @@ def global_level_ws(dev, B: int):
     need = 2 * B * 4 * 128
     ws = _GLOBAL_WS.get(key)
     if ws is None or ws[0].numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            # zero fills captured into a graph would run at every replay and reset the launch epoch under the other graphs
+            raise StrataHipError("global_level_forward: its exchange area must exist before a stream capture starts -- run one "
+                                 "eager training forward first (TrainPipeline.capture does) or call hip_ops.global_level_ws(dev, B)")
         ws = [torch.zeros(max(need, 2 * 16 * 4 * 128), dtype=I64, device=dev), torch.zeros(2, dtype=I32, device=dev), 0]
         _GLOBAL_WS[key] = ws
     return ws
