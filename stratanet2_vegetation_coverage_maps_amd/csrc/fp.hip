@@ -2046,7 +2046,8 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
             if (grid > cap_fwd_rows) grid = cap_fwd_rows;
             // (round 4: a variant with the plot's whole table in LDS -- 144 KB, one 16-wave workgroup per CU, the 226 MB of L2
             // gathers replaced by ds_read_b128 -- ran in 38.1 us against this kernel's 36.5: the gathers are not its bound; at
-            // ~14 instructions per row and wave-instruction it is instruction issue, like the head kernels)
+            // ~14 instructions per row and wave-instruction it is instruction issue, like the head kernels; the skip part's FMA
+            // chains as v_pk_fma_f32 pairs -- 32 instructions fewer per two rows -- ran in 38.0 us as well)
             auto kr = p->act_bf16 ? &fp_fwd_rows_kernel<CA, CB, CO, true> : &fp_fwd_rows_kernel<CA, CB, CO, false>;
             hipLaunchKernelGGL(kr, dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
                                p->skip_stride, (const float*)p->src_ws, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.b, p->h,
