@@ -109,8 +109,7 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
     const sn2_block* last = &p->blk[NL - 1];
     const int rows = p->B * p->M, C = last->cout;
     int pb = sn2_cdiv(rows, 256 / C);
-    static const int pb_cap = getenv("SN2_PREP_WGS") ? atoi(getenv("SN2_PREP_WGS")) : 256;      // (experiment switch)
-    if (pb > pb_cap) pb = pb_cap;
+    if (pb > 256) pb = 256;      // (fewer workgroups = fewer same-address atomics, but slower: 8.7 / 9.8 / 16 us at 256 / 64 / 32)
     hipLaunchKernelGGL(sa_bwd_prep_kernel, dim3(pb), dim3(256), 0, st, p->dout, p->ext, p->arg, last->mean, last->invstd,
                        rows, C, last->dgamma, last->dbeta);
     if constexpr (NL == 2) SN2_TRY((sa_mfma_launch_bwd<CF, NL, C1, C2, 2>(p, st)));
