@@ -609,3 +609,23 @@ def test_global_level_in_one_launch_is_the_five_launches(B, N, ratio1):
 
 
 DEV_T = torch.device("cuda:0")
+
+
+def test_global_level_exchange_area_is_not_allocated_inside_a_capture():
+    """The exchange area of the fused global level holds the launch epoch: zero fills captured into a graph would reset it at
+    every replay, under the other graphs' feet.  `hip_ops.global_level_ws` refuses to allocate while a stream is capturing
+    (TrainPipeline warms every slot eagerly first; this is for hosts that capture on their own)."""
+    saved = dict(ops._GLOBAL_WS)
+    ops._GLOBAL_WS.clear()
+    try:
+        g = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            with pytest.raises(Exception, match="before a stream capture"):
+                with torch.cuda.graph(g, stream=st):
+                    ops.global_level_ws(DEV_T, 4)
+        torch.cuda.synchronize()
+        assert ops.global_level_ws(DEV_T, 4)[0].numel() >= 2 * 4 * 4 * 128          # outside a capture: fine
+    finally:
+        ops._GLOBAL_WS.clear()
+        ops._GLOBAL_WS.update(saved)
