@@ -579,7 +579,8 @@ def inference_leg(dev, plots=2048, points=10000, batch=512, repeat=3, prefetch=3
 def dropin_eager_leg(dev, B, n_points, steps=10, warmup=3):
     """The drop-in as a user of the reference would run it: the loop of /root/reference/learning/train.py:46-66 -- CPU-resident
     batches as the DataLoader collates them, `model(cloud_data)` (which uploads them), `project_to_plotwise_coverages`, the
-    three loss terms as plain torch ops, `loss.backward()`, `torch.optim.Adam.step()`, the three `.item()` reads -- eager, no
+    three loss terms called one by one as the reference does (`losses.get_*`: on the device each is the fused loss node with the
+    other two terms switched off), `loss.backward()`, `torch.optim.Adam.step()`, the three `.item()` reads -- eager, no
     TrainPipeline, no hipGraph, no prefetch, random FPS starts (the reference's are unseeded too)."""
     args = make_args(cuda=dev.index or 0, subsample_size=n_points, ratio1=M1 / n_points, r1=1.0, ratio2=0.25, r2=2.0)
     torch.manual_seed(0)
@@ -598,7 +599,7 @@ def dropin_eager_leg(dev, B, n_points, steps=10, warmup=3):
         cov, proba = model(cloud_data)
         pred = project_to_plotwise_coverages(cov, clouds, args)
         loss_abs = losses.get_absolute_loss(pred, gt)
-        loss_log = losses.get_NLL_loss(proba, d["pdf_all"].cuda(dev))     # the reference evaluates its KDE on the CPU and uploads
+        loss_log = losses.get_NLL_loss(proba, d["pdf_all"])               # the reference evaluates its KDE on the CPU; the function uploads
         loss_e = losses.get_entropy_loss(proba)
         loss = loss_abs + args.m * loss_log + args.e * loss_e
         loss.backward()
@@ -611,7 +612,7 @@ def dropin_eager_leg(dev, B, n_points, steps=10, warmup=3):
     torch.cuda.empty_cache()
     return {"ms_per_step": round(t * 1e3, 3), "plots_per_s": round(B / t, 1), "statistic": f"median of {steps} steps after {warmup} warm-ups",
             "what": f"learning/train.py:46-66 as written, {B} plots x {n_points} pts per step from HOST tensors (40 MB H2D per step), "
-                    "torch.optim.Adam, plain torch loss ops, eager launches, geometry and features back to back"}
+                    "torch.optim.Adam, the three loss terms called one by one (losses.get_*), eager launches, geometry and features back to back"}
 
 
 def secondary_legs(dev):

@@ -41,7 +41,7 @@ for it in range(14):
     cov, proba = model({"cloud": d["cloud"], "xyz": d["xyz"]}); t.append(time.perf_counter())
     pred = project_to_plotwise_coverages(cov, d["cloud"], args); t.append(time.perf_counter())
     la = losses.get_absolute_loss(pred, gt)
-    ll = losses.get_NLL_loss(proba, d["pdf_all"].cuda(dev))
+    ll = losses.get_NLL_loss(proba, d["pdf_all"])
     le = losses.get_entropy_loss(proba)
     loss = la + args.m * ll + args.e * le; t.append(time.perf_counter())
     loss.backward(); t.append(time.perf_counter())
@@ -77,7 +77,7 @@ if os.environ.get("SN2_CPROFILE"):
         cov, proba = model({"cloud": d["cloud"], "xyz": d["xyz"]})
         pred = project_to_plotwise_coverages(cov, d["cloud"], args)
         pr.disable()
-        loss = losses.get_absolute_loss(pred, gt) + args.m * losses.get_NLL_loss(proba, d["pdf_all"].cuda(dev)) + args.e * losses.get_entropy_loss(proba)
+        loss = losses.get_absolute_loss(pred, gt) + args.m * losses.get_NLL_loss(proba, d["pdf_all"]) + args.e * losses.get_entropy_loss(proba)
         pr.enable()
         loss.backward()
         pr.disable()

@@ -102,7 +102,7 @@ class PinnedRing:
     that need only the first tensor (the geometry pass needs `xyz` only) start while the rest is still on its way.
     A slot is reused only after the DMA that read it has finished (an event per slot, waited for on the host)."""
 
-    def __init__(self, dev, slots: int = 3):
+    def __init__(self, dev, slots: int = 4):
         self.dev = torch.device(dev)
         self.bufs = [None] * slots
         self.events = [None] * slots

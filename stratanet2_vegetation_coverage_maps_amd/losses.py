@@ -5,8 +5,9 @@
 
 `total_loss` is ONE autograd node over three HIP kernels (csrc/loss.hip: pointwise partial sums, finalize, backward)
 instead of the ~75 elementwise launches torch needs for the same expression and its gradient -- at 2.5 ms per step
-those launches were a fifth of the step.  `total_loss_torch` and the three `get_*` functions keep the plain torch-op form
-(same as the reference, usable on any device); the tests hold the fused kernels to them.
+those launches were a fifth of the step.  `total_loss_torch` and the three `get_*_torch` functions keep the plain torch-op form
+(same as the reference, usable on any device); the tests hold the fused kernels to them.  The three `get_*` functions the
+reference's loop calls are that node with two terms switched off on a HIP device, the torch forms elsewhere.
 
 Difference from the reference signature: `get_NLL_loss` takes the KDE-mixture densities `pdf_all (B*N,3)` directly
 instead of evaluating `args.kde_mixture` on the CPU each step (`loss_functions.py:30-42`; KDE fitting is out of scope).
@@ -19,29 +20,88 @@ from ._lib import StrataHipError
 EPS = 0.0001
 
 
-def get_absolute_loss(pred_pl, gt):
+def get_absolute_loss_torch(pred_pl, gt):
     # strata [low, med, high] = columns 0, 2, 3; sliced (not list-indexed: a python index list costs a host-to-device
     # copy per step and cannot be captured into a hipGraph)
     d = torch.cat((pred_pl[:, 0:1], pred_pl[:, 2:4]), 1) - torch.cat((gt[:, 0:1], gt[:, 2:4]), 1)
     return (d.pow(2) + EPS).pow(0.5).mean(0).mean()
 
 
-def get_entropy_loss(pred_pixels):
+def get_entropy_loss_torch(pred_pixels):
     p = pred_pixels[:, 2:]
     return -(p * torch.log(p + EPS) + (1 - p) * torch.log(1 - p + EPS)).mean()
 
 
-def get_NLL_loss(pred_pointwise, pdf_all):
+def get_NLL_loss_torch(pred_pointwise, pdf_all):
     p_ground = pred_pointwise[:, 0] + pred_pointwise[:, 1]
     lik = p_ground * pdf_all[:, 0] + pred_pointwise[:, 2] * pdf_all[:, 1] + pred_pointwise[:, 3] * pdf_all[:, 2]
     return -torch.log(lik).mean()
 
 
 def total_loss_torch(pred_coverages, proba_pointwise, gt, pdf_all, m=0.10, e=0.2 / 5):
-    l_abs = get_absolute_loss(pred_coverages, gt)
-    l_log = get_NLL_loss(proba_pointwise, pdf_all)
-    l_e = get_entropy_loss(proba_pointwise)
+    l_abs = get_absolute_loss_torch(pred_coverages, gt)
+    l_log = get_NLL_loss_torch(proba_pointwise, pdf_all)
+    l_e = get_entropy_loss_torch(proba_pointwise)
     return l_abs + m * l_log + e * l_e, (l_abs, l_log, l_e)
+
+
+# The reference's loop calls the three terms one by one (learning/train.py:58-62).  On a HIP device each of them is the fused
+# node with the other two terms switched off -- three launches forward and one backward per term instead of ~20 elementwise
+# torch launches and their autograd graph (the eager drop-in loop is bound by its host time: DESIGN.md section 5) --, the
+# values in fp64 as `total_loss`.  FUSED_TERMS = False (SN2_FUSED_LOSS_TERMS=0), CPU tensors: the plain torch forms above.
+import os as _os
+FUSED_TERMS = _os.environ.get("SN2_FUSED_LOSS_TERMS", "1") == "1"
+_DUMMY = {}          # (device index, rows) -> constant stand-ins for the terms that are switched off
+
+
+def _dummy(dev, rows):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), rows)
+    d = _DUMMY.get(key)
+    if d is None:
+        if len(_DUMMY) > 8:
+            _DUMMY.clear()
+        d = (torch.full((rows, 4), 0.25, dtype=torch.float32, device=dev), torch.ones(rows, 3, dtype=torch.float64, device=dev),
+             torch.zeros(1, 4, dtype=torch.float32, device=dev), torch.zeros(1, 4, dtype=torch.float64, device=dev))
+        _DUMMY[key] = d
+    return d
+
+
+def _fused_ok(*tensors):
+    return FUSED_TERMS and all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors)
+
+
+def get_absolute_loss(pred_pl, gt):
+    if not _fused_ok(pred_pl, gt):
+        return get_absolute_loss_torch(pred_pl, gt)
+    with torch.cuda.device(pred_pl.device):
+        proba1, pdf1, _, _ = _dummy(pred_pl.device, 1)          # one point with likelihood 1: NLL = 0, and both switched off
+        total, _, _, _ = _TotalLoss.apply(pred_pl.float().contiguous(), proba1, gt.to(torch.float64).contiguous(), pdf1, 0.0, 0.0)
+    return total
+
+
+def get_NLL_loss(pred_pointwise, pdf_all):
+    if FUSED_TERMS and isinstance(pred_pointwise, torch.Tensor) and pred_pointwise.is_cuda and not pdf_all.is_cuda:
+        # the reference evaluates its KDE mixture on the CPU and moves the densities to the device inside this function
+        # (loss_functions.py:30-42): through the pinned ring, asynchronously (12.6 MB at C2: a pageable `.cuda()` blocks 0.4 ms)
+        with torch.cuda.device(pred_pointwise.device):
+            pdf_all = ops.pinned_ring(pred_pointwise.device).upload(pdf_all, dtype=torch.float64)
+    if not _fused_ok(pred_pointwise, pdf_all):
+        return get_NLL_loss_torch(pred_pointwise, pdf_all)
+    with torch.cuda.device(pred_pointwise.device):
+        _, _, pred0, gt0 = _dummy(pred_pointwise.device, 1)      # the absolute term of a constant plot: subtracted again
+        total, l_abs, _, _ = _TotalLoss.apply(pred0, pred_pointwise.float().contiguous(), gt0,
+                                              pdf_all.to(torch.float64).contiguous(), 1.0, 0.0)
+    return total - l_abs
+
+
+def get_entropy_loss(pred_pixels):
+    if not _fused_ok(pred_pixels):
+        return get_entropy_loss_torch(pred_pixels)
+    with torch.cuda.device(pred_pixels.device):
+        _, pdf1, _, _ = _dummy(pred_pixels.device, pred_pixels.shape[0])
+        _, _, pred0, gt0 = _dummy(pred_pixels.device, 1)
+        total, l_abs, _, _ = _TotalLoss.apply(pred0, pred_pixels.float().contiguous(), gt0, pdf1, 0.0, 1.0)
+    return total - l_abs
 
 
 class KdeTables:

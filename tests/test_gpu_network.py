@@ -240,6 +240,38 @@ def test_losses_match_oracle():
             np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
 
 
+def test_the_three_loss_terms_one_by_one_are_the_fused_node():
+    """The reference's loop calls `get_absolute_loss`, `get_NLL_loss`, `get_entropy_loss` one by one (learning/train.py:58-62): on
+    a HIP device each is the fused node with the other two terms switched off.  Values against the plain torch forms (1e-6)
+    and the oracle's, gradients of their weighted sum 1e-5; CPU tensors take the torch forms."""
+    from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
+    g = torch.Generator().manual_seed(1)
+    B, R = 5, 40001
+    pred = torch.rand(B, 4, generator=g)
+    proba = torch.softmax(torch.randn(R, 4, generator=g), 1) * torch.rand(R, 1, generator=g)
+    gt = torch.rand(B, 4, generator=g, dtype=torch.float64)
+    pdf = torch.rand(R, 3, generator=g, dtype=torch.float64) + 0.05
+    res = {}
+    for fused in (True, False):
+        dev_losses.FUSED_TERMS = fused
+        try:
+            pd, qd = pred.cuda().requires_grad_(True), proba.cuda().requires_grad_(True)
+            la = dev_losses.get_absolute_loss(pd, gt.cuda())
+            ll = dev_losses.get_NLL_loss(qd, pdf.cuda())
+            le = dev_losses.get_entropy_loss(qd)
+            (2.0 * (la + 0.1 * ll + 0.04 * le)).backward()
+            res[fused] = (la.item(), ll.item(), le.item(), pd.grad.clone(), qd.grad.clone())
+        finally:
+            dev_losses.FUSED_TERMS = True
+    _, (oa, ol, oe) = losses.total_loss(pred, proba, gt, pdf, 0.1, 0.04)
+    for k, o in enumerate((oa, ol, oe)):
+        assert abs(res[True][k] - res[False][k]) < 1e-6 * max(1.0, abs(res[False][k])) and abs(res[True][k] - o.item()) < 1e-6 * max(1.0, abs(o.item()))
+    for k in (3, 4):
+        ref = res[False][k].cpu().numpy()
+        np.testing.assert_allclose(res[True][k].cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+    assert dev_losses.get_absolute_loss(pred, gt).dtype == dev_losses.get_absolute_loss_torch(pred, gt).dtype      # CPU: torch form
+
+
 def test_prefetched_geometry_gives_identical_results():
     """`prefetch_geometry` (position-only kernels on a side stream) + forward == plain forward, bit for bit in eval."""
     N = 4096
