@@ -576,7 +576,7 @@ def inference_leg(dev, plots=2048, points=10000, batch=512, repeat=3, prefetch=3
     return out
 
 
-def dropin_eager_leg(dev, B, n_points, steps=10, warmup=3):
+def dropin_eager_leg(dev, B, n_points, steps=40, warmup=5):
     """The drop-in as a user of the reference would run it: the loop of /root/reference/learning/train.py:46-66 -- CPU-resident
     batches as the DataLoader collates them, `model(cloud_data)` (which uploads them), `project_to_plotwise_coverages`, the
     three loss terms called one by one as the reference does (`losses.get_*`: on the device each is the fused loss node with the

@@ -64,7 +64,15 @@ def _call(name, *args, tag=None, key=None):
     check(rc, name)
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """The raw handle of torch's current stream on the current device (every entry point launches there).  Through torch's
+    own raw accessor where it exists: `torch.cuda.current_stream()` builds a Stream object per call, ~2 us x 60 calls per
+    eager step."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
