@@ -21,6 +21,8 @@
 #ifndef STRATA_HIP_H
 #define STRATA_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -273,11 +275,18 @@ int sn2_plot_max_backward(const float *dout, const int *arg, int B, int R_per_pl
  *   sa3, fp3: the descriptors the separate calls take (sa3: ca 32, cb 3, no 3-NN table, src = x2 (B*M2,32), skip = pos2 (B*M2,4);
  *             fp3: ca 64, cb 32, S_per_plot 1, src = x3, its 3-NN table, skip = x2; both cout 64, h_stride 64, fp32 operands);
  *             blk.stat_slots is not used;  x3 (B,64), arg3 (B,64): the plot feature and the rows attaining it;
- *   xchg: SN2_GLOBAL_XCHG_WORDS(B) 64-bit words and ctl: 2 words, BOTH ZERO-FILLED ONCE and then left to the library; launches
- *         that share them must be on one stream.  ctl[1] counts waits that gave up (spin limit: a workgroup was not resident
- *         within ~0.2 s): the statistics of that launch are WRONG -- read it where the host synchronises anyway and fail.
+ *   xchg: SN2_GLOBAL_XCHG_WORDS(B) 64-bit words and ctl: SN2_GLOBAL_CTL_WORDS 32-bit words, BOTH ZERO-FILLED ONCE and then left to
+ *         the library (the launch epoch lives there: allocate them once, at the size of the largest batch, and never again while
+ *         graphs that captured their address exist); launches that share them must be on one stream at a time.
+ *   A wait for the peers' sums is bounded (HIP does not promise that the B workgroups of a launch are resident together): a
+ *   workgroup whose wait runs out counts itself in ctl[1] and leaves, and the call's SECOND launch -- one workgroup that reads
+ *   two words and returns when nothing gave up -- then computes the whole level again, alone, with the same tiles and the same
+ *   fixed-order sums: the results (rows, statistics, running statistics, counters) are those of an undisturbed launch, bit for
+ *   bit, whatever happened (torch's BatchNorm has no such failure mode: model/point_net2.py:45-53).  ctl[1] stays as a sticky
+ *   count a host may read where it synchronises anyway, to learn that launches are being repeated.
  * SN2_ELIMIT for other shapes, bfloat16 operands or more than 28 plots: use the separate calls. */
 #define SN2_GLOBAL_XCHG_WORDS(B) ((size_t)2 * (size_t)(B) * 4 * 128)
+#define SN2_GLOBAL_CTL_WORDS 8
 int sn2_global_level_forward(const sn2_fp *sa3, const sn2_fp *fp3, float *x3, int *arg3, unsigned long long *xchg,
                              unsigned *ctl, void *stream);
 /* tests only: the sweeps (~1 us each, default 2^18; 0 = back to it) an exchange wait of sn2_global_level_forward makes before
@@ -396,6 +405,141 @@ int sn2_loss_backward(const float *pred, const double *gt, int B, const float *p
 int sn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int *step_dev /* two device ints: {steps taken so far (incremented here), 0} */,
                   float grad_scale, void *stream);
+
+/* ==== the whole network behind ONE call per pass (round 5) ===================================================
+ * PointNet2.forward of the reference (model/point_net2.py:106-153) is ~25 of the entry points above in a fixed order, and
+ * loss.backward() through it (learning/train.py:64) ~10 more.  A host that issues them one by one from Python spends more
+ * time between the launches than the device needs for the kernels (the reference's training loop as written: 3.5 ms per step
+ * over ~2.4 ms of kernels).  sn2_net_geometry / sn2_net_forward / sn2_net_backward issue the same entry points, with the same
+ * descriptors, in the same order, from inside the library: one call each.  Nothing else changes: every buffer is the
+ * caller's, nothing is allocated, freed or synchronised, all launches go to `stream` (and, for the forked geometry pass, to
+ * the caller's side streams, ordered by the events of a caller-owned context).  Results are those of the separate calls, bit
+ * for bit (tests/test_gpu_executor.py).
+ *
+ * The reference architecture only (model/point_net2.py:81-99): SA1 MLP[11,16,16], SA2 MLP[19,32], global SA MLP[35,64],
+ * FP3 MLP[96,64] k=1, FP2 MLP[80,34] k=3, FP1 MLP[42,34] k=3, lin1 34->16, lin2 16->5. */
+
+/* one (Linear -> ReLU -> BatchNorm1d) block of the model: its parameters and buffers (device), and where its four gradients
+ * live inside the flat parameter gradient (offsets in floats; parameters() order of the reference module) */
+typedef struct sn2_net_layer {
+    int cin, cout;
+    const float *W, *b, *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *num_batches_tracked;      /* or NULL */
+    int gW, gb, ggamma, gbeta;
+    int mma_bf16;                        /* sn2_block.mma_bf16 of this block */
+} sn2_net_layer;
+
+typedef struct sn2_net_model {
+    sn2_net_layer sa1[2], sa2, sa3, fp3, fp2, fp1;      /* model/point_net2.py:84-93 */
+    const float *lin1_W, *lin1_b, *lin2_W, *lin2_b;     /* :95-99 */
+    int g_lin1_W, g_lin1_b, g_lin2_W, g_lin2_b;
+    int n_flat;                          /* length of the flat parameter (and gradient) vector: 14 997 */
+    float r1_sq, r2_sq;                  /* fp32(r*r) of the two ball queries, r*r evaluated in double (sn2_ball_query) */
+    int max_neighbors;                   /* model/point_net2.py:24 (2000) */
+    float drop_p;                        /* args.drop (:142) */
+    int fuse_global_level;               /* training: sn2_global_level_forward where its limits allow (else the separate calls) */
+    int fuse_eval_head;                  /* eval: sn2_fp_head_eval instead of sn2_fp_forward + sn2_head_forward */
+    int source_side;                     /* hand out sn2_fp.src_ws (the per-point layer's source-side form) */
+    int fps_waves_shared, fps_waves_many;/* sn2_fps_waves of the level-1 FPS of a pass that shares the chip (<= 32 plots / more) */
+} sn2_net_model;
+
+typedef struct sn2_net_dims {
+    int B, N, M1, M2;                    /* plots, points per plot, centroids of the two levels (ceil(fp32(n) * fp32(ratio))) */
+    int cap1, cap2;                      /* row stride of nbr1 / nbr2: min(max_neighbors, N) / min(max_neighbors, M1) */
+    int act_bf16;                        /* the per-point activation buffers h1 / dy1 / du1 are bfloat16 (sn2_fp.act_bf16) */
+    int p2_diam_pix;                     /* > 0: the geometry pass also computes the pixel ids of sn2_plot_pixels (geo.p2_*) */
+} sn2_net_dims;
+
+/* The position-only tables of one batch -- what SAModule / FPModule obtain from torch_cluster in the reference
+ * (model/point_net2.py:22-25, 63) -- and the two input-only pieces a geometry pass may also produce.  Shapes as in the
+ * entry points that fill them.  sn2_net_geo_carve lays them out in one caller-owned arena. */
+typedef struct sn2_net_geo {
+    const float *xyz;                                    /* (B,3,N): the batch's positions */
+    int *idx1; float *pos1_soa, *pos1_aos; int *ws1;     /* sn2_fps level 1; ws1 = NULL where the FPS fills no workspace */
+    int *nbr1, *cnt1; unsigned long long *tot1; int *ord1;
+    int *idx2; float *pos2_soa, *pos2_aos; int *ws2;
+    int *nbr2, *cnt2; unsigned long long *tot2; int *ord2;
+    const float *pos3;                                   /* (B,3,1) zeros: the global feature sits at the origin (:41) */
+    int *knn3_idx; float *knn3_w;                        /* (B*M2,3) */
+    int *knn2_idx; float *knn2_w;                        /* (B*M1,3) */
+    int *knn1_idx; float *knn1_w;                        /* (B*N,3)  */
+    float *inv3, *inv2, *inv1;                           /* SN2_INTERP_WS_WORDS each */
+    int *nn_ws2, *nn_ws1;                                /* SN2_THREE_NN_XY_WS_WORDS or NULL (full scan) */
+    const int *rank1;                                    /* sn2_fp.row_perm of FP1 or NULL */
+    float *rows0;                                        /* (B*N,12) sn2_pack_rows */
+    int *p2_pix; float *p2_mm;                           /* sn2_plot_pixels or NULL */
+} sn2_net_geo;
+
+/* The buffers of one forward pass (kept for its backward pass when training). */
+typedef struct sn2_net_act {
+    float *aux;                          /* 4 * 260 floats: (a, c, mean, invstd) of the seven blocks, in model order */
+    float *stats;                        /* SN2_STAT_SLOTS * 2 * 260 floats: their statistic slots */
+    float *ext1; int *arg1; float *x1;   /* (B*M1,16) */
+    float *ext2; int *arg2; float *x2;   /* (B*M2,32) */
+    float *h_sa3, *h3;                   /* (B*M2,64) */
+    float *x3; int *arg3;                /* (B,64) */
+    float *h2;                           /* (B*M1,36) */
+    void *h1;                            /* (B*N,36) fp32 / bfloat16 rows; unused by the fused eval pass */
+    float *src_ws1, *src_ws2;            /* SN2_FP_SRC_WS_WORDS of FP1 / FP2, or NULL (sn2_fp.src_ws) */
+    float *cov, *proba;                  /* OUT (B*N,4): coverages_pointwise, proba_pointwise -- set by the caller, not carved */
+    const int *drop_mask;                /* sn2_head.drop_mask or NULL -- set by the caller */
+} sn2_net_act;
+
+/* The buffers of one backward pass: `arena` (zero-filled INSIDE sn2_net_backward) = 32 images of the flat parameter gradient,
+ * image stride = n_flat rounded up to 64 floats, followed by the accumulate-into buffers; the rest is scratch. */
+typedef struct sn2_net_bwd {
+    const float *dcov, *dproba;          /* IN (B*N,4) each, either may be NULL -- set by the caller */
+    float *arena; long arena_words;
+    int images, image_stride;
+    float *dy2, *dy3, *dx1, *dx2, *dx3, *dy_sa3;
+    void *dy1, *du1;                     /* (B*N,36) rows of the activation type */
+    float *du2, *du3;                    /* (B*M1,64), (B*M2,64) */
+    int *bn_ok;                          /* 3 words */
+    float *src_ws1, *src_ws2;
+} sn2_net_bwd;
+
+#define SN2_NET_FORK 1          /* geometry: level-2 chain on io.stream_b, per-point 3-NN chain on io.stream_c (needs io.ctx) */
+#define SN2_NET_SHARED 2        /* geometry: the pass shares the chip with other kernels (level-1 FPS: model.fps_waves_*) */
+#define SN2_NET_INVERTED 4      /* geometry: also the inverted 3-NN tables (only a backward pass reads them) */
+#define SN2_NET_DEFER_JOIN 8    /* geometry (with FORK): return without joining; the forward pass that follows joins */
+#define SN2_NET_INPUT_ONLY 16   /* geometry: also rows0 (and the P2 pixel ids when dims.p2_diam_pix > 0) from io.cloud */
+#define SN2_NET_HAS_ROWS0 32    /* forward: geo.rows0 is already packed */
+#define SN2_NET_JOIN_PENDING 64 /* forward: the geometry pass on this ctx was launched with DEFER_JOIN: SA2 waits for chain b, FP1 for chain c */
+#define SN2_NET_WITH_GEOMETRY 128 /* forward: run the geometry pass first (forked when io.ctx and the side streams are given), the
+                                     row packing beside the level-1 FPS */
+#define SN2_NET_HAS_INVERTED 256 /* forward (training): geo.inv* are already built (else they are built here) */
+
+typedef struct sn2_net_io {
+    const float *cloud;                  /* (B,10,N) features on the device, or NULL where not needed */
+    const int *fps_start;                /* (2,B) start indices of the two FPS calls, or NULL (= 0) */
+    unsigned *fps_status;                /* sn2_fps_status's word or NULL */
+    unsigned long long *gl_xchg; unsigned *gl_ctl;   /* sn2_global_level_forward's exchange area, or NULL: separate launches */
+    void *stream_b, *stream_c, *stream_pack;         /* side streams of a forked pass (hipStream_t), or NULL */
+    void *ctx;                           /* sn2_net_ctx_create: the events that order them, or NULL (no fork) */
+    int flags;                           /* SN2_NET_* */
+    int training;                        /* model.training */
+} sn2_net_io;
+
+/* events of a forked geometry pass: created once by the caller (one per model and device), used by one pass at a time */
+int sn2_net_ctx_create(void **ctx);
+int sn2_net_ctx_destroy(void *ctx);
+/* Lay the tables / buffers out in caller-owned arenas: every pointer of *out = base + its offset (256-byte aligned); *bytes = the
+ * arena's size.  base = NULL: the pointers ARE the offsets (a host can cache them per shape).  Fields marked "set by the
+ * caller" are left NULL. */
+int sn2_net_geo_carve(const sn2_net_model *m, const sn2_net_dims *d, void *base, sn2_net_geo *out, size_t *bytes);
+int sn2_net_act_carve(const sn2_net_model *m, const sn2_net_dims *d, int training, void *base, sn2_net_act *out, size_t *bytes);
+int sn2_net_bwd_carve(const sn2_net_model *m, const sn2_net_dims *d, void *arena_base, void *scratch_base, sn2_net_bwd *out,
+                      size_t *arena_bytes, size_t *scratch_bytes);
+/* the position-only kernels of one batch: FPS x2, ball query x2, SA work items x2, 3-NN x3 [, inverted tables x3, rows0, P2 ids]
+ * -- PointNet2._geometry; replaces the torch_cluster calls of model/point_net2.py:22-25, 63 */
+int sn2_net_geometry(const sn2_net_model *m, const sn2_net_dims *d, const sn2_net_geo *g, const sn2_net_io *io, void *stream);
+/* PointNet2.forward, model/point_net2.py:131-151 (training or eval by io->training) */
+int sn2_net_forward(const sn2_net_model *m, const sn2_net_dims *d, const sn2_net_geo *g, const sn2_net_act *a,
+                    const sn2_net_io *io, void *stream);
+/* its backward pass (loss.backward(), learning/train.py:64): every parameter gradient into image 0 of b->arena */
+int sn2_net_backward(const sn2_net_model *m, const sn2_net_dims *d, const sn2_net_geo *g, const sn2_net_act *a,
+                     const sn2_net_bwd *b, void *stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,56 @@ class Head(Structure):  # sn2_head
                 ("act_bf16", c_int)]
 
 
+class NetLayer(Structure):  # sn2_net_layer
+    _fields_ = [("cin", c_int), ("cout", c_int), ("W", c_void_p), ("b", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
+                ("gW", c_int), ("gb", c_int), ("ggamma", c_int), ("gbeta", c_int), ("mma_bf16", c_int)]
+
+
+class NetModel(Structure):  # sn2_net_model
+    _fields_ = [("sa1", NetLayer * 2), ("sa2", NetLayer), ("sa3", NetLayer), ("fp3", NetLayer), ("fp2", NetLayer), ("fp1", NetLayer),
+                ("lin1_W", c_void_p), ("lin1_b", c_void_p), ("lin2_W", c_void_p), ("lin2_b", c_void_p),
+                ("g_lin1_W", c_int), ("g_lin1_b", c_int), ("g_lin2_W", c_int), ("g_lin2_b", c_int), ("n_flat", c_int),
+                ("r1_sq", c_float), ("r2_sq", c_float), ("max_neighbors", c_int), ("drop_p", c_float),
+                ("fuse_global_level", c_int), ("fuse_eval_head", c_int), ("source_side", c_int),
+                ("fps_waves_shared", c_int), ("fps_waves_many", c_int)]
+
+
+class NetDims(Structure):  # sn2_net_dims
+    _fields_ = [("B", c_int), ("N", c_int), ("M1", c_int), ("M2", c_int), ("cap1", c_int), ("cap2", c_int), ("act_bf16", c_int),
+                ("p2_diam_pix", c_int)]
+
+
+class NetGeo(Structure):  # sn2_net_geo
+    _fields_ = [(n, c_void_p) for n in (
+        "xyz", "idx1", "pos1_soa", "pos1_aos", "ws1", "nbr1", "cnt1", "tot1", "ord1",
+        "idx2", "pos2_soa", "pos2_aos", "ws2", "nbr2", "cnt2", "tot2", "ord2", "pos3",
+        "knn3_idx", "knn3_w", "knn2_idx", "knn2_w", "knn1_idx", "knn1_w", "inv3", "inv2", "inv1", "nn_ws2", "nn_ws1",
+        "rank1", "rows0", "p2_pix", "p2_mm")]
+
+
+class NetAct(Structure):  # sn2_net_act
+    _fields_ = [(n, c_void_p) for n in (
+        "aux", "stats", "ext1", "arg1", "x1", "ext2", "arg2", "x2", "h_sa3", "h3", "x3", "arg3", "h2", "h1", "src_ws1", "src_ws2",
+        "cov", "proba", "drop_mask")]
+
+
+class NetBwd(Structure):  # sn2_net_bwd
+    _fields_ = [("dcov", c_void_p), ("dproba", c_void_p), ("arena", c_void_p), ("arena_words", c_long), ("images", c_int),
+                ("image_stride", c_int)] + [(n, c_void_p) for n in (
+                    "dy2", "dy3", "dx1", "dx2", "dx3", "dy_sa3", "dy1", "du1", "du2", "du3", "bn_ok", "src_ws1", "src_ws2")]
+
+
+class NetIO(Structure):  # sn2_net_io
+    _fields_ = [("cloud", c_void_p), ("fps_start", c_void_p), ("fps_status", c_void_p), ("gl_xchg", c_void_p), ("gl_ctl", c_void_p),
+                ("stream_b", c_void_p), ("stream_c", c_void_p), ("stream_pack", c_void_p), ("ctx", c_void_p), ("flags", c_int),
+                ("training", c_int)]
+
+
+NET_FORK, NET_SHARED, NET_INVERTED, NET_DEFER_JOIN, NET_INPUT_ONLY = 1, 2, 4, 8, 16          # SN2_NET_* of the header
+NET_HAS_ROWS0, NET_JOIN_PENDING, NET_WITH_GEOMETRY, NET_HAS_INVERTED = 32, 64, 128, 256
+
+
 # name -> argtypes; every entry point returns int (0 ok, >0 hipError_t, <0 argument error)
 SIGNATURES = {
     "sn2_version": [],
@@ -101,6 +151,15 @@ SIGNATURES = {
                           c_void_p, c_void_p],
     "sn2_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
                       c_void_p, c_float, c_void_p],
+    "sn2_net_ctx_create": [POINTER(c_void_p)],
+    "sn2_net_ctx_destroy": [c_void_p],
+    "sn2_net_geo_carve": [POINTER(NetModel), POINTER(NetDims), c_void_p, POINTER(NetGeo), POINTER(ctypes.c_size_t)],
+    "sn2_net_act_carve": [POINTER(NetModel), POINTER(NetDims), c_int, c_void_p, POINTER(NetAct), POINTER(ctypes.c_size_t)],
+    "sn2_net_bwd_carve": [POINTER(NetModel), POINTER(NetDims), c_void_p, c_void_p, POINTER(NetBwd), POINTER(ctypes.c_size_t),
+                          POINTER(ctypes.c_size_t)],
+    "sn2_net_geometry": [POINTER(NetModel), POINTER(NetDims), POINTER(NetGeo), POINTER(NetIO), c_void_p],
+    "sn2_net_forward": [POINTER(NetModel), POINTER(NetDims), POINTER(NetGeo), POINTER(NetAct), POINTER(NetIO), c_void_p],
+    "sn2_net_backward": [POINTER(NetModel), POINTER(NetDims), POINTER(NetGeo), POINTER(NetAct), POINTER(NetBwd), c_void_p],
 }
 
 _lib = None

@@ -1445,29 +1445,34 @@ struct GlArgs {
     int* arg3;
     GlLayer sa3, fp3;
     gl_u64* xchg;           // [2 phases][B * 4 groups][128]
-    unsigned* ctl;          // [0] epoch of the last finished launch, [1] waits that gave up (sticky)
+    unsigned* ctl;          // [0] epoch of the last finished launch, [1] workgroups that gave up (sticky), [2] ... that a repair
+                            // launch has handled, [3] running statistics workgroup 0 updated in the last launch (bit 0 SA3, 1 FP3)
     unsigned spin_limit;
 };
 
 // all granules of a phase -> s_x (floats), every thread its share, eight loads in flight, swept until every tag matches (or
-// the limit runs out)
+// the limit runs out, or a publisher says that it gave up: the POISON tag = tag with the top bit flipped)
+constexpr unsigned GL_POISON = 0x80000000u;
 __device__ __forceinline__ bool gl_collect(const gl_u64* gx, int n, unsigned tag, float* s_x, unsigned spin_limit) {
     bool ok = true;
     for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
         gl_u64 v[8];
         unsigned spins = 0;
-        bool all;
+        bool all, poisoned;
         do {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * 1024;
                 v[u] = __hip_atomic_load(gx + (i < n ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            all = true;
+            all = true, poisoned = false;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) all = all && (unsigned)(v[u] >> 32) == tag;
-            if (!all) __builtin_amdgcn_s_sleep(2);
-        } while (!all && ++spins < spin_limit);
+            for (int u = 0; u < 8; ++u) {
+                all = all && (unsigned)(v[u] >> 32) == tag;
+                poisoned = poisoned || (unsigned)(v[u] >> 32) == (tag ^ GL_POISON);
+            }
+            if (!all && !poisoned) __builtin_amdgcn_s_sleep(2);
+        } while (!all && !poisoned && ++spins < spin_limit);
         if (!all) ok = false;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -1476,8 +1481,23 @@ __device__ __forceinline__ bool gl_collect(const gl_u64* gx, int n, unsigned tag
     return ok;
 }
 
+// REPAIR = false: the launch proper, one workgroup per plot.  A workgroup whose wait for its peers' statistics runs out (HIP does
+// not promise that the B workgroups of a launch are resident together) or that finds a peer's POISON gives up: it counts itself
+// in ctl[1], publishes POISON instead of its FP3 sums and leaves; workgroup 0 updates a layer's running statistics only when
+// its own collection of that layer's sums was complete, and says which it updated in ctl[3].
+// REPAIR = true: the gated launch behind it (one workgroup, same stream).  ctl[1] == ctl[2] -- no wait gave up since the last
+// repair -- and it returns at once; otherwise it computes the WHOLE level alone, plot after plot, with the same tiles, the same
+// per-group sums published to and collected from the same exchange area and the same fixed-order finalisation -- the bits of
+// an undisturbed launch --, applies the running-statistics updates workgroup 0 did not (ctl[3]), and moves the epoch past
+// every tag a late workgroup of the failed launch may have written.
+template <bool REPAIR>
 __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
     extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+    if constexpr (REPAIR) {
+        if (__hip_atomic_load(&A.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+            __hip_atomic_load(&A.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            return;                              // the launch in front was undisturbed (the usual case: two loads)
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 8), g = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
     float* s_q = gl_smem + grp * 64 * GL_QS;                     // the group's staged rows
@@ -1493,18 +1513,22 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
     float* s_x = s_wf + GL_WF;                                   // [B * 4 * 128] the collected granules of an exchange
     __shared__ unsigned s_epoch;
     __shared__ int s_fail;
-    const int b = blockIdx.x, B = A.B, M2 = A.M2;
+    const int B = A.B, M2 = A.M2;
+    const int b_lo = REPAIR ? 0 : (int)blockIdx.x, b_hi = REPAIR ? B : b_lo + 1;       // the plots of this workgroup
+    const bool lead = REPAIR || blockIdx.x == 0;                                       // writes the shared results
     if (tid == 0) {
         s_epoch = __hip_atomic_load(&A.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         s_fail = 0;
     }
-    const long row_lo = (long)b * M2, R_lim = row_lo + M2;
     const int nblk = (M2 + 63) >> 6, trips = (nblk + GL_GROUPS - 1) / GL_GROUPS;
     const int qq = lane >> 4, cc = lane & 15, o = 16 * g + cc;
     const int n_gran = B * GL_GROUPS * 128;
     const double n_rows = (double)B * (double)M2;
     __syncthreads();
     const unsigned epoch = s_epoch;
+    // which running statistics workgroup 0 of the launch in front already updated (bit 0: SA3's, bit 1: FP3's)
+    unsigned applied = 0;
+    if constexpr (REPAIR) applied = __hip_atomic_load(&A.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Both layers' weights come in once per workgroup, coalesced, and the lanes take their tile operands from LDS: sixteen
     // waves each fetching their own (output, k) elements straight from memory were ~400 cache lines per wave through the CU's
     // one address unit -- half of the kernel's first phase.
@@ -1516,8 +1540,9 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
     for (int t = 0; t < 4; ++t) V3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     GSTAMP(0)
     // ================================================================ SA3: [x2 (32) | pos2 (3) | 1] -> 64
-    {
+    for (int b = b_lo; b < b_hi; ++b) {
         constexpr int CA = 32, CB = 3, CI = CA + CB, CK = CI + 1, KB = (CK + 3) / 4, QS = OuterAcc<16, CK>::QS;
+        const long row_lo = (long)b * M2, R_lim = row_lo + M2;
         float Wb[KB];
         float ssum = 0.f, ssq = 0.f;
         for (int it = 0; it < trips; ++it) {
@@ -1550,19 +1575,38 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
             s_red[grp * 128 + o] = ssum;
             s_red[grp * 128 + 64 + o] = ssq;
         }
-    }
-    __syncthreads();
-    GSTAMP(1)
-    // ---- publish the four groups' sums, collect everybody's, finalise SA3's BatchNorm (every workgroup for itself)
-    {
-        gl_u64* gx = A.xchg;
-        const unsigned tag = epoch * 2u + 0u;
+        __syncthreads();
+        if (b == b_lo) { GSTAMP(1) }
+        // ---- publish the four groups' sums of this plot
         if (tid < GL_GROUPS * 128)
-            __hip_atomic_store(gx + (size_t)b * GL_GROUPS * 128 + tid, ((gl_u64)tag << 32) | (gl_u64)__float_as_uint(s_red[tid]),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!gl_collect(gx, n_gran, tag, s_x, A.spin_limit)) s_fail = 1;
+            __hip_atomic_store(A.xchg + (size_t)b * GL_GROUPS * 128 + tid,
+                               ((gl_u64)(epoch * 2u + 0u) << 32) | (gl_u64)__float_as_uint(s_red[tid]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (REPAIR) __syncthreads();   // (s_red is the next plot's)
+    }
+    // ---- collect everybody's, finalise SA3's BatchNorm (every workgroup for itself)
+    {
+        const unsigned tag = epoch * 2u + 0u;
+        if (!gl_collect(A.xchg, n_gran, tag, s_x, A.spin_limit)) s_fail = 1;
         __syncthreads();
         GSTAMP(2)
+        if (s_fail) {
+            // this workgroup's wait ran out: what it would compute from here on is wrong.  Tell workgroup 0 (POISON in place of
+            // the FP3 sums), count, leave the repair launch behind this one to redo the level.
+            if constexpr (!REPAIR) {
+                if (tid < GL_GROUPS * 128)
+                    __hip_atomic_store(A.xchg + n_gran + (size_t)b_lo * GL_GROUPS * 128 + tid, (gl_u64)((epoch * 2u + 1u) ^ GL_POISON) << 32,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) {
+                    atomicAdd(&A.ctl[1], 1u);
+                    if (lead) {
+                        __hip_atomic_store(&A.ctl[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&A.ctl[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                return;
+            }
+        }
         {
             // column col of the 128, sixteen threads each: partial sums over every sixteenth publisher, then the sixteen in order
             const int col = tid & 127, part = tid >> 7;          // 8 parts x 128 columns
@@ -1576,20 +1620,23 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
 #pragma unroll
             for (int part = 0; part < 8; ++part) s1 += s_d[part * 128 + tid], s2 += s_d[part * 128 + 64 + tid];
             float aa, cc2, mean, invstd;
-            sn2_bn_from_sums(s1, s2, n_rows, A.sa3.gamma[tid], A.sa3.beta[tid], b == 0 ? &A.sa3.running_mean[tid] : nullptr,
-                             b == 0 ? &A.sa3.running_var[tid] : nullptr, aa, cc2, mean, invstd);
+            const bool upd = lead && !(applied & 1u);
+            sn2_bn_from_sums(s1, s2, n_rows, A.sa3.gamma[tid], A.sa3.beta[tid], upd ? &A.sa3.running_mean[tid] : nullptr,
+                             upd ? &A.sa3.running_var[tid] : nullptr, aa, cc2, mean, invstd);
             s_ac[tid] = aa;
             s_ac[64 + tid] = cc2;
-            if (b == 0) {
+            if (lead) {
                 A.sa3.a[tid] = aa, A.sa3.c[tid] = cc2, A.sa3.mean[tid] = mean, A.sa3.invstd[tid] = invstd;
-                if (tid == 0 && A.sa3.nbt) *A.sa3.nbt += 1;
+                if (tid == 0 && upd && A.sa3.nbt) *A.sa3.nbt += 1;
             }
         }
         __syncthreads();
     }
     GSTAMP(3)
+    for (int b = b_lo; b < b_hi; ++b) {
+    const long row_lo = (long)b * M2, R_lim = row_lo + M2;
     // ================================================================ the plot's max of a h + c (first row wins ties)
-    if (trips == 1) {
+    if (!REPAIR && trips == 1) {
         // the group's block is still in registers (V3[t][j]: row 16 t + 4 qq + j of block grp, channel o): rows in ascending
         // order per lane, then the four row quarters (qq) of the channel, then the four groups -- ties to the lower row
         const float aa = s_ac[o], cc2 = s_ac[64 + o];
@@ -1659,7 +1706,7 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
         }
         __syncthreads();
     }
-    GSTAMP(4)
+    if (b == b_lo) { GSTAMP(4) }
     // ================================================================ FP3: [plot feature (64) | x2 (32) | 1] -> 64
     {
         // Every row of the plot interpolates the plot's ONE source: the 64 interpolated inputs are the plot feature x3[b] for
@@ -1685,9 +1732,9 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
         for (int it = 0; it < trips; ++it) {
             const int blk = it * GL_GROUPS + grp;
             const long r0 = row_lo + (long)blk * 64;
-            if (blk < nblk && trips > 1) {
+            if (blk < nblk && (REPAIR || trips > 1)) {
                 // the skip rows: eight lanes per row, one float4 each; 32 rows per pass of the group's 256 threads
-                // (one trip: the group's tile still holds them -- SA3 staged x2 into the same columns, row stride QS)
+                // (one trip, one plot: the group's tile still holds them -- SA3 staged x2 into the same columns, row stride QS)
                 const int t256 = tid & 255;
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
@@ -1711,20 +1758,30 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
         }
     }
     __syncthreads();
-    GSTAMP(5)
+    if (b == b_lo) { GSTAMP(5) }
+    if (tid < GL_GROUPS * 128)
+        __hip_atomic_store(A.xchg + n_gran + (size_t)b * GL_GROUPS * 128 + tid,
+                           ((gl_u64)(epoch * 2u + 1u) << 32) | (gl_u64)__float_as_uint(s_red[tid]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (REPAIR) __syncthreads();       // (s_red, s_mv, s_x3 are the next plot's)
+    }
     {
         gl_u64* gx = A.xchg + n_gran;
         const unsigned tag = epoch * 2u + 1u;
-        if (tid < GL_GROUPS * 128)
-            __hip_atomic_store(gx + (size_t)b * GL_GROUPS * 128 + tid, ((gl_u64)tag << 32) | (gl_u64)__float_as_uint(s_red[tid]),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (b != 0) {
-            if (tid == 0 && s_fail) atomicAdd(&A.ctl[1], 1u);
-            return;
-        }
+        if (!lead) return;
         if (!gl_collect(gx, n_gran, tag, s_x, A.spin_limit)) s_fail = 1;
         __syncthreads();
         GSTAMP(6)
+        if (s_fail) {
+            // (not in a repair launch: every granule it waits for is its own) a peer's FP3 sums did not arrive or are POISON:
+            // SA3's running statistics are updated, FP3's are not -- the repair launch finishes the level
+            if (tid == 0) {
+                atomicAdd(&A.ctl[1], 1u);
+                __hip_atomic_store(&A.ctl[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.ctl[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
         {
             const int col = tid & 127, part = tid >> 7;
             double acc = 0.0;
@@ -1737,16 +1794,25 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
 #pragma unroll
             for (int part = 0; part < 8; ++part) s1 += s_d[part * 128 + tid], s2 += s_d[part * 128 + 64 + tid];
             float aa, cc2, mean, invstd;
-            sn2_bn_from_sums(s1, s2, n_rows, A.fp3.gamma[tid], A.fp3.beta[tid], &A.fp3.running_mean[tid], &A.fp3.running_var[tid],
-                             aa, cc2, mean, invstd);
+            const bool upd = !(applied & 2u);
+            sn2_bn_from_sums(s1, s2, n_rows, A.fp3.gamma[tid], A.fp3.beta[tid], upd ? &A.fp3.running_mean[tid] : nullptr,
+                             upd ? &A.fp3.running_var[tid] : nullptr, aa, cc2, mean, invstd);
             A.fp3.a[tid] = aa, A.fp3.c[tid] = cc2, A.fp3.mean[tid] = mean, A.fp3.invstd[tid] = invstd;
-            if (tid == 0 && A.fp3.nbt) *A.fp3.nbt += 1;
+            if (tid == 0 && upd && A.fp3.nbt) *A.fp3.nbt += 1;
         }
         __syncthreads();
         GSTAMP(7)
         if (tid == 0) {
-            if (s_fail) atomicAdd(&A.ctl[1], 1u);
-            __hip_atomic_store(&A.ctl[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (REPAIR) {
+                // the level is whole again: mark the give-ups as handled, and move the epoch past every tag a late workgroup of
+                // the failed launch may have written (it read ctl[0] after workgroup 0 advanced it: epoch + 1)
+                __hip_atomic_store(&A.ctl[2], __hip_atomic_load(&A.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.ctl[0], epoch + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(&A.ctl[3], 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.ctl[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -3194,8 +3260,12 @@ extern "C" int sn2_global_level_forward(const sn2_fp* sa3, const sn2_fp* fp3, fl
     A.xchg = xchg, A.ctl = ctl;
     A.spin_limit = g_gl_spin_limit;
     const size_t lds = ((size_t)GL_FIXED_FLOATS + (size_t)B * GL_GROUPS * 128) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&global_level_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(global_level_fwd_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, A);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&global_level_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&global_level_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(global_level_fwd_kernel<false>, dim3(B), dim3(1024), lds, (hipStream_t)stream, A);
+    // the repair launch: one workgroup that reads two control words and leaves -- unless a wait of the launch above gave up
+    // (nothing guarantees that its B workgroups are resident together), in which case it computes the whole level again
+    hipLaunchKernelGGL(global_level_fwd_kernel<true>, dim3(1), dim3(1024), lds, (hipStream_t)stream, A);
     SN2_RETURN_LAUNCH();
 }
 

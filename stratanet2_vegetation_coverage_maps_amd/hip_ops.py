@@ -741,53 +741,77 @@ def plot_max_forward(h, a, c, B, R_per_plot, C):
     return out, arg
 
 
-_GLOBAL_WS = {}          # device index -> [exchange granules (int64), control words (int32), give-ups seen]
+GL_MAX_PLOTS = 28        # sn2_global_level_forward's limit (csrc/fp.hip: GL_MAX_PLOTS)
+_GLOBAL_WS = {}          # device index -> workspace of callers that name no owner
+_GLOBAL_WS_ALL = []      # weak references to every live workspace (global_level_gave_up looks at all of them)
 
 
-def global_level_ws(dev, B: int):
-    """The exchange area and control words of `global_level_forward` on this device (zero-filled once, then the library's).
-    One per device: launches that use it are on one stream at a time (the feature pass's)."""
+class _GlobalWs(list):
+    """[exchange granules (int64), control words (int32), give-ups already reported]"""
+    __slots__ = ("__weakref__",)
+
+
+def global_level_ws(dev, B: int = GL_MAX_PLOTS, owner=None):
+    """The exchange area and control words of `global_level_forward` (zero-filled once, then the library's).
+    owner: the object whose training forwards use it (a PointNet2): the workspace lives on it, so two models that train on two
+    streams of one process never share an exchange area; without an owner there is one per device.  Launches that share a
+    workspace must be on one stream at a time.  Allocated ONCE at the largest size the kernel takes (28 plots: 229 KB) and
+    never again: hipGraphs captured earlier hold its raw address and its launch epoch (round 4 reallocated it when a later call
+    had more plots, under the feet of the graphs captured before)."""
     dev = torch.device(dev)
+    if B > GL_MAX_PLOTS:
+        raise ValueError(f"global_level_forward takes at most {GL_MAX_PLOTS} plots")
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    need = 2 * B * 4 * 128
-    ws = _GLOBAL_WS.get(key)
-    if ws is None or ws[0].numel() < need:
+    store = _GLOBAL_WS if owner is None else owner.__dict__.setdefault("_gl_ws", {})
+    ws = store.get(key)
+    if ws is None:
         if torch.cuda.is_current_stream_capturing():
             # zero fills captured into a graph would run at every replay and reset the launch epoch under the other graphs
             raise StrataHipError("global_level_forward: its exchange area must exist before a stream capture starts -- run one "
-                                 "eager training forward first (TrainPipeline.capture does) or call hip_ops.global_level_ws(dev, B)")
-        ws = [torch.zeros(max(need, 2 * 16 * 4 * 128), dtype=I64, device=dev), torch.zeros(2, dtype=I32, device=dev), 0]
-        _GLOBAL_WS[key] = ws
+                                 "eager training forward first (TrainPipeline.capture does) or call hip_ops.global_level_ws(dev, owner=model)")
+        ws = _GlobalWs([torch.zeros(2 * GL_MAX_PLOTS * 4 * 128, dtype=I64, device=dev), torch.zeros(8, dtype=I32, device=dev), 0])
+        store[key] = ws
+        import weakref
+        _GLOBAL_WS_ALL[:] = [r for r in _GLOBAL_WS_ALL if r() is not None]
+        _GLOBAL_WS_ALL.append(weakref.ref(ws))
     return ws
 
 
-def global_level_forward(d_sa3: FP, d_fp3: FP, x3: torch.Tensor, arg3: torch.Tensor):
+def global_level_forward(d_sa3: FP, d_fp3: FP, x3: torch.Tensor, arg3: torch.Tensor, owner=None):
     """SA3 -> BatchNorm -> plot max -> FP3 -> BatchNorm in one launch (training mode; include/strata_hip.h).  d_fp3 must have
-    been built with src = x3."""
+    been built with src = x3.  owner: see `global_level_ws`."""
     B = d_sa3.B
     _chk(x3, F32, (B, 64), "x3")
     _chk(arg3, I32, (B, 64), "arg3")
-    ws = global_level_ws(x3.device, B)
+    ws = global_level_ws(x3.device, B, owner=owner)
     _call("sn2_global_level_forward", d_sa3, d_fp3, _ptr(x3), _ptr(arg3), _ptr(ws[0]), _ptr(ws[1]), _stream())
 
 
-def global_level_gave_up(dev) -> int:
-    """Exchange waits of `global_level_forward` that gave up on this device since the process started (a workgroup of the
-    launch was not resident within the spin limit: another process held the device).  The statistics of such a launch are
-    wrong: RAISES when the count grew since the last call.  Reads one device word: call it where the host synchronises anyway
-    (TrainPipeline.drain, after a test); `PointNet2.fuse_global_level = False` runs the level as separate launches."""
+def global_level_gave_up(dev, warn: bool = True) -> int:
+    """Exchange waits of `global_level_forward` that gave up on this device since the process started (a workgroup of a launch
+    was not resident within the spin limit: another stream or process held the CUs), over every live workspace.  Each such
+    launch was REPAIRED by the gated launch behind it (sn2_global_level_forward: the level is recomputed by one workgroup),
+    so the results are unaffected; a count that grew since the last call is reported once as a StrataHipWarning (the passes took
+    longer; `PointNet2.fuse_global_level = False` runs the level as separate launches).  Reads device words: call it where the
+    host synchronises anyway (TrainPipeline.drain, after a test)."""
     dev = torch.device(dev)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ws = _GLOBAL_WS.get(key)
-    if ws is None:
-        return 0
-    n = int(ws[1][1].item())
-    if n > ws[2]:
-        seen, ws[2] = ws[2], n
-        raise StrataHipError(f"global_level_forward: {n - seen} exchange wait(s) gave up on {dev}: the BatchNorm statistics of "
-                             "those training steps are wrong (the launch's workgroups were not resident together); set "
-                             "PointNet2.fuse_global_level = False where other processes share the device")
-    return n
+    total = 0
+    for r in list(_GLOBAL_WS_ALL):
+        ws = r()
+        if ws is None or ws[1].device.index != key:
+            continue
+        n = int(ws[1][1].item())
+        total += n
+        if n > ws[2]:
+            seen, ws[2] = ws[2], n
+            if warn:
+                import warnings
+                warnings.warn(f"global_level_forward: {n - seen} exchange wait(s) gave up on {dev}; those launches were repeated "
+                              "by the single-workgroup repair launch (results unaffected, the passes took longer); set "
+                              "PointNet2.fuse_global_level = False where other kernels or processes share the device",
+                              StrataHipWarning, stacklevel=2)
+    return total
 
 
 def plot_max_backward(dout, arg, B, R_per_plot, C, dy):

@@ -25,6 +25,7 @@ from torch.nn import Linear as Lin
 from torch.nn import ReLU
 from torch.nn import Sequential as Seq
 
+from . import executor as X
 from . import hip_ops as ops
 from ._lib import MAX_NEIGHBORS as _MAXN, STAT_SLOTS, StrataHipError
 
@@ -168,6 +169,11 @@ class PointNet2(nn.Module):
     # itself is shorter with fewer waves (4.1 against 5.1 ms per 512 plots of 10 000 points) and the loop 2.6 % faster
     fps_waves_many = int(os.environ.get("SN2_FPS_WAVES_MANY", "4"))
     geometry_fork = True       # `_geometry`: the three independent chains behind the level-1 FPS on three streams
+    # One C-ABI call per pass (executor.py; include/strata_hip.h: sn2_net_geometry / sn2_net_forward / sn2_net_backward) instead of
+    # ~25 + ~10 calls issued from Python: same entry points, same descriptors, same order, same bits -- the host time between the
+    # launches is what bounded the reference's loop as written (learning/train.py:44-71).  False: the per-call path below (also
+    # taken while hip_ops.timing measures single entry points).
+    executor = os.environ.get("SN2_EXECUTOR", "1") == "1"
     fuse_eval_head = os.environ.get("SN2_FUSE_EVAL_HEAD", "1") == "1"     # eval: FP1 + head in one kernel (sn2_fp_head_eval)
     # training: SA3, its BatchNorm, the plot max, FP3 and its BatchNorm in one launch (sn2_global_level_forward) instead of five;
     # its workgroups exchange the batch statistics among themselves -- False where other processes share the device
@@ -249,13 +255,58 @@ class PointNet2(nn.Module):
         return _PointNet2Fn.apply(self, xyz_d, cloud_d, None, g, self._dropout_keep(cloud_data, cloud_d), *params)
 
     def _params(self):
-        """The module's parameters in `parameters()` order, walked once (the module tree is fixed after construction; `.to()` /
-        `load_state_dict` keep the Parameter objects): the walk was 0.1 ms of host time per forward and per backward."""
-        ps = self.__dict__.get("_param_list")
-        if ps is None:
-            ps = list(self.parameters())
-            self.__dict__["_param_list"] = ps
+        """The module's parameters in `parameters()` order, walked once (the walk was 0.1 ms of host time per forward and per
+        backward) and VALIDATED per use: the direct children and every cached leaf's Parameter / buffer objects must still be the
+        ones the walk saw -- a swapped `lin2`, `to_empty()`, `load_state_dict(assign=True)` or a Parameter assigned by hand
+        rebuild the list (and with it the executor's model struct) instead of routing gradients to stale objects.  (A module
+        replaced deeper in the tree, e.g. `fp1_module.nn[0] = ...`, is not seen by the cheap check: call `invalidate_caches()`.)"""
+        c = self.__dict__.get("_leafs")
+        if c is not None:
+            mods = self._modules
+            ok = all(mods.get(k) is v for k, v in c[0]) and all(m._parameters.get(n) is p for m, n, p in c[1]) and \
+                all(m._buffers.get(n) is b for m, n, b in c[2])
+            if ok:
+                return self.__dict__["_param_list"]
+        self.invalidate_caches()
+        ps = list(self.parameters())
+        leaf_p, leaf_b = [], []
+        for mod in self.modules():
+            leaf_p += [(mod, n, p) for n, p in mod._parameters.items() if p is not None]
+            leaf_b += [(mod, n, b) for n, b in mod._buffers.items() if b is not None]
+        self.__dict__["_param_list"] = ps
+        self.__dict__["_leafs"] = (tuple(self._modules.items()), leaf_p, leaf_b)
         return ps
+
+    def invalidate_caches(self):
+        """Forget everything derived from the module tree (parameter list, the executor's model struct and plans)."""
+        for k in ("_param_list", "_leafs", "_net_ms"):
+            self.__dict__.pop(k, None)
+
+    def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .float() / to_empty(): tensors may move or be replaced
+        self.invalidate_caches()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_caches()
+        return super().load_state_dict(*a, **kw)
+
+    def _use_executor(self):
+        return bool(self.executor) and ops._timing is None
+
+    def _net_model(self):
+        """The executor's view of this model (executor.ModelStruct), rebuilt when a parameter / buffer object or address or one
+        of the settings it carries changed."""
+        params = self._params()                       # (validates the module tree, drops `_net_ms` when it changed)
+        ms = self.__dict__.get("_net_ms")
+        if ms is None or not ms.current(self, MAX_NEIGHBORS):
+            ms = self.__dict__["_net_ms"] = X.ModelStruct(self, params, MAX_NEIGHBORS)
+        return ms
+
+    def _net_ctx(self):
+        c = self.__dict__.get("_net_ctx_obj")
+        if c is None:
+            c = self.__dict__["_net_ctx_obj"] = X.NetCtx()
+        return c
 
     def _dropout_keep(self, cloud_data, cloud_d):
         """F.dropout(x, p=self.drop, training=self.training) between lin1 and lin2 (model/point_net2.py:142): the (B*N) words
@@ -303,6 +354,9 @@ class PointNet2(nn.Module):
         """Persistent result buffers for `_geometry(..., out=)`: what a software-pipelined training loop hands to the
         position-only kernels of the batches in flight (pipeline.TrainPipeline)."""
         dev = torch.device(device if device is not None else self.lin1.weight.device)
+        if self._use_executor():
+            with torch.cuda.device(dev):
+                return X.ArenaGeometry(self._net_model().plan(self, B, N), dev, self)      # one allocation, views on demand
         M1, M2 = self._sizes(N)
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
         g = _Saved()
@@ -364,6 +418,9 @@ class PointNet2(nn.Module):
         `shared`: the pass runs beside other batches' feature kernels (a pipelined loop, `prefetch_geometry`): the level-1
         FPS takes `fps_waves_shared` waves per plot (include/strata_hip.h: sn2_fps_waves).
         `cloud` (B,10,N) on the device: also run the input-only pieces of the feature pass here (`_input_only`)."""
+        if self._use_executor():
+            return X.geometry(self, self._net_model(), xyz, fps_start, out=out, fork=fork, shared=shared, defer_join=defer_join,
+                              inverted=inverted, cloud=cloud)
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
@@ -521,6 +578,11 @@ class PointNet2(nn.Module):
         return xyz_d, fs
 
     def _forward_impl(self, xyz, cloud, fps_start, training, geo=None, drop_keep=None):
+        if self._use_executor():
+            cov, proba, s = X.forward(self, self._net_model(), xyz, cloud, fps_start, training, geo, drop_keep)
+            if self.log_embeddings:
+                self.last_G_tensor = s.x3
+            return cov, proba, s
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
@@ -543,6 +605,8 @@ class PointNet2(nn.Module):
             raise ValueError("prefetched geometry does not match this batch")
         join = getattr(geo, "_join", None)
         geo._join = None
+        if join == "ctx":
+            raise StrataHipError("a geometry pass launched by the executor with a deferred join must be consumed by the executor")
         if training and not getattr(geo, "has_inverted", True):
             # tables prefetched in eval mode, forward in training mode: the backward pass needs the inverted indices
             ops.interp_index(geo.knn3, B, M2, 1, out=geo.inv3)
@@ -595,7 +659,7 @@ class PointNet2(nn.Module):
             # ... and its max, FP3 (k=1 from the plot's global feature) and both BatchNorms: one launch  (:133-137)
             s.x3 = torch.empty(B, 64, dtype=F32, device=dev)
             s.arg3 = torch.empty(B, 64, dtype=I32, device=dev)
-            ops.global_level_forward(self._sa3_desc(s), self._fp3_desc(s), s.x3, s.arg3)
+            ops.global_level_forward(self._sa3_desc(s), self._fp3_desc(s), s.x3, s.arg3, owner=self)
         else:
             ops.fp_forward(self._sa3_desc(s), training)
             s.x3, s.arg3 = ops.plot_max_forward(s.h_sa3, s.b_sa3.a, s.b_sa3.c, B, M2, 64)
@@ -649,6 +713,8 @@ class PointNet2(nn.Module):
 
     # ------------------------------------------------------------------------------------------ backward
     def _backward_impl(self, s, dcov, dproba):
+        if isinstance(s, X.NetSaved):
+            return X.backward(self, s, dcov, dproba)
         dev = s.xyz.device
         B, N, M1, M2 = s.B, s.N, s.M1, s.M2
         params = self._params()

@@ -37,15 +37,17 @@ def test_struct_layouts_match_the_header_abi():
     import subprocess
     import tempfile
     from stratanet2_vegetation_coverage_maps_amd import _lib
-    src = ('#include <stdio.h>\n#include "strata_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
-           'sizeof(sn2_block),sizeof(sn2_sa),sizeof(sn2_fp),sizeof(sn2_head));return 0;}\n')
+    src = ('#include <stdio.h>\n#include "strata_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+           'sizeof(sn2_block),sizeof(sn2_sa),sizeof(sn2_fp),sizeof(sn2_head),sizeof(sn2_net_layer),sizeof(sn2_net_model),'
+           'sizeof(sn2_net_dims),sizeof(sn2_net_geo),sizeof(sn2_net_act),sizeof(sn2_net_bwd),sizeof(sn2_net_io));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(_lib.Block), ctypes.sizeof(_lib.SA), ctypes.sizeof(_lib.FP), ctypes.sizeof(_lib.Head)]
+    assert sizes == [ctypes.sizeof(c) for c in (_lib.Block, _lib.SA, _lib.FP, _lib.Head, _lib.NetLayer, _lib.NetModel, _lib.NetDims,
+                                                _lib.NetGeo, _lib.NetAct, _lib.NetBwd, _lib.NetIO)]
 
 
 def test_argument_checks_return_before_any_device_work():
@@ -75,3 +77,76 @@ def test_argument_checks_return_before_any_device_work():
     assert fn(ctypes.byref(sa3), ctypes.byref(fp3), fake, fake, fake, fake, None) == -1
     fp3.S_per_plot = 1
     assert fn(ctypes.byref(sa3), ctypes.byref(fp3), fake, fake, fake, fake, None) == -1   # no rows, tables or weights given
+
+
+def _net_model_shell(max_neighbors=2000, n_flat=14997, source_side=1, fuse_eval_head=1):
+    """A sn2_net_model with the reference architecture's layer shapes and no pointers: what the layout and the argument checks read."""
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    m = _lib.NetModel()
+    for L, (ci, co) in zip([m.sa1[0], m.sa1[1], m.sa2, m.sa3, m.fp3, m.fp2, m.fp1],
+                           [(11, 16), (16, 16), (19, 32), (35, 64), (96, 64), (80, 34), (42, 34)]):
+        L.cin, L.cout = ci, co
+    m.n_flat, m.max_neighbors, m.source_side, m.fuse_eval_head = n_flat, max_neighbors, source_side, fuse_eval_head
+    return m
+
+
+def _dims(B, N, M1, M2, maxn=2000, act_bf16=0, p2=0):
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    d = _lib.NetDims()
+    d.B, d.N, d.M1, d.M2, d.cap1, d.cap2, d.act_bf16, d.p2_diam_pix = B, N, M1, M2, min(maxn, N), min(maxn, M1), act_bf16, p2
+    return d
+
+
+def test_network_executor_layouts_match_the_host_shape_tables():
+    """sn2_net_geo_carve / sn2_net_act_carve (host-only arithmetic, no device): every buffer 256-byte aligned, no two overlap, each
+    at least as large as the shape the host views it with (executor._geo_shapes / _act_shapes), everything inside the arena --
+    for the metric's shape, the reference defaults, config 5's plots in bfloat16 and a tiny batch."""
+    from ctypes import byref
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    from stratanet2_vegetation_coverage_maps_amd import executor as X
+    lib = _lib.load()
+    base = X._FAKE_BASE
+    for (B, N, M1, M2, bf, p2) in [(16, 32768, 1024, 256, 0, 20), (20, 10000, 2500, 625, 0, 0), (8, 131072, 1024, 256, 1, 0),
+                                   (2, 64, 16, 4, 0, 0), (512, 10000, 2500, 625, 0, 0)]:
+        m, d = _net_model_shell(), _dims(B, N, M1, M2, act_bf16=bf, p2=p2)
+        sz = ctypes.c_size_t()
+        g = _lib.NetGeo()
+        assert lib.sn2_net_geo_carve(byref(m), byref(d), base, byref(g), byref(sz)) == 0
+        offs = X._offsets(g, X._geo_shapes(B, N, M1, M2, d.cap1, d.cap2))
+        assert ("p2_pix" in offs) == (p2 > 0) and ("ws1" in offs) == (N > 2048 and not (N <= 4096 and B > 32))
+        spans = sorted((o, o + X._ITEM[dt] * int(__import__("math").prod(sh))) for o, dt, sh in offs.values())
+        assert all(o % 256 == 0 for o, _ in spans) and spans[-1][1] <= sz.value
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+        for training in (0, 1):
+            a = _lib.NetAct()
+            assert lib.sn2_net_act_carve(byref(m), byref(d), training, base, byref(a), byref(sz)) == 0
+            offs = X._offsets(a, X._act_shapes(B, N, M1, M2, bf))
+            assert ("h1" in offs) == bool(training or bf)               # the fused eval pass keeps no per-point rows
+            spans = sorted((o, o + X._ITEM[dt] * int(__import__("math").prod(sh))) for o, dt, sh in offs.values())
+            assert all(o % 256 == 0 for o, _ in spans) and spans[-1][1] <= sz.value
+            assert all(x[1] <= y[0] for x, y in zip(spans, spans[1:]))
+        bw = _lib.NetBwd()
+        sz2 = ctypes.c_size_t()
+        assert lib.sn2_net_bwd_carve(byref(m), byref(d), base, base, byref(bw), byref(sz), byref(sz2)) == 0
+        stride = (14997 + 63) // 64 * 64
+        assert bw.images == 32 and bw.image_stride == stride and bw.arena_words * 4 == sz.value
+        assert bw.dy2 - base == 32 * stride * 4 and bw.dy_sa3 - base + B * M2 * 64 * 4 <= sz.value
+
+
+def test_network_executor_argument_checks_return_before_any_device_work():
+    from ctypes import byref
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    lib = _lib.load()
+    m, d = _net_model_shell(), _dims(4, 4096, 512, 128)
+    g, a, b, io = _lib.NetGeo(), _lib.NetAct(), _lib.NetBwd(), _lib.NetIO()
+    sz = ctypes.c_size_t()
+    assert lib.sn2_net_geo_carve(None, byref(d), None, byref(g), byref(sz)) == -1
+    assert lib.sn2_net_geometry(byref(m), byref(d), byref(g), byref(io), None) == -1          # no tables
+    assert lib.sn2_net_forward(byref(m), byref(d), byref(g), byref(a), byref(io), None) == -1  # no parameters
+    assert lib.sn2_net_backward(byref(m), byref(d), byref(g), byref(a), byref(b), None) == -1
+    d.cap1 = 100                                                                                # not min(max_neighbors, N)
+    assert lib.sn2_net_geo_carve(byref(m), byref(d), None, byref(g), byref(sz)) == -1
+    d = _dims(4, 4096, 512, 128)
+    m.fp2.cout = 48                                                                             # not the reference architecture
+    assert lib.sn2_net_geo_carve(byref(m), byref(d), None, byref(g), byref(sz)) == -2
+    assert lib.sn2_net_ctx_destroy(None) == -1

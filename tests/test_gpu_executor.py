@@ -1,0 +1,256 @@
+"""The one-call-per-pass executor (include/strata_hip.h: sn2_net_geometry / sn2_net_forward / sn2_net_backward; executor.py)
+against the per-call path it replaces (`PointNet2.executor = False`: ~25 + ~10 entry points issued from Python).  Same entry
+points, same descriptors, same order => the position-only tables, the forward outputs, the running statistics and the
+counters must be the SAME BITS; the parameter gradients agree to the order of the backward kernels' float atomics (two runs
+of ONE path differ by as much: the weight-gradient sums leave the kernels through `atomicAdd`)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_plotwise_coverages
+from stratanet2_vegetation_coverage_maps_amd import executor as X
+from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
+from stratanet2_vegetation_coverage_maps_amd import losses, point_net2
+from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _model(args, sd, executor, **attrs):
+    args.cuda = 0
+    m = PointNet2(args)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m.executor = executor
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+def _step(m, d, args):
+    cov, proba = m(d)
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+    loss, _ = losses.total_loss(pred, proba, d["coverages"].to(DEV), d["pdf_all"].to(DEV), args.m, args.e)
+    saved = getattr(cov.grad_fn, "saved", None)                # (released by the backward pass: taken before it)
+    loss.backward()
+    torch.cuda.synchronize()
+    return dict(cov=cov.detach().clone(), proba=proba.detach().clone(), loss=float(loss),
+                grads={k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                state={k: v.detach().clone() for k, v in m.state_dict().items()}, saved=saved)
+
+
+def _assert_same_step(a, b, what, grad_tol=2e-5):
+    assert torch.equal(a["cov"], b["cov"]) and torch.equal(a["proba"], b["proba"]), f"{what}: forward outputs differ"
+    for k, v in b["state"].items():
+        assert torch.equal(a["state"][k], v), f"{what}: {k}"
+    worst = 0.0
+    for k, g in b["grads"].items():
+        scale = max(float(g.abs().max()), 1e-12)
+        err = float((a["grads"][k] - g).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= grad_tol, (what, k, err)
+    return worst
+
+
+CASES = [(2, 2048, 0.125, 0.25), (3, 4096, 0.25, 0.25), (5, 10000, 0.25, 0.25), (16, 32768, 1024 / 32768, 0.25)]
+
+
+@pytest.mark.parametrize("B,N,ratio1,ratio2", CASES)
+def test_training_step_is_the_per_call_step(B, N, ratio1, ratio2):
+    args = make_args(subsample_size=N, ratio1=ratio1, r1=1.0, ratio2=ratio2, r2=2.0, log_embeddings=True)
+    d = make_batch(B, N, first_plot=40)
+    d["fps_start"] = torch.stack([torch.arange(B) % 7, torch.arange(B) % 5]).to(torch.int64)
+    sd = network.init_state_dict(4)
+    res = {}
+    for ex in (True, False):
+        m = _model(args, sd, ex).train()
+        res[ex] = _step(m, d, args)
+        res[ex]["G"] = m.last_G_tensor.clone()
+        assert isinstance(res[ex]["saved"], X.NetSaved) == ex          # the path that ran is the one asked for
+    worst = _assert_same_step(res[True], res[False], f"{B}x{N}")
+    assert torch.equal(res[True]["G"], res[False]["G"])
+    # a second run of the per-call path alone: the yardstick for the gradients' agreement
+    m = _model(args, sd, False).train()
+    again = _step(m, d, args)
+    self_err = max(float((again["grads"][k] - g).abs().max()) / max(float(g.abs().max()), 1e-12) for k, g in res[False]["grads"].items())
+    print(f"  {B} x {N}: executor vs per-call gradients {worst:.1e} of scale (per-call vs itself {self_err:.1e}); loss {res[True]['loss']:.6f}")
+    assert res[True]["loss"] == res[False]["loss"]
+
+
+@pytest.mark.parametrize("B,N", [(3, 4096), (8, 10000)])
+def test_geometry_tables_are_the_per_call_tables(B, N):
+    args = make_args(subsample_size=N, ratio1=0.25, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=3)
+    xyz = d["xyz"].to(DEV)
+    cloud = d["cloud"].to(DEV)
+    fs = torch.stack([torch.arange(B) % 11, torch.arange(B) % 3]).to(device=DEV, dtype=torch.int32)
+    sd = network.init_state_dict(1)
+    tabs = {}
+    for ex in (True, False):
+        m = _model(args, sd, ex).train()
+        m.p2_diam_pix = args.diam_pix
+        for fork in (True, False):
+            g = m._geometry(xyz, fs, fork=fork, inverted=True, cloud=cloud)
+            torch.cuda.synchronize()
+            assert isinstance(g, X.ArenaGeometry) == ex
+            cnt1, cnt2 = g.cnt1.long(), g.cnt2.long()
+            k1 = torch.arange(g.nbr1.shape[1], device=DEV)[None, :] < cnt1[:, None]
+            k2 = torch.arange(g.nbr2.shape[1], device=DEV)[None, :] < cnt2[:, None]
+            tabs[(ex, fork)] = dict(idx1=g.idx1.clone(), idx2=g.idx2.clone(), pos1=g.pos1_aos.clone(), pos2=g.pos2_soa.clone(),
+                                    cnt1=g.cnt1.clone(), cnt2=g.cnt2.clone(), nbr1=torch.where(k1, g.nbr1, -1), nbr2=torch.where(k2, g.nbr2, -1),
+                                    tot=torch.cat([g.tot1, g.tot2]).clone(), ord1=g.ord1.clone(), ord2=g.ord2.clone(),
+                                    knn1i=g.knn1[0].clone(), knn1w=g.knn1[1].clone(), knn2i=g.knn2[0].clone(), knn2w=g.knn2[1].clone(),
+                                    knn3w=g.knn3[1].clone(), rows0=g.rows0.clone(), pix=g.p2_pix.clone(), mm=g.p2_mm.clone())
+    ref = tabs[(False, False)]
+    for key, t in tabs.items():
+        for k, v in ref.items():
+            assert torch.equal(t[k], v), (key, k)
+
+
+@pytest.mark.parametrize("fused_head", [True, False])
+def test_eval_forward_is_the_per_call_forward(fused_head):
+    B, N = 6, 10000
+    args = make_args(subsample_size=N)                                   # reference defaults: ratios .25/.25, r sqrt2/sqrt8
+    d = make_batch(B, N, first_plot=11)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    sd = network.init_state_dict(2)
+    out = {}
+    for ex in (True, False):
+        m = _model(args, sd, ex, fuse_eval_head=fused_head).eval()
+        with torch.no_grad():
+            out[ex] = [t.clone() for t in m(d)]
+            geo = m.prefetch_geometry(d)                                 # the parcel loop's path: tables from a side stream
+            out[(ex, "prefetch")] = [t.clone() for t in m({**d, "geometry": geo})]
+        torch.cuda.synchronize()
+    for k in (True, (True, "prefetch"), (False, "prefetch")):
+        assert torch.equal(out[k][0], out[False][0]) and torch.equal(out[k][1], out[False][1]), k
+
+
+def test_host_inputs_prefetch_and_persistent_handles():
+    """The three ways a batch reaches the executor: CPU tensors as the reference's DataLoader hands them (pinned upload ring,
+    geometry launched on `xyz` while `cloud` follows: a deferred join consumed by the forward call), a prefetched handle, and a
+    persistent handle from `alloc_geometry` filled twice (a pipeline slot)."""
+    B, N = 4, 8192
+    args = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=21)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    sd = network.init_state_dict(6)
+    ref = _step(_model(args, sd, False).train(), {**d, "cloud": d["cloud"].to(DEV), "xyz": d["xyz"].to(DEV)}, args)
+    # host tensors
+    a = _step(_model(args, sd, True).train(), d, args)
+    _assert_same_step(a, ref, "host inputs")
+    # prefetched in EVAL mode (no inverted tables), consumed by a training forward: the forward call builds them
+    m = _model(args, sd, True)
+    geo = m.eval().prefetch_geometry(d)
+    assert not geo.has_inverted
+    m.train()
+    b = _step(m, {**d, "geometry": geo}, args)
+    _assert_same_step(b, ref, "prefetched handle")
+    # a persistent handle, filled twice (other batch first)
+    m = _model(args, sd, True).train()
+    g = m.alloc_geometry(B, N)
+    other = make_batch(B, N, first_plot=77)
+    fs = torch.zeros(2, B, dtype=torch.int32, device=DEV)
+    m._geometry(other["xyz"].to(DEV), fs, out=g, fork=False, shared=True, cloud=other["cloud"].to(DEV))
+    m._geometry(d["xyz"].to(DEV), fs, out=g, fork=False, shared=True, cloud=d["cloud"].to(DEV))
+    c = _step(m, {"cloud": d["cloud"].to(DEV), "xyz": d["xyz"].to(DEV), "geometry": g, "coverages": d["coverages"],
+                  "pdf_all": d["pdf_all"]}, args)
+    _assert_same_step(c, ref, "persistent handle")
+
+
+def test_dropout_bf16_and_lowered_cap():
+    B, N = 2, 4096
+    sd = network.init_state_dict(8)
+    # dropout with the keep-mask handed to both paths
+    args = make_args(subsample_size=N, ratio1=0.25, r1=1.0, ratio2=0.25, r2=2.0, drop=0.4)
+    d = make_batch(B, N, first_plot=5)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    d["dropout_mask"] = (torch.rand(B * N, 16, generator=torch.Generator().manual_seed(1)) > 0.4).float()
+    r = {ex: _step(_model(args, sd, ex).train(), d, args) for ex in (True, False)}
+    _assert_same_step(r[True], r[False], "dropout")
+    # bfloat16 operands on the matrix cores
+    args = make_args(subsample_size=N, ratio1=0.25, r1=1.0, ratio2=0.25, r2=2.0)
+    args.mma_dtype = "bf16"
+    d.pop("dropout_mask")
+    r = {ex: _step(_model(args, sd, ex).train(), d, args) for ex in (True, False)}
+    # (the input gradients of SA2 leave their kernel through float atomics and are then ROUNDED to bfloat16 as operands of SA1's
+    # backward: a last-bit difference in a sum can move an operand by a whole bfloat16 ulp -- the per-call path against itself
+    # is the yardstick, printed)
+    again = _step(_model(args, sd, False).train(), d, args)
+    self_err = max(float((again["grads"][k] - g).abs().max()) / max(float(g.abs().max()), 1e-12) for k, g in r[False]["grads"].items())
+    worst = _assert_same_step(r[True], r[False], "bf16", grad_tol=max(5e-3, 4 * self_err))
+    print(f"  bf16: executor vs per-call gradients {worst:.1e} of scale (per-call vs itself {self_err:.1e})")
+    # a lowered neighbour cap (tests monkeypatch it): another row stride of the lists, another model struct
+    args = make_args(subsample_size=N, ratio1=0.25, r1=2.0, ratio2=0.25, r2=3.0)
+    old = point_net2.MAX_NEIGHBORS
+    point_net2.MAX_NEIGHBORS = 48
+    try:
+        r = {ex: _step(_model(args, sd, ex).train(), d, args) for ex in (True, False)}
+    finally:
+        point_net2.MAX_NEIGHBORS = old
+    _assert_same_step(r[True], r[False], "cap 48")
+    assert int(r[True]["saved"].nbr1.shape[1]) == 48
+
+
+def test_replaced_parameters_and_moved_storage_are_seen():
+    """the cached parameter list (and now the executor's model struct) must follow a Parameter that is replaced or
+    re-homed after the first forward: gradients have to reach the objects `parameters()` yields NOW."""
+    B, N = 2, 2048
+    args = make_args(subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=1)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    sd = network.init_state_dict(5)
+    m = _model(args, sd, True).train()
+    _step(m, d, args)
+    # (1) a Parameter assigned by hand (fine-tuning a fresh output layer)
+    new_w = torch.nn.Parameter(m.lin2.weight.detach().clone() * 0.5)
+    m.lin2.weight = new_w
+    m.zero_grad(set_to_none=True)
+    a = _step(m, d, args)
+    assert new_w.grad is not None and float(new_w.grad.abs().max()) > 0
+    # the same two steps with the per-call path
+    m2 = _model(args, sd, False).train()
+    _step(m2, d, args)
+    m2.lin2.weight = torch.nn.Parameter(sd["lin2.weight"].clone().to(DEV) * 0.5)
+    b = _step(m2, d, args)
+    assert torch.equal(a["cov"], b["cov"])
+    # (2) every parameter re-homed into one flat buffer (optim.flatten_parameters): addresses move, objects stay
+    from stratanet2_vegetation_coverage_maps_amd.optim import flatten_parameters
+    m3 = _model(args, sd, True).train()
+    r0 = _step(m3, d, args)
+    m3.load_state_dict({k: v.clone() for k, v in sd.items()})
+    flatten_parameters(m3)
+    m3.zero_grad(set_to_none=True)
+    r1 = _step(m3, d, args)
+    assert torch.equal(r0["cov"], r1["cov"])
+    with torch.no_grad():
+        m3._flat_params.mul_(0.5)                                      # the kernels must read the re-homed storage
+    r2 = _step(m3, d, args)
+    assert not torch.equal(r2["cov"], r1["cov"])
+
+
+def test_argument_errors_come_back_as_codes_not_faults():
+    from ctypes import byref
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    lib = _lib.load()
+    args = make_args(subsample_size=2048, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0)
+    m = _model(args, network.init_state_dict(0), True).train()
+    ms = m._net_model()
+    plan = ms.plan(m, 2, 2048)
+    g = X.ArenaGeometry(plan, DEV, m)
+    io = _lib.NetIO()
+    assert lib.sn2_net_geometry(byref(ms.c), byref(plan.dims), byref(g.cgeo), byref(io), None) == -1      # no xyz
+    bad = _lib.NetDims.from_buffer_copy(plan.dims)
+    bad.cap1 = 7
+    assert lib.sn2_net_geometry(byref(ms.c), byref(bad), byref(g.cgeo), byref(io), None) == -1            # cap != min(max_neighbors, N)
+    act = _lib.NetAct()
+    assert lib.sn2_net_forward(byref(ms.c), byref(plan.dims), byref(g.cgeo), byref(act), byref(io), None) == -1
+    # a handle of another cap is refused on the host before any call
+    old = point_net2.MAX_NEIGHBORS
+    point_net2.MAX_NEIGHBORS = 64
+    try:
+        with pytest.raises(ValueError, match="geometry buffers"):
+            m._geometry(torch.zeros(2, 3, 2048, device=DEV), torch.zeros(2, 2, dtype=torch.int32, device=DEV), out=g)
+    finally:
+        point_net2.MAX_NEIGHBORS = old
