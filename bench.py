@@ -165,7 +165,8 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_plotwise_coverages  # noqa: E402
+import numpy as np  # noqa: E402
+from stratanet2_vegetation_coverage_maps_amd import PointNet2, project_to_2d_rasters, project_to_plotwise_coverages  # noqa: E402
 from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops  # noqa: E402
 from stratanet2_vegetation_coverage_maps_amd import losses  # noqa: E402
 from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters, shard_of_rank  # noqa: E402
@@ -615,6 +616,53 @@ def dropin_eager_leg(dev, B, n_points, steps=40, warmup=5):
                     "torch.optim.Adam, the three loss terms called one by one (losses.get_*), eager launches, geometry and features back to back"}
 
 
+def dropin_predict_leg(dev, plots=512, points=10000, batch=20, repeat=3):
+    """The drop-in under the reference's INFERENCE loop as written (/root/reference/predict.py:96-126 with
+    inference/predict_utils.py:94-102): `model.eval()`, no `torch.no_grad()` (the reference has none), CPU-resident batches of
+    `args.batch_size` = 20 plots (config.py:85) x `subsample_size` = 10 000 points as its DataLoader collates them,
+    `model(cloud_data)`, `get_batch_format`, then PER PLOT `project_to_2d_rasters(clouds[idx], coverages_pointwise[idx], args)`,
+    which returns a numpy array (one device-to-host read per plot, project_to_2d.py:78-113).  The GIS steps behind it (weights
+    band, geotransform, GeoTIFF file: GDAL / rasterio) are out of scope and not run.  `config4_parcel_inference` is the same work
+    through `inference.predict_parcel` (512 plots per launch, rasters and mosaic on the device)."""
+    args = make_args(cuda=dev.index or 0, subsample_size=points)           # reference defaults: ratios .25/.25, r sqrt2/sqrt8
+    torch.manual_seed(0)
+    model = PointNet2(args).eval()
+    batches = []
+    for s0 in range(0, plots, batch):
+        d = make_batch(min(batch, plots - s0), points, first_plot=s0)
+        batches.append({"cloud": d["cloud"], "xyz": d["xyz"]})
+
+    def run():
+        n = 0
+        for cloud_data in batches:
+            clouds = cloud_data["cloud"]
+            coverages_pointwise, _ = model(cloud_data)
+            if len(coverages_pointwise.shape) < 3:
+                coverages_pointwise = model.get_batch_format(coverages_pointwise)
+            for idx in range(clouds.shape[0]):
+                rasters = project_to_2d_rasters(clouds[idx], coverages_pointwise[idx], args)
+                n += 1
+        return n, rasters
+
+    run()
+    times = []
+    for _ in range(repeat):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        n, rasters = run()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+    med = sorted(times)[len(times) // 2]
+    del model, batches
+    torch.cuda.empty_cache()
+    return {"plots_per_s": round(n / med, 1), "ms_per_batch_of_20": round(med / ((n + batch - 1) // batch) * 1e3, 3),
+            "runs_s": [round(t, 4) for t in times], "statistic": f"median of {repeat} passes over {n} plots",
+            "last_raster_finite_pixels": int(np.isfinite(rasters).sum()),
+            "what": f"predict.py:96-126 as written: eval mode, autograd on, {batch} plots x {points} pts per batch from HOST tensors, "
+                    "model(cloud_data), get_batch_format, project_to_2d_rasters per plot (numpy out, one D2H read per plot); "
+                    "GIS file output not run"}
+
+
 def secondary_legs(dev):
     """name -> thunk: the other configurations BASELINE.json names, as compact legs of the same process."""
     return {"config2_3sa_arch": lambda: secondary_train_leg(dev, "3sa", 16, 32768, "f32", 100, 10),
@@ -623,6 +671,7 @@ def secondary_legs(dev):
             "config4_parcel_inference": lambda: inference_leg(dev),
             "config4_parcel_inference_bf16": lambda: inference_leg(dev, dtype="bf16"),
             "dropin_eager": lambda: dropin_eager_leg(dev, 16, 32768),
+            "dropin_predict": lambda: dropin_predict_leg(dev),
             "exchange_world1": lambda: exchange_leg(dev)}
 
 

@@ -386,7 +386,11 @@ int sn2_mosaic_finalize(const float *mean, const float *wsum, int H, int W, int 
  * pred (B,4) fp32 plot-wise coverages, gt (B,4) fp64, proba (R,4) fp32 pointwise class probabilities, pdf (R,3) fp64 the
  * KDE-mixture densities at the points' heights (the reference evaluates them on the CPU each step, :30-42; KDE fitting is
  * out of scope, so they are an input).  partials: 2*SN2_LOSS_BLOCKS fp64 workspace.  out[4] = total, absolute, NLL,
- * entropy.  Backward: grad_total = device scalar d(objective)/d(total); writes dpred (B,4), dproba (R,4). */
+ * entropy.  Backward: grad_total = device scalar d(objective)/d(total); writes dpred (B,4), dproba (R,4).
+ * A term that is switched off is SKIPPED (not multiplied by zero) and its inputs may be absent -- what the reference's loop,
+ * which calls the three functions one by one (learning/train.py:58-60), needs: B = 0: no absolute term (pred, gt, dpred
+ * unused); m == 0: no NLL (pdf unused: rows that are no probability vectors give no 0 * log(<= 0) = NaN); e == 0: no entropy;
+ * R = 0: no pointwise term (proba, pdf, partials, dproba unused).  The skipped components of out[] are 0. */
 /* KDE-mixture densities at the points' heights -- KdeMixture.predict, learning/kde_mixture.py:65-70 (three scipy
  * interp1d(kind="linear") over one knot vector), which get_NLL_loss evaluates on the CPU for all B*N points every step
  * (learning/loss_functions.py:30-42).  cloud (B,C,N) fp32, height = cloud[:, z_channel, :] * z_max formed in fp32;

@@ -32,21 +32,33 @@ def _timed_upload(self, t, stream=None, dtype=None, out=None, consumer=None):
     return r
 _ops.PinnedRing.upload = _timed_upload
 _ops._UPLOAD_TRACE = []
+GPU_EV = os.environ.get("SN2_GPU_EVENTS") == "1"     # also: when did the DEVICE get to the end of each phase (events on the main stream)
+def _ev():
+    if not GPU_EV:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
 for it in range(14):
     d = batches[it % 4]
     torch.cuda.synchronize()
+    ev = [_ev()]
     t = [time.perf_counter()]
-    gt = d["coverages"].cuda(dev); t.append(time.perf_counter())
-    opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
-    cov, proba = model({"cloud": d["cloud"], "xyz": d["xyz"]}); t.append(time.perf_counter())
-    pred = project_to_plotwise_coverages(cov, d["cloud"], args); t.append(time.perf_counter())
+    gt = d["coverages"].cuda(dev); t.append(time.perf_counter()); ev.append(_ev())
+    opt.zero_grad(set_to_none=True); t.append(time.perf_counter()); ev.append(_ev())
+    cov, proba = model({"cloud": d["cloud"], "xyz": d["xyz"]}); t.append(time.perf_counter()); ev.append(_ev())
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args); t.append(time.perf_counter()); ev.append(_ev())
     la = losses.get_absolute_loss(pred, gt)
     ll = losses.get_NLL_loss(proba, d["pdf_all"])
     le = losses.get_entropy_loss(proba)
-    loss = la + args.m * ll + args.e * le; t.append(time.perf_counter())
-    loss.backward(); t.append(time.perf_counter())
-    opt.step(); t.append(time.perf_counter())
+    loss = la + args.m * ll + args.e * le; t.append(time.perf_counter()); ev.append(_ev())
+    loss.backward(); t.append(time.perf_counter()); ev.append(_ev())
+    opt.step(); t.append(time.perf_counter()); ev.append(_ev())
     _ = (la.item(), ll.item(), loss.item()); t.append(time.perf_counter())
+    if GPU_EV:
+        torch.cuda.synchronize()
+        print("   host issued at ", " ".join(f"{(x - t[0]) * 1e3:7.3f}" for x in t[1:]))
+        print("   device done at ", " ".join(f"{ev[0].elapsed_time(e):7.3f}" for e in ev[1:]))
     print("    ", [(w, round(v, 3)) for w, v in _ops._UPLOAD_TRACE]); _ops._UPLOAD_TRACE.clear()
     print(it, " ".join(f"{(t[k + 1] - t[k]) * 1e3:7.3f}" for k in range(len(names))), flush=True)
     if it >= 4:

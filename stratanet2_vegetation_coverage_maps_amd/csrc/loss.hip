@@ -20,20 +20,28 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// one row per lane: 16 B of probabilities + 24 B of densities, both contiguous across the wave
+// one row per lane: 16 B of probabilities + 24 B of densities, both contiguous across the wave.  NLL / ENT: which of the two
+// pointwise terms are wanted (a term whose weight is zero is SKIPPED, not multiplied by zero: a caller that asks for the entropy
+// of rows that are no probability vectors -- the reference's docstring says "coverage raster" -- must not get 0 * log(<= 0) =
+// NaN from a likelihood nobody asked for, and the densities need not exist)
+template <bool NLL, bool ENT>
 __global__ __launch_bounds__(256) void loss_point_kernel(const float4* __restrict__ proba, const double* __restrict__ pdf,
                                                          int R, double* __restrict__ partials) {
     __shared__ double s_part[2][4];
     double nll = 0.0, ent = 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) {
         const float4 p = proba[i];
-        const double f0 = pdf[3 * (size_t)i], f1 = pdf[3 * (size_t)i + 1], f2 = pdf[3 * (size_t)i + 2];
-        const float pg = p.x + p.y;                                   // pred[:, :2].sum(1) in fp32 (:44)
-        const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
-        nll -= log(lik);
-        const float e2 = p.z * logf(p.z + EPS_F) + (1.f - p.z) * logf(1.f - p.z + EPS_F);
-        const float e3 = p.w * logf(p.w + EPS_F) + (1.f - p.w) * logf(1.f - p.w + EPS_F);
-        ent -= (double)e2 + (double)e3;
+        if constexpr (NLL) {
+            const double f0 = pdf[3 * (size_t)i], f1 = pdf[3 * (size_t)i + 1], f2 = pdf[3 * (size_t)i + 2];
+            const float pg = p.x + p.y;                               // pred[:, :2].sum(1) in fp32 (:44)
+            const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
+            nll -= log(lik);
+        }
+        if constexpr (ENT) {
+            const float e2 = p.z * logf(p.z + EPS_F) + (1.f - p.z) * logf(1.f - p.z + EPS_F);
+            const float e3 = p.w * logf(p.w + EPS_F) + (1.f - p.w) * logf(1.f - p.w + EPS_F);
+            ent -= (double)e2 + (double)e3;
+        }
     }
     nll = wave_sum_f64(nll);
     ent = wave_sum_f64(ent);
@@ -69,8 +77,8 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const double l_abs = s[2][0] / (3.0 * B), l_nll = s[0][0] / R;
-        const double l_ent = (double)(float)(s[1][0] / (2.0 * R));      // the reference's entropy is an fp32 tensor
+        const double l_abs = B > 0 ? s[2][0] / (3.0 * B) : 0.0, l_nll = nblocks > 0 ? s[0][0] / R : 0.0;
+        const double l_ent = nblocks > 0 ? (double)(float)(s[1][0] / (2.0 * R)) : 0.0;      // the reference's entropy is an fp32 tensor
         out[0] = l_abs + m * l_nll + e * l_ent;
         out[1] = l_abs;
         out[2] = l_nll;
@@ -79,27 +87,35 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
 }
 
 // d loss / d proba, d loss / d pred for the upstream gradient g of the TOTAL loss (device scalar)
+template <bool NLL, bool ENT>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ pred, const double* __restrict__ gt, int B,
                                                        const float4* __restrict__ proba, const double* __restrict__ pdf, int R,
                                                        double m, double e, const double* __restrict__ gout,
                                                        float* __restrict__ dpred, float4* __restrict__ dproba) {
     const double g = gout[0];
-    const double cn = g * m / R, ce = g * e / (2.0 * R);
+    const double cn = R > 0 ? g * m / R : 0.0, ce = R > 0 ? g * e / (2.0 * R) : 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += gridDim.x * 256) {
         const float4 p = proba[i];
-        const double f0 = pdf[3 * (size_t)i], f1 = pdf[3 * (size_t)i + 1], f2 = pdf[3 * (size_t)i + 2];
-        const float pg = p.x + p.y;
-        const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
-        const double il = -cn / lik;
-        const float h2 = -(logf(p.z + EPS_F) + p.z / (p.z + EPS_F) - logf(1.f - p.z + EPS_F) - (1.f - p.z) / (1.f - p.z + EPS_F));
-        const float h3 = -(logf(p.w + EPS_F) + p.w / (p.w + EPS_F) - logf(1.f - p.w + EPS_F) - (1.f - p.w) / (1.f - p.w + EPS_F));
+        double d0 = 0.0, d2 = 0.0, d3 = 0.0;
+        if constexpr (NLL) {
+            const double f0 = pdf[3 * (size_t)i], f1 = pdf[3 * (size_t)i + 1], f2 = pdf[3 * (size_t)i + 2];
+            const float pg = p.x + p.y;
+            const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
+            const double il = -cn / lik;
+            d0 = il * f0, d2 = il * f1, d3 = il * f2;
+        }
+        if constexpr (ENT) {
+            const float h2 = -(logf(p.z + EPS_F) + p.z / (p.z + EPS_F) - logf(1.f - p.z + EPS_F) - (1.f - p.z) / (1.f - p.z + EPS_F));
+            const float h3 = -(logf(p.w + EPS_F) + p.w / (p.w + EPS_F) - logf(1.f - p.w + EPS_F) - (1.f - p.w) / (1.f - p.w + EPS_F));
+            d2 += ce * (double)h2, d3 += ce * (double)h3;
+        }
         float4 d;
-        d.x = d.y = (float)(il * f0);
-        d.z = (float)(il * f1 + ce * (double)h2);
-        d.w = (float)(il * f2 + ce * (double)h3);
+        d.x = d.y = (float)d0;
+        d.z = (float)d2;
+        d.w = (float)d3;
         dproba[i] = d;
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && dpred) {
         for (int i = threadIdx.x; i < 4 * B; i += 256) {
             const int col = i & 3;
             float r = 0.f;
@@ -153,19 +169,37 @@ inline int loss_grid(int R) {
 
 extern "C" int sn2_loss_forward(const float* pred, const double* gt, int B, const float* proba, const double* pdf, int R,
                                 double m, double e, double* partials, double* out, void* stream) {
-    if (!pred || !gt || !proba || !pdf || !partials || !out || B <= 0 || R <= 0) return SN2_EINVAL;
-    const int nb = loss_grid(R);
+    // a term that is switched off is skipped and its inputs may be absent: B = 0 (no absolute term: pred, gt unused),
+    // m == 0 (no NLL: pdf unused), e == 0 (no entropy); m == e == 0 or R == 0: no pass over the points at all
+    if (!out || B < 0 || R < 0 || (B > 0 && (!pred || !gt))) return SN2_EINVAL;
+    const bool nll = m != 0.0 && R > 0, ent = e != 0.0 && R > 0;
+    if ((nll || ent) && (!proba || !partials)) return SN2_EINVAL;
+    if (nll && !pdf) return SN2_EINVAL;
+    const int nb = (nll || ent) ? loss_grid(R) : 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_point_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4*>(proba), pdf, R, partials);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, pred, gt, B, (const double*)partials, nb, R, m, e, out);
+    const float4* p4 = reinterpret_cast<const float4*>(proba);
+    if (nll && ent) hipLaunchKernelGGL((loss_point_kernel<true, true>), dim3(nb), dim3(256), 0, st, p4, pdf, R, partials);
+    else if (nll) hipLaunchKernelGGL((loss_point_kernel<true, false>), dim3(nb), dim3(256), 0, st, p4, pdf, R, partials);
+    else if (ent) hipLaunchKernelGGL((loss_point_kernel<false, true>), dim3(nb), dim3(256), 0, st, p4, pdf, R, partials);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, pred, gt, B, (const double*)partials, nb, R > 0 ? R : 1, m, e, out);
     SN2_RETURN_LAUNCH();
 }
 
 extern "C" int sn2_loss_backward(const float* pred, const double* gt, int B, const float* proba, const double* pdf, int R,
                                  double m, double e, const double* grad_total, float* dpred, float* dproba, void* stream) {
-    if (!pred || !gt || !proba || !pdf || !grad_total || !dpred || !dproba || B <= 0 || R <= 0) return SN2_EINVAL;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(loss_grid(R)), dim3(256), 0, (hipStream_t)stream, pred, gt, B,
-                       reinterpret_cast<const float4*>(proba), pdf, R, m, e, grad_total, dpred, reinterpret_cast<float4*>(dproba));
+    if (!grad_total || B < 0 || R < 0 || (B > 0 && (!pred || !gt || !dpred)) || (R > 0 && (!proba || !dproba))) return SN2_EINVAL;
+    const bool nll = m != 0.0 && R > 0, ent = e != 0.0 && R > 0;
+    if (nll && !pdf) return SN2_EINVAL;
+    if (B == 0 && R == 0) return 0;
+    const int grid = R > 0 ? loss_grid(R) : 1;
+    hipStream_t st = (hipStream_t)stream;
+    const float4* p4 = reinterpret_cast<const float4*>(proba);
+    float4* d4 = reinterpret_cast<float4*>(dproba);
+    float* dp = B > 0 ? dpred : nullptr;
+    if (nll && ent) hipLaunchKernelGGL((loss_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, R, m, e, grad_total, dp, d4);
+    else if (nll) hipLaunchKernelGGL((loss_bwd_kernel<true, false>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, R, m, e, grad_total, dp, d4);
+    else if (ent) hipLaunchKernelGGL((loss_bwd_kernel<false, true>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, R, m, e, grad_total, dp, d4);
+    else hipLaunchKernelGGL((loss_bwd_kernel<false, false>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, R, m, e, grad_total, dp, d4);
     SN2_RETURN_LAUNCH();
 }
 

@@ -16,8 +16,12 @@ constexpr int WIDTH_SUM = 260;
 constexpr int GRAD_IMAGES = 32;                              // hip_ops.GRAD_IMAGES
 constexpr int GL_MAX_PLOTS_HOST = 28;                        // sn2_global_level_forward's limit (fp.hip: GL_MAX_PLOTS)
 
+// events of a forked geometry pass.  Chain b (level 2): FPS, ball query, work items [b_tables: all SA2 needs] -> the two small
+// 3-NN tables [b_nn: all FP3 / FP2 need] -> their inverted indices [b_done].  Chain c: the per-point 3-NN table [c_nn: all FP1
+// needs] -> its inverted index [c_done].  The inverted indices are read by the backward pass only, so a forward pass that
+// consumes a deferred join waits for each table where it first reads it and for b_done / c_done at its very end.
 struct NetCtx {
-    hipEvent_t fork, b_done, c_done, pack_fork, packed;
+    hipEvent_t fork, b_tables, b_nn, b_done, c_nn, c_done, pack_fork, packed;
 };
 
 inline long rows_stat_limit() { return 64L * SN2_STAT_SLOTS; }
@@ -269,11 +273,14 @@ int geometry_impl(const sn2_net_model* m, const sn2_net_dims* d, const sn2_net_g
     SN2_TRY(sn2_fps_status(g->pos1_soa, B, M1, M2, start1, g->idx2, g->pos2_soa, g->pos2_aos, ws2, 0, io->fps_status, sb));
     SN2_TRY(sn2_ball_query(g->pos1_soa, B, M1, g->pos2_soa, M2, m->r2_sq, d->cap2, g->nbr2, g->cnt2, g->tot2, ws2, sb));
     SN2_TRY(sn2_sa_order(g->cnt2, B, M2, g->ord2, sb));
+    if (fork) NET_HIP(hipEventRecord(ctx->b_tables, sb));
     SN2_TRY(sn2_three_nn(g->pos3, B, 1, g->pos2_soa, M2, 1, g->knn3_idx, g->knn3_w, nullptr, nullptr, sb));
     SN2_TRY(three_nn_any(g->pos2_soa, B, M2, g->pos1_soa, M1, 3, g->knn2_idx, g->knn2_w, g->nn_ws2, sb));
+    if (fork) NET_HIP(hipEventRecord(ctx->b_nn, sb));
     if (inverted) SN2_TRY(inverted_tables(d, g, 1, sb));
     // (c) the per-point table
     SN2_TRY(three_nn_any(g->pos1_soa, B, M1, g->xyz, N, 3, g->knn1_idx, g->knn1_w, g->nn_ws1, sc));
+    if (fork) NET_HIP(hipEventRecord(ctx->c_nn, sc));
     if (inverted) SN2_TRY(inverted_tables(d, g, 2, sc));
     // the input-only pieces of the feature pass
     if (flags & SN2_NET_INPUT_ONLY) {
@@ -302,8 +309,8 @@ extern "C" int sn2_net_ctx_create(void** out) {
     if (!out) return SN2_EINVAL;
     NetCtx* c = new (std::nothrow) NetCtx();
     if (!c) return SN2_EINVAL;
-    hipEvent_t* ev[5] = {&c->fork, &c->b_done, &c->c_done, &c->pack_fork, &c->packed};
-    for (int i = 0; i < 5; ++i) {
+    hipEvent_t* ev[8] = {&c->fork, &c->b_tables, &c->b_nn, &c->b_done, &c->c_nn, &c->c_done, &c->pack_fork, &c->packed};
+    for (int i = 0; i < 8; ++i) {
         hipError_t e = hipEventCreateWithFlags(ev[i], hipEventDisableTiming);
         if (e != hipSuccess) {
             for (int j = 0; j < i; ++j) (void)hipEventDestroy(*ev[j]);
@@ -319,7 +326,10 @@ extern "C" int sn2_net_ctx_destroy(void* ctx) {
     if (!ctx) return SN2_EINVAL;
     NetCtx* c = static_cast<NetCtx*>(ctx);
     (void)hipEventDestroy(c->fork);
+    (void)hipEventDestroy(c->b_tables);
+    (void)hipEventDestroy(c->b_nn);
     (void)hipEventDestroy(c->b_done);
+    (void)hipEventDestroy(c->c_nn);
     (void)hipEventDestroy(c->c_done);
     (void)hipEventDestroy(c->pack_fork);
     (void)hipEventDestroy(c->packed);
@@ -485,9 +495,10 @@ extern "C" int sn2_net_forward(const sn2_net_model* m, const sn2_net_dims* d, co
     sn2_sa sa;
     sa1_desc(&sa, m, d, g, a, nograd, nullptr);
     SN2_TRY(sn2_sa_forward(&sa, training, cur));
-    if (join_b) NET_HIP(hipStreamWaitEvent(cur, ctx->b_done, 0));       // chain b: level-2 tables, the small 3-NN tables
+    if (join_b) NET_HIP(hipStreamWaitEvent(cur, ctx->b_tables, 0));     // chain b: the level-2 centroids, lists and work items
     sa2_desc(&sa, m, d, g, a, nograd, nullptr, nullptr);
     SN2_TRY(sn2_sa_forward(&sa, training, cur));
+    if (join_b) NET_HIP(hipStreamWaitEvent(cur, ctx->b_nn, 0));         // ... its two small 3-NN tables
     // ---- global level: SA3 -> plot max -> FP3                                                (:133-137, 37-42, 62-67)
     sn2_fp p3, pf3;
     fp_desc(&p3, d, a, sa3_in(m, d, g, a), nograd);
@@ -504,7 +515,7 @@ extern "C" int sn2_net_forward(const sn2_net_model* m, const sn2_net_dims* d, co
     sn2_fp p2;
     fp_desc(&p2, d, a, fp2_in(m, d, g, a, a->src_ws2), nograd);
     SN2_TRY(sn2_fp_forward(&p2, training, cur));
-    if (join_c) NET_HIP(hipStreamWaitEvent(cur, ctx->c_done, 0));       // chain c: the per-point 3-NN table (+ inverted index)
+    if (join_c) NET_HIP(hipStreamWaitEvent(cur, ctx->c_nn, 0));         // chain c: the per-point 3-NN table
     // ---- FP1 + head                                                                          (:139-151)
     sn2_fp p1;
     sn2_head hd;
@@ -514,12 +525,18 @@ extern "C" int sn2_net_forward(const sn2_net_model* m, const sn2_net_dims* d, co
         a2.h1 = nullptr;
         fp_desc(&p1, d, &a2, fp1_in(m, d, g, &a2, a->src_ws1), nograd);
         head_desc(&hd, m, d, &a2, 0);
-        return sn2_fp_head_eval(&p1, &hd, cur);
+        SN2_TRY(sn2_fp_head_eval(&p1, &hd, cur));
+    } else {
+        fp_desc(&p1, d, a, fp1_in(m, d, g, a, a->src_ws1), nograd);
+        SN2_TRY(sn2_fp_forward(&p1, training, cur));
+        head_desc(&hd, m, d, a, training);
+        SN2_TRY(sn2_head_forward(&hd, cur));
     }
-    fp_desc(&p1, d, a, fp1_in(m, d, g, a, a->src_ws1), nograd);
-    SN2_TRY(sn2_fp_forward(&p1, training, cur));
-    head_desc(&hd, m, d, a, training);
-    return sn2_head_forward(&hd, cur);
+    // the chains' ends (the inverted indices: the backward pass reads them on this stream; and the side streams' last reads of
+    // the tables lie in front of whatever the caller does with the buffers next)
+    if (join_b) NET_HIP(hipStreamWaitEvent(cur, ctx->b_done, 0));
+    if (join_c) NET_HIP(hipStreamWaitEvent(cur, ctx->c_done, 0));
+    return 0;
 }
 
 // PointNet2._backward_impl

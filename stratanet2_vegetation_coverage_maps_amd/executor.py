@@ -441,4 +441,5 @@ def backward(model, s, dcov, dproba):
     flat = arena[:ms.n_flat]
     s.flat_grad = flat
     model._last_flat_grad = flat
-    return [flat[o:o + n].view(shape) for o, n, shape in zip(ms.param_offsets, ms.param_numels, ms.param_shapes)]
+    # (one split call instead of 32 slices: the views are made in C++)
+    return [p if len(shape) == 1 else p.view(shape) for p, shape in zip(flat.split(ms.param_numels), ms.param_shapes)]

@@ -153,6 +153,7 @@ class PinnedRing:
         else:
             stage.copy_(src)                                  # host memcpy into pinned memory
         st = torch.cuda.current_stream(self.dev) if stream is None else stream
+        allocated_here = out is None
         with torch.cuda.stream(st):
             if out is None:
                 out = torch.empty(src.shape, dtype=dtype, device=self.dev)
@@ -165,6 +166,11 @@ class PinnedRing:
             consumer.wait_event(ev)
             ev = torch.cuda.Event()
             ev.record(consumer)
+            if allocated_here:
+                # allocated on the copy stream, read on the consumer's: the caching allocator must not hand the block to a later
+                # allocation of the copy stream before the consumer is done with it.  (Two blocks then alternate from step to
+                # step -- scripts/debug_side_alloc.py: no hipMalloc after the second iteration.)
+                out.record_stream(consumer)
         self.events[i] = ev
         return out
 
@@ -1083,6 +1089,43 @@ def loss_backward(pred, gt, proba, pdf, m: float, e: float, grad_total):
     _call("sn2_loss_backward", _ptr(pred), _ptr(gt), B, _ptr(proba), _ptr(pdf), R, float(m), float(e), _ptr(grad_total),
           _ptr(dpred), _ptr(dproba), _stream())
     return dpred, dproba
+
+
+def loss_term_forward(kind: int, x: torch.Tensor, y: Optional[torch.Tensor]):
+    """ONE term of the loss (the reference's loop calls them one by one, learning/train.py:58-60) -> out (4,) fp64 with
+    out[kind] = the term: kind 1 = absolute (x = pred (B,4), y = gt (B,4) fp64), 2 = NLL (x = proba (R,4), y = pdf (R,3) fp64),
+    3 = entropy (x = proba (R,4)).  The other terms are skipped inside sn2_loss_forward (their inputs are not passed)."""
+    out = torch.empty(4, dtype=F64, device=x.device)
+    if kind == 1:
+        B = x.shape[0]
+        _chk(x, F32, (B, 4), "pred")
+        _chk(y, F64, (B, 4), "gt")
+        _call("sn2_loss_forward", _ptr(x), _ptr(y), B, None, None, 0, 0.0, 0.0, None, _ptr(out), _stream())
+        return out
+    R = x.shape[0]
+    _chk(x, F32, (R, 4), "proba")
+    partials = torch.empty(2 * LOSS_BLOCKS, dtype=F64, device=x.device)
+    if kind == 2:
+        _chk(y, F64, (R, 3), "pdf")
+        _call("sn2_loss_forward", None, None, 0, _ptr(x), _ptr(y), R, 1.0, 0.0, _ptr(partials), _ptr(out), _stream())
+    elif kind == 3:
+        _call("sn2_loss_forward", None, None, 0, _ptr(x), None, R, 0.0, 1.0, _ptr(partials), _ptr(out), _stream())
+    else:
+        raise ValueError("loss term kind must be 1, 2 or 3")
+    return out
+
+
+def loss_term_backward(kind: int, x: torch.Tensor, y: Optional[torch.Tensor], grad: torch.Tensor):
+    """d term / d x for the upstream gradient `grad` (fp64 device scalar) of that one term."""
+    _chk(grad, F64, None, "grad")
+    dx = torch.empty_like(x)
+    if kind == 1:
+        _call("sn2_loss_backward", _ptr(x), _ptr(y), x.shape[0], None, None, 0, 0.0, 0.0, _ptr(grad), _ptr(dx), None, _stream())
+    elif kind == 2:
+        _call("sn2_loss_backward", None, None, 0, _ptr(x), _ptr(y), x.shape[0], 1.0, 0.0, _ptr(grad), None, _ptr(dx), _stream())
+    else:
+        _call("sn2_loss_backward", None, None, 0, _ptr(x), None, x.shape[0], 0.0, 1.0, _ptr(grad), None, _ptr(dx), _stream())
+    return dx
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):

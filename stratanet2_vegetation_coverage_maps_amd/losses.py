@@ -45,63 +45,67 @@ def total_loss_torch(pred_coverages, proba_pointwise, gt, pdf_all, m=0.10, e=0.2
     return l_abs + m * l_log + e * l_e, (l_abs, l_log, l_e)
 
 
-# The reference's loop calls the three terms one by one (learning/train.py:58-62).  On a HIP device each of them is the fused
-# node with the other two terms switched off -- three launches forward and one backward per term instead of ~20 elementwise
-# torch launches and their autograd graph (the eager drop-in loop is bound by its host time: DESIGN.md section 5) --, the
-# values in fp64 as `total_loss`.  FUSED_TERMS = False (SN2_FUSED_LOSS_TERMS=0), CPU tensors: the plain torch forms above.
+# The reference's loop calls the three terms one by one (learning/train.py:58-62).  On a HIP device each of them is ONE autograd
+# node over the fused loss kernels with the other two terms SKIPPED (csrc/loss.hip: a switched-off term is not computed and its
+# inputs need not exist) -- one or two launches forward and one backward per term instead of ~20 elementwise torch launches
+# and their autograd graph (the eager drop-in loop is bound by its host time: DESIGN.md section 5) --, the values in fp64 as
+# `total_loss`.  FUSED_TERMS = False (SN2_FUSED_LOSS_TERMS=0), CPU tensors: the plain torch forms above.
 import os as _os
 FUSED_TERMS = _os.environ.get("SN2_FUSED_LOSS_TERMS", "1") == "1"
-_DUMMY = {}          # (device index, rows) -> constant stand-ins for the terms that are switched off
-
-
-def _dummy(dev, rows):
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), rows)
-    d = _DUMMY.get(key)
-    if d is None:
-        if len(_DUMMY) > 8:
-            _DUMMY.clear()
-        d = (torch.full((rows, 4), 0.25, dtype=torch.float32, device=dev), torch.ones(rows, 3, dtype=torch.float64, device=dev),
-             torch.zeros(1, 4, dtype=torch.float32, device=dev), torch.zeros(1, 4, dtype=torch.float64, device=dev))
-        _DUMMY[key] = d
-    return d
 
 
 def _fused_ok(*tensors):
     return FUSED_TERMS and all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors)
 
 
+class _LossTerm(torch.autograd.Function):
+    """ONE term of the training loss: kind 1 = absolute (x = plot-wise predictions (B,4), y = ground truth (B,4) fp64),
+    2 = NLL (x = pointwise probabilities (R,4), y = densities (R,3) fp64), 3 = entropy (x = (R,4), y = None)."""
+
+    @staticmethod
+    def forward(ctx, kind, x, y):
+        out = ops.loss_term_forward(kind, x, y)
+        ctx.kind = kind
+        ctx.save_for_backward(x, y) if y is not None else ctx.save_for_backward(x)
+        return out[kind]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        saved = ctx.saved_tensors
+        x, y = saved[0], (saved[1] if len(saved) > 1 else None)
+        return None, ops.loss_term_backward(ctx.kind, x, y, g.to(torch.float64).contiguous()), None
+
+
 def get_absolute_loss(pred_pl, gt):
     if not _fused_ok(pred_pl, gt):
         return get_absolute_loss_torch(pred_pl, gt)
     with torch.cuda.device(pred_pl.device):
-        proba1, pdf1, _, _ = _dummy(pred_pl.device, 1)          # one point with likelihood 1: NLL = 0, and both switched off
-        total, _, _, _ = _TotalLoss.apply(pred_pl.float().contiguous(), proba1, gt.to(torch.float64).contiguous(), pdf1, 0.0, 0.0)
-    return total
+        return _LossTerm.apply(1, pred_pl.float().contiguous(), gt.to(torch.float64).contiguous())
 
 
 def get_NLL_loss(pred_pointwise, pdf_all):
     if FUSED_TERMS and isinstance(pred_pointwise, torch.Tensor) and pred_pointwise.is_cuda and not pdf_all.is_cuda:
         # the reference evaluates its KDE mixture on the CPU and moves the densities to the device inside this function
-        # (loss_functions.py:30-42): through the pinned ring, asynchronously (12.6 MB at C2: a pageable `.cuda()` blocks 0.4 ms)
-        with torch.cuda.device(pred_pointwise.device):
-            pdf_all = ops.pinned_ring(pred_pointwise.device).upload(pdf_all, dtype=torch.float64)
+        # (loss_functions.py:30-42): through the pinned ring, asynchronously (12.6 MB at C2: a pageable `.cuda()` blocks 0.4 ms),
+        # on the upload stream -- the copy runs beside whatever the current stream still has queued (the forward pass: in the
+        # reference's loop the device is 0.8 ms behind the host here), not behind it
+        dev = pred_pointwise.device
+        with torch.cuda.device(dev):
+            pdf_all = ops.pinned_ring(dev).upload(pdf_all, stream=ops.shared_stream(dev, "upload"), dtype=torch.float64,
+                                                  consumer=torch.cuda.current_stream(dev))
     if not _fused_ok(pred_pointwise, pdf_all):
         return get_NLL_loss_torch(pred_pointwise, pdf_all)
     with torch.cuda.device(pred_pointwise.device):
-        _, _, pred0, gt0 = _dummy(pred_pointwise.device, 1)      # the absolute term of a constant plot: subtracted again
-        total, l_abs, _, _ = _TotalLoss.apply(pred0, pred_pointwise.float().contiguous(), gt0,
-                                              pdf_all.to(torch.float64).contiguous(), 1.0, 0.0)
-    return total - l_abs
+        return _LossTerm.apply(2, pred_pointwise.float().contiguous(), pdf_all.to(torch.float64).contiguous())
 
 
 def get_entropy_loss(pred_pixels):
     if not _fused_ok(pred_pixels):
         return get_entropy_loss_torch(pred_pixels)
     with torch.cuda.device(pred_pixels.device):
-        _, pdf1, _, _ = _dummy(pred_pixels.device, pred_pixels.shape[0])
-        _, _, pred0, gt0 = _dummy(pred_pixels.device, 1)
-        total, l_abs, _, _ = _TotalLoss.apply(pred0, pred_pixels.float().contiguous(), gt0, pdf1, 0.0, 1.0)
-    return total - l_abs
+        return _LossTerm.apply(3, pred_pixels.float().contiguous(), None)
 
 
 class KdeTables:

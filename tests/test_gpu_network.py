@@ -270,6 +270,23 @@ def test_the_three_loss_terms_one_by_one_are_the_fused_node():
         ref = res[False][k].cpu().numpy()
         np.testing.assert_allclose(res[True][k].cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
     assert dev_losses.get_absolute_loss(pred, gt).dtype == dev_losses.get_absolute_loss_torch(pred, gt).dtype      # CPU: torch form
+    #  a switched-off term is SKIPPED, not multiplied by zero: the entropy of rows that are no probability vectors
+    # (the reference's docstring says "coverage raster"; all-zero rows included) is finite, value and gradient, as in torch
+    rows = torch.rand(1000, 4, generator=g) * 0.3
+    rows[::7] = 0.0
+    out = {}
+    for fused in (True, False):
+        dev_losses.FUSED_TERMS = fused
+        try:
+            q = rows.cuda().requires_grad_(True)
+            le = dev_losses.get_entropy_loss(q)
+            le.backward()
+            out[fused] = (le.item(), q.grad.clone())
+        finally:
+            dev_losses.FUSED_TERMS = True
+    assert np.isfinite(out[True][0]) and torch.isfinite(out[True][1]).all()
+    assert abs(out[True][0] - out[False][0]) < 1e-6 * max(1.0, abs(out[False][0]))
+    np.testing.assert_allclose(out[True][1].cpu().numpy(), out[False][1].cpu().numpy(), rtol=1e-5, atol=1e-9)
 
 
 def test_prefetched_geometry_gives_identical_results():
