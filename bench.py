@@ -234,7 +234,7 @@ DOMINANT_KERNEL = {
     "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false, true>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>",
     "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34, false>",
     "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512, false>",
-    "sn2_head_forward": "head_fwd_mfma_kernel<false>", "sn2_head_backward": "head_bwd_kernel<false>",
+    "sn2_head_forward": "head_fwd_mfma_kernel<false>", "sn2_head_backward": "head_bwd_mfma_kernel<false>",
     "sn2_three_nn:T=32768": "three_nn_grid_kernel", "sn2_pack_rows": "pack_rows_kernel",
 }
 
@@ -275,6 +275,78 @@ def rocprof_kernel_avg_ms(entry):
         if k in r["Name"]:
             return round(float(r["AverageNs"]) * 1e-6, 4)
     return None
+
+
+def measured_peaks(dev):
+    """The chip's peaks MEASURED in this run, beside the datasheet figures the roofline fractions are quoted against (SURVEY.md
+    8d: "to be confirmed by a measured stream/MFMA microbenchmark in the same run"): a stream copy and a
+    read-only stream over 1 GiB (csrc/misc.hip: stream_probe_kernel, 16 B per lane and load, four loads in flight), and
+    independent chains of one matrix instruction (mfma_probe_kernel) for fp32 and bf16 operands; HIP events on the launch
+    stream, best of 5 launches after a warm-up."""
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    st = ops._stream()
+    n = 1 << 28                                           # floats: 1 GiB per buffer
+    src = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+    dst = torch.empty(n, dtype=torch.float32, device=dev)
+    sink = torch.zeros(4096, dtype=torch.float32, device=dev)
+
+    def best_ms(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        t = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            t.append(a.elapsed_time(b))
+        return min(t)
+
+    out = {}
+    ms = best_ms(lambda: _lib.check(lib.sn2_debug_stream_probe(src.data_ptr(), dst.data_ptr(), n, 0, sink.data_ptr(), st), "stream copy"))
+    out["hbm_copy_GBps"] = round(2 * 4 * n / (ms * 1e-3) / 1e9, 1)
+    ms = best_ms(lambda: _lib.check(lib.sn2_debug_stream_probe(src.data_ptr(), None, n, 1, sink.data_ptr(), st), "stream read"))
+    out["hbm_read_GBps"] = round(4 * n / (ms * 1e-3) / 1e9, 1)
+    del src, dst
+    names = {0: "mfma_f32_16x16x4_TFLOPs", 1: "mfma_f32_32x32x2_TFLOPs", 2: "mfma_bf16_16x16x32_TFLOPs", 3: "mfma_bf16_32x32x16_TFLOPs"}
+    for mode, name in names.items():
+        fl = ctypes.c_double()
+        iters = 4000 if mode < 2 else 16000
+        ms = best_ms(lambda: _lib.check(lib.sn2_debug_mfma_probe(mode, iters, sink.data_ptr(), ctypes.byref(fl), st), "mfma probe"))
+        out[name] = round(fl.value / (ms * 1e-3) / 1e12, 1)
+    out["mfma_f32_TFLOPs"] = max(out[names[0]], out[names[1]])
+    out["mfma_bf16_TFLOPs"] = max(out[names[2]], out[names[3]])
+    out["datasheet"] = {"hbm_GBps": HBM_PEAK_GBS, "mfma_f32_TFLOPs": 157.3, "mfma_bf16_TFLOPs": 2500.0,
+                        "source": "/opt/skills/guides/MI355X_MICROARCH.md"}
+    out["what"] = ("measured in this run: 1 GiB stream copy (read + write) / read-only stream; chains of independent matrix "
+                   "instructions, 8 workgroups x 4 waves per CU; best of 5 launches, HIP events")
+    torch.cuda.empty_cache()
+    return out
+
+
+def dominant_kernel_alone(step_fn, dev, reps=5, opt=None):
+    """Live duration of the ONE device kernel the roofline record names (`fp_bwd_rows_kernel`: the row pass of the per-point
+    layer's backward) -- the entry point `sn2_fp_backward:34+8->34` launches three kernels, and its HIP-event time is theirs
+    together.  A diagnostic switch (sn2_debug_fp1_backward_parts) makes the entry point launch the row pass only; HIP events
+    around the entry point over `reps` eager steps then time that kernel alone (the steps' gradients are not used)."""
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    lib = _lib.load()
+    keep = None if opt is None else [t.clone() for t in (opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_words)]
+    lib.sn2_debug_fp1_backward_parts(1)
+    try:
+        with ops.timing({"sn2_fp_backward:34+8->34"}) as t:
+            for _ in range(reps):
+                step_fn()
+        r = t.summary().get("sn2_fp_backward:34+8->34")
+    finally:
+        lib.sn2_debug_fp1_backward_parts(7)
+        if keep is not None:                 # (those steps' gradients were incomplete: put the optimiser's state back)
+            for dst, src in zip((opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_words), keep):
+                dst.copy_(src)
+    return None if not r else r[1] / r[0]
 
 
 def cpu_baseline():
@@ -355,18 +427,13 @@ def make_exchange(kind, dev, world):
     if kind == "auto":
         if world == 1:
             return None, False, "none (single GPU)"
-        ok, comm, why = 1, None, ""
-        try:
-            comm = rccl.comm_from_torch_group(dev)
-            rccl.self_test(comm, graph=True)
-        except Exception as exc:                     # noqa: BLE001
-            ok, why = 0, f"{type(exc).__name__}: {exc}"
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            return comm, False, f"rccl {rccl.version()} ncclAllReduce inside the step's hipGraph (direct binding; self-test passed on all ranks)"
-        log(f"direct RCCL exchange not used ({why or 'another rank failed its self-test'}): torch.distributed.all_reduce between two graphs")
-        return None, False, "torch.distributed.all_reduce (nccl backend) between the backward graph and the Adam graph"
+        # stage by stage, with an agreement through torch's group between the stages: every RCCL collective is entered by all
+        # ranks or by none (rccl.negotiate_comm)
+        comm, why = rccl.negotiate_comm(dev, graph=True, log=log)
+        if comm is not None:
+            return comm, False, f"rccl {rccl.version()} ncclAllReduce inside the step's hipGraph (direct binding; self-test passed on all {world} ranks)"
+        log(f"direct RCCL exchange not used ({why}): torch.distributed.all_reduce between two graphs")
+        return None, False, f"torch.distributed.all_reduce (nccl backend) between the backward graph and the Adam graph [direct RCCL refused: {why}]"
     if kind == "rccl":
         comm = rccl.comm_from_torch_group(dev)
         rccl.self_test(comm, graph=True)
@@ -813,7 +880,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (the geometry pass forks into these three and joins them itself; anything else left forked is an error)
+            with ops.graph_capture(g, dev, allowed_forks=("fork_b", "fork_c", "pack")):
                 l = step()
             g.replay()
             torch.cuda.synchronize()
@@ -920,6 +988,18 @@ def main():
         e1, e2 = int(saved.tot1.item()), int(saved.tot2.item())
         m1, m2 = saved.M1, saved.M2
 
+    peaks, dom_alone_ms = None, None
+    if rank == 0 and world == 1:
+        if dominant == "sn2_fp_backward:34+8->34":
+            dom_alone_ms = dominant_kernel_alone(step, dev, opt=opt)
+        log("measured peaks (stream copy / read, MFMA fp32 / bf16)")
+        peaks = measured_peaks(dev)
+        log("  " + json.dumps({k: v for k, v in peaks.items() if k.endswith(("GBps", "TFLOPs"))}))
+    ranks_seen = world
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         kernels = []
@@ -984,7 +1064,44 @@ def main():
                           "parallelism": f"dp{world} (plots sharded; one 60 KB gradient all-reduce)" if world > 1 else "single GPU"},
                "loss": round(loss_value, 6), "roofline": roof, "kernels": kernels,
                "host_cores_of_this_rank": os.environ.get("SN2_BENCH_PINNED", f"all:{len(os.sched_getaffinity(0))}")}
+        if peaks is not None:
+            out["measured_peaks"] = peaks
+        # what a SCALE record can be audited by: the library, the ranks that took part, the exchange that really ran
+        try:
+            from stratanet2_vegetation_coverage_maps_amd import rccl as _rccl
+            out["config"]["rccl_version"] = _rccl.version()
+        except Exception as exc:                         # noqa: BLE001
+            out["config"]["rccl_version"] = f"unavailable ({type(exc).__name__})"
+        out["config"]["ranks_seen"] = ranks_seen
+        out["config"]["exchange_in_graph"] = bool(getattr(opt, "comm", None) is not None)
         if roof is not None:
+            # ---- one record, scalar fields, each with ONE denominator:
+            #   frac / entry_point_frac : the ENTRY POINT's algorithmic bytes over its live HIP-event time (all its kernels), vs 8 TB/s
+            #   dominant_kernel_frac    : the named device kernel ALONE (its own bytes over its own live duration), vs 8 TB/s
+            #   *_of_measured_copy      : the same against the stream-copy rate measured in this run
+            #   whole_step_*            : SURVEY 8d's compulsory bytes / dense flops of one step over ms_per_step
+            roof["entry_point_frac"] = roof["frac"]
+            roof["entry_point_kernels"] = ENTRY_KERNELS.get(roof["kernel"], [DOMINANT_KERNEL.get(roof["kernel"])])
+            if dom_alone_ms is not None:
+                dk_bytes = (288 + 32 + 136) * N_POINTS * B      # h + dy rows, skip columns in, d pre-activation rows out
+                roof["dominant_kernel_ms"] = round(dom_alone_ms, 4)
+                roof["dominant_kernel_bytes"] = dk_bytes
+                roof["dominant_kernel_GBps"] = round(dk_bytes / (dom_alone_ms * 1e-3) / 1e9, 1)
+                roof["dominant_kernel_frac"] = round(dk_bytes / (dom_alone_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+            roof["whole_step_hbm_frac"] = whole_step["hbm_frac"]
+            roof["whole_step_mfma_frac"] = whole_step["mfma_frac"]
+            roof["whole_step_compulsory_bytes"] = whole_step["compulsory_bytes"]
+            roof["whole_step_dense_flops"] = whole_step["dense_flops"]
+            if peaks is not None:
+                cp = peaks["hbm_copy_GBps"]
+                roof["measured_copy_peak_GBps"] = cp
+                if roof["achieved"] is not None:
+                    roof["frac_of_measured_copy"] = round(roof["achieved"] / cp, 4)
+                if dom_alone_ms is not None:
+                    roof["dominant_kernel_frac_of_measured_copy"] = round(roof["dominant_kernel_GBps"] / cp, 4)
+                roof["whole_step_hbm_frac_of_measured_copy"] = round(whole_step["compulsory_bytes"] / (ms * 1e-3) / (cp * 1e9), 4)
+                mp = peaks["mfma_bf16_TFLOPs" if a.dtype == "bf16" else "mfma_f32_TFLOPs"]
+                roof["whole_step_mfma_frac_of_measured"] = round(whole_step["dense_flops"] / (ms * 1e-3) / (mp * 1e12), 4)
             roof["whole_step"] = whole_step
         if roof_geo is not None:
             if roof_geo["kernel"].startswith("sn2_fps"):

@@ -41,6 +41,18 @@ int sn2_debug_mfma_chain(const float *a, const float *b, float *d, int mode, voi
 /* diagnostic: `blocks` one-wave workgroups idle for `clocks` shader clocks each (s_sleep loop, bounded); out: NULL or one int */
 int sn2_debug_spin(int blocks, long long clocks, int *out, void *stream);
 
+/* measured peaks (bench.py times them with HIP events in the same run as the metric, next to the datasheet figures):
+ * sn2_debug_stream_probe: mode 0 = copy dst[i] = src[i] over n_floats floats (2 * 4 * n_floats bytes moved), 1 = read-only sum
+ * (4 * n_floats bytes); sink: SN2_PROBE_SINK_WORDS floats of scratch.  sn2_debug_mfma_probe: independent chains of one matrix
+ * instruction, 8 workgroups of 4 waves per CU, `iters` rounds -- mode 0 v_mfma_f32_16x16x4_f32, 1 v_mfma_f32_32x32x2_f32,
+ * 2 v_mfma_f32_16x16x32_bf16, 3 v_mfma_f32_32x32x16_bf16; *flops (HOST pointer or NULL) = the flops of the launch. */
+/* diagnostic (bench.py's roofline record): which kernels of the per-point layer's source-side backward sn2_fp_backward launches --
+ * bit 0 the row pass, 1 the source pass, 2 the merge; 7 (default; 0 = back to it) = all, the only setting that yields gradients */
+int sn2_debug_fp1_backward_parts(int mask);
+#define SN2_PROBE_SINK_WORDS 4096
+int sn2_debug_stream_probe(const float *src, float *dst, size_t n_floats, int mode, float *sink, void *stream);
+int sn2_debug_mfma_probe(int mode, int iters, float *sink, double *flops, void *stream);
+
 /* ---- one (Linear -> ReLU -> BatchNorm1d) block, model/point_net2.py:45-53 -------------------------------- */
 typedef struct sn2_block {
     int cin, cout;

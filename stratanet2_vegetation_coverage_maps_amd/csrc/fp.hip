@@ -2176,6 +2176,14 @@ int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_
     SN2_RETURN_LAUNCH();
 }
 
+// diagnostic (bench.py): which of the three kernels of the per-point layer's source-side backward run -- bit 0 the row pass, 1 the
+// source pass over the chunk table, 2 the merge (7 = all, the only setting that computes the gradients)
+static int g_fp1_bwd_parts = 7;
+extern "C" int sn2_debug_fp1_backward_parts(int mask) {
+    g_fp1_bwd_parts = mask & 7 ? mask & 7 : 7;
+    return 0;
+}
+
 template <int CA, int CB, int CO, bool KNN>
 int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     constexpr int CI = CA + CB;
@@ -2230,6 +2238,8 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             auto k1 = p->act_bf16 ? &fp_bwd_rows_kernel<CA, CB, CO, NT, true> : &fp_bwd_rows_kernel<CA, CB, CO, NT, false>;
             if (lb1 > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb1);
+            const int parts = g_fp1_bwd_parts;
+            if (parts & 1)
             hipLaunchKernelGGL(k1, dim3(2 * grid_mult * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
                                p->blk.gamma, (const float*)p->blk.mean, (const float*)p->blk.invstd,
                                (const float*)p->blk.dgamma, (const float*)p->blk.dbeta, (const float*)p->h, p->dy,
@@ -2249,8 +2259,10 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
             if (L > 64) L = 64;
             const int gc = (sn2_cdiv(sn2_cdiv(n_chunks, L), 4) + 7) & ~7;
             auto kc = p->act_bf16 ? &fp_bwd_src_chunk_kernel<CA, CB, CO, true> : &fp_bwd_src_chunk_kernel<CA, CB, CO, false>;
+            if (parts & 2)
             hipLaunchKernelGGL(kc, dim3(gc), dim3(256), 0, st, n_chunks, L, R, Rp, S, (const int4*)x.chunks, (const int*)x.inv_row,
                                (const float*)x.inv_w, (const float*)p->du_scratch, p->src_ws);
+            if (parts & 4)
             hipLaunchKernelGGL((fp_bwd_src_merge_dw_kernel<CA, CB, CO>), dim3(sn2_cdiv(n_src, 64)), dim3(256), 0, st, n_src, S, x.CM,
                                p->src_stride, p->dsrc_stride, (const int4*)x.items, p->src, p->src_a, p->src_c,
                                (const float*)p->src_ws, p->blk.W, p->dsrc,

@@ -383,6 +383,99 @@ extern "C" int sn2_debug_spin(int blocks, long long clocks, int* out, void* stre
 
 extern "C" int sn2_version(void) { return SN2_VERSION; }
 
+// ---- measured peaks (bench.py: "peaks measured in the same run", SURVEY.md 8d / BASELINE.md 3.5b) ------------------------
+// mode 0: stream COPY dst[i] = src[i] (bytes moved = 2 n), mode 1: stream READ (sum into one word per workgroup; bytes = n):
+// 16 bytes per lane and load, four loads in flight per lane, grid = 8 workgroups per CU, grid-stride.
+namespace {
+__global__ __launch_bounds__(256) void stream_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4,
+                                                           int mode, float* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        if (mode == 0) {
+            dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+        } else {
+            acc += (a.x + b.y) + (c.z + d.w);
+        }
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = src[i];
+        if (mode == 0) dst[i] = a;
+        else acc += a.x;
+    }
+    if (mode != 0 && acc == 123456.789f) sink[blockIdx.x] = acc;        // (keeps the loads alive)
+}
+
+// MODE 0: v_mfma_f32_16x16x4_f32 (2048 flops per wave-instruction), 1: v_mfma_f32_32x32x2_f32 (4096), 2: v_mfma_f32_16x16x32_bf16
+// (16 384), 3: v_mfma_f32_32x32x16_bf16 (32 768).  Eight independent accumulator chains per wave, `iters` rounds.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_probe_kernel(int iters, float* __restrict__ sink) {
+    const float av = 1.0f + (threadIdx.x & 7) * 0.125f, bv = 0.5f + (threadIdx.x & 3) * 0.25f;
+    float total = 0.f;
+    if constexpr (MODE == 0 || MODE == 2) {
+        f32x4 acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 a8, b8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a8[j] = (__bf16)av, b8[j] = (__bf16)bv;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (MODE == 0) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[k], 0, 0, 0);
+                else acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[k], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) total += acc[k][0] + acc[k][3];
+    } else {
+        f32x16 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+        bf16x8 a8, b8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a8[j] = (__bf16)av, b8[j] = (__bf16)bv;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (MODE == 1) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+                else acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[k], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) total += acc[k][0] + acc[k][15];
+    }
+    if (total == 123456.789f) sink[blockIdx.x] = total;                 // (keeps the chains alive)
+}
+}  // namespace
+
+extern "C" int sn2_debug_stream_probe(const float* src, float* dst, size_t n_floats, int mode, float* sink, void* stream) {
+    if (!src || !sink || n_floats < 4 || (n_floats & 3) || (mode != 0 && mode != 1) || (mode == 0 && !dst)) return SN2_EINVAL;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(8 * sn2_cu_count()), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n_floats / 4, mode, sink);
+    SN2_RETURN_LAUNCH();
+}
+
+// -> *flops (host, may be NULL) = the flops the launch performs (8 workgroups of 4 waves per CU)
+extern "C" int sn2_debug_mfma_probe(int mode, int iters, float* sink, double* flops, void* stream) {
+    if (!sink || iters <= 0 || iters > (1 << 22) || mode < 0 || mode > 3) return SN2_EINVAL;
+    const int grid = 8 * sn2_cu_count();
+    hipStream_t st = (hipStream_t)stream;
+    const double per_instr[4] = {2048.0, 4096.0, 16384.0, 32768.0};
+    const int chains[4] = {8, 4, 8, 4};
+    if (flops) *flops = (double)grid * 4.0 * iters * chains[mode] * per_instr[mode];
+    if (mode == 0) hipLaunchKernelGGL(mfma_probe_kernel<0>, dim3(grid), dim3(256), 0, st, iters, sink);
+    else if (mode == 1) hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3(grid), dim3(256), 0, st, iters, sink);
+    else if (mode == 2) hipLaunchKernelGGL(mfma_probe_kernel<2>, dim3(grid), dim3(256), 0, st, iters, sink);
+    else hipLaunchKernelGGL(mfma_probe_kernel<3>, dim3(grid), dim3(256), 0, st, iters, sink);
+    SN2_RETURN_LAUNCH();
+}
+
 
 // ---- images of a flat gradient vector -> image 0 (sn2_block.grad_replicas) ---------------------------------------
 namespace {

@@ -97,6 +97,59 @@ def shared_stream(dev, name: str) -> torch.cuda.Stream:
     return _SHARED_STREAMS[key]
 
 
+def forked_streams(dev, exclude=None):
+    """Names of the process's shared streams of `dev` that are part of a stream capture RIGHT NOW (hipStreamIsCapturing):
+    streams a capture forked into (`side.wait_stream(capture stream)` + work on `side`)."""
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    out = []
+    for (di, name), s in list(_SHARED_STREAMS.items()):
+        if di != idx or (exclude is not None and s == exclude):
+            continue
+        with torch.cuda.stream(s):
+            if torch.cuda.is_current_stream_capturing():
+                out.append(name)
+    return out
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def graph_capture(graph, dev, pool=None, allowed_forks=()):
+    """`torch.cuda.graph(graph, pool=pool)` with the two rules this package's captures live by ENFORCED (round 5; DESIGN.md
+    section 4, "the capture_end crash of round 4"):
+      * a capture starts with none of the process's shared streams inside another capture (two live users of `shared_stream`
+        names, ADVICE r03) -- refused with StrataHipError before anything is captured;
+      * a capture ENDS with every stream it forked into joined back.  ROCm 7.2's hipStreamEndCapture does not return
+        hipErrorStreamCaptureUnjoined for a stream that is still forked: it crashed the process (round 4: a loss-value branch
+        on a fourth stream whose autograd node the engine ran -- and left work -- on that stream after the step's join).
+        Here every shared stream found capturing at the end of the block is joined first (so the runtime never sees the
+        state), and unless its name is in `allowed_forks` (streams the captured code forks into and joins itself: the
+        unpipelined step's geometry branches) the graph is dropped and StrataHipError raised."""
+    dev = torch.device(dev)
+    busy = forked_streams(dev)
+    if busy:
+        raise StrataHipError(f"graph_capture: shared stream(s) {busy} are already part of a stream capture: one capture at a time "
+                             "per device (hip_ops.shared_stream: single owner at a time)")
+    stray = []
+    kw = {} if pool is None else {"pool": pool}
+    with torch.cuda.graph(graph, **kw):
+        cap = torch.cuda.current_stream(dev)
+        try:
+            yield cap
+        finally:
+            for name in forked_streams(dev, exclude=cap):
+                cap.wait_stream(shared_stream(dev, name))      # joined: hipStreamEndCapture sees a legal graph whatever happened
+                if name not in allowed_forks:
+                    stray.append(name)
+    if stray:
+        graph.reset()
+        raise StrataHipError(f"graph_capture: the captured code left work on shared stream(s) {stray} that nothing joined back "
+                             "into the capture stream (an autograd node created on a side stream runs its backward there); "
+                             "the graph was dropped")
+
+
 _UPLOAD_TRACE = None       # scripts/profile_dropin_host.py sets a list: (what, host ms) of every wait / copy inside PinnedRing.upload
 
 

@@ -195,13 +195,20 @@ class TrainPipeline:
         with torch.cuda.stream(cap):
             for k in range(self.slots):           # warm-up on the capture stream
                 self.feature_step(self.inputs[k], self.geo[k])
+            comm = getattr(self.opt, "comm", None)
+            if comm is not None:
+                # RCCL connects lazily at a communicator's FIRST collective: that one must not be the node being captured
+                #  -- one eager all-reduce of a scratch buffer on the capture stream, on every rank
+                comm.all_reduce_sum_(torch.zeros(256, dtype=torch.float32, device=self.dev))
         main.wait_stream(cap)
         torch.cuda.synchronize(self.dev)
         pool = torch.cuda.graph_pool_handle()
         world = getattr(self.opt, "world_size", 1)
+        # (ops.graph_capture: torch.cuda.graph + the guards of DESIGN.md section 4 -- no shared stream inside another capture
+        # at the start, none left forked at the end: a feature pass forks nowhere)
         for k in range(self.slots):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with ops.graph_capture(g, self.dev, pool=pool):
                 self.loss[k] = self.feature_step(self.inputs[k], self.geo[k])
                 self.flat_grad[k] = self.model._last_flat_grad
                 if not self.split_exchange:
@@ -209,7 +216,7 @@ class TrainPipeline:
             self.graph_fb[k] = g
             if self.split_exchange:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=pool):
+                with ops.graph_capture(g2, self.dev, pool=pool):
                     ops.adam_step(self.opt.flat, self.flat_grad[k], self.opt.exp_avg, self.opt.exp_avg_sq, self.opt.lr,
                                   self.opt.betas[0], self.opt.betas[1], self.opt.eps, self.opt.weight_decay,
                                   self.opt.step_words, 1.0 / world)

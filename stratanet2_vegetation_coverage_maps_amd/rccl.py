@@ -132,25 +132,112 @@ def comm_from_torch_group(device, group=None) -> RcclComm:
     backend -- carries its 128 bytes to the others.  Without an initialised process group: a one-rank communicator."""
     dist = torch.distributed
     if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(box, src=0, group=group)
-        return RcclComm(rank, world, box[0], device)
+        uid, rank, world = exchange_unique_id(group)
+        if uid is None:
+            raise RcclError("rank 0 could not draw a unique id (ncclGetUniqueId)")
+        return RcclComm(rank, world, uid, device)
     return RcclComm(0, 1, unique_id(), device)
 
 
-def self_test(comm: RcclComm, graph: bool = True):
-    """Eager and (graph=True) hipGraph-captured all-reduce of a small buffer with a known answer; raises RcclError on a wrong
-    result.  Run by every rank at start-up before the exchange is trusted with gradients (bench.py)."""
+def exchange_unique_id(group=None, make_uid=unique_id):
+    """Rank 0 draws the communicator's unique id, torch's process group (any backend: it only moves 128 bytes through the
+    store / a broadcast) hands it to every rank -> (uid or None, rank, world).  uid is None ON EVERY RANK when rank 0 could not
+    draw one: the ranks fail together, nobody walks into `ncclCommInitRank` alone."""
+    dist = torch.distributed
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = make_uid()
+        except Exception:                      # noqa: BLE001
+            box[0] = None
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    uid = box[0]
+    if uid is not None and len(uid) != NCCL_UNIQUE_ID_BYTES:
+        uid = None
+    return uid, rank, world
+
+
+def _all_agree(ok: bool, group, device) -> bool:
+    """MIN over the ranks of a local success flag, through torch's group."""
+    dist = torch.distributed
+    on_dev = dist.get_backend(group) == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_dev else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
+def negotiate_comm(device, group=None, graph: bool = True, make_uid=unique_id, make_comm=None, test=None, log=None):
+    """The direct-RCCL exchange for torch's (default) process group, or None when ANY rank cannot have it -- decided stage by
+    stage, with a MIN all-reduce through torch's group between the stages, so that every RCCL collective (the rendezvous of
+    `ncclCommInitRank`, the eager all-reduce of the self-test, the captured one) is entered by ALL ranks or by NONE: a rank
+    whose librccl does not load, or whose eager result is wrong, can no longer leave its peers blocked inside the next
+    collective (the agreement used to come after the whole sequence).
+        stage 1  local: load the library                                -> agree
+        stage 2  torch collective: rank 0's unique id to everyone       (None everywhere when rank 0 failed)
+        stage 3  RCCL collective: ncclCommInitRank                      -> agree
+        stage 4  RCCL collective: eager all-reduce with a known sum     -> agree on the RESULT
+        stage 5  RCCL collective inside a captured graph (graph=True)   -> agree on the result
+    make_uid / make_comm(rank, world, uid, device) / test(comm, graph) replace the library calls (tests: the staged agreement runs
+    on CPU over gloo).  -> (communicator or None, reason the direct exchange is not used or "")."""
+    make_comm = make_comm or RcclComm
+    test = test or self_test
+    say = log or (lambda m: None)
+    ok, why = True, ""
+    try:
+        if make_uid is unique_id:
+            load()
+    except Exception as exc:                   # noqa: BLE001
+        ok, why = False, f"stage 1 (load): {type(exc).__name__}: {exc}"
+    if not _all_agree(ok, group, device):
+        return None, why or "stage 1 (load): another rank could not load librccl"
+    uid, rank, world = exchange_unique_id(group, make_uid)
+    if uid is None:                            # the same on every rank: no agreement round needed
+        return None, "stage 2 (unique id): rank 0 could not draw one"
+    comm = None
+    try:
+        comm = make_comm(rank, world, uid, device)
+    except Exception as exc:                   # noqa: BLE001
+        ok, why = False, f"stage 3 (ncclCommInitRank): {type(exc).__name__}: {exc}"
+    if not _all_agree(ok, group, device):
+        _drop(comm)
+        return None, why or "stage 3 (ncclCommInitRank): another rank failed"
+    for stage, with_graph in ((4, False), (5, True)):
+        if with_graph and not graph:
+            break
+        try:
+            test(comm, graph=with_graph, eager=not with_graph)
+        except Exception as exc:               # noqa: BLE001
+            ok, why = False, f"stage {stage} ({'captured' if with_graph else 'eager'} all-reduce): {type(exc).__name__}: {exc}"
+        if not _all_agree(ok, group, device):
+            _drop(comm)
+            return None, why or f"stage {stage}: another rank's self-test failed"
+    say(f"direct RCCL exchange agreed on by {world} rank(s)")
+    return comm, ""
+
+
+def _drop(comm):
+    try:
+        if comm is not None:
+            comm.destroy()
+    except Exception:                          # noqa: BLE001
+        pass
+
+
+def self_test(comm: RcclComm, graph: bool = True, eager: bool = True):
+    """Eager (eager=True) and hipGraph-captured (graph=True) all-reduce of a small buffer with a known answer; raises RcclError on
+    a wrong result.  Run by every rank at start-up before the exchange is trusted with gradients (bench.py; `negotiate_comm`
+    runs the two parts as separate stages)."""
     dev, w, r = comm.device, comm.world, comm.rank
     want = float(w * (w + 1) // 2)
     with torch.cuda.device(dev):
-        x = torch.full((4096,), float(r + 1), device=dev)
-        comm.all_reduce_sum_(x)
-        torch.cuda.synchronize(dev)
-        if not bool((x == want).all()):
-            raise RcclError(f"eager all-reduce: got {float(x[0])}, expected {want}")
+        if eager:
+            x = torch.full((4096,), float(r + 1), device=dev)
+            comm.all_reduce_sum_(x)
+            torch.cuda.synchronize(dev)
+            if not bool((x == want).all()):
+                raise RcclError(f"eager all-reduce: got {float(x[0])}, expected {want}")
         if graph:
             buf = torch.empty(4096, device=dev)
             src = torch.full((4096,), float(r + 1), device=dev)

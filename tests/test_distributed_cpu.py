@@ -71,3 +71,104 @@ def test_ranks_gloo_allreduce_of_flat_gradient(world):
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {r: 1 for r in range(world)}
+
+
+# ---- the direct-RCCL exchange's start-up protocol (rccl.negotiate_comm), rehearsed on CPU over gloo: no device call, the
+# library calls are replaced by stand-ins whose "collectives" are gloo collectives -- a rank that entered one alone would hang
+# (and the test time out) instead of failing quietly
+class _FakeComm:
+    def __init__(self, rank, world, uid, device):
+        assert len(uid) == 128
+        self.rank, self.world, self.uid, self.destroyed = rank, world, uid, False
+        t = torch.tensor([float(sum(uid))])
+        dist.all_reduce(t)                                   # the rendezvous of ncclCommInitRank: entered by every rank or hangs
+        assert float(t) == world * float(sum(uid))            # ... and everyone holds the SAME id
+
+    def destroy(self):
+        self.destroyed = True
+
+
+def _negotiation_worker(rank, world, port, out, fail_rank, fail_stage):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stratanet2_vegetation_coverage_maps_amd import rccl
+        calls = []
+
+        def make_uid():
+            if fail_stage == 2:
+                raise rccl.RcclError("no unique id")
+            return bytes((7 * i + 1) % 256 for i in range(128))
+
+        def make_comm(r, w, uid, device):
+            calls.append("init")
+            if fail_stage == 3 and r == fail_rank:
+                # (a real ncclCommInitRank that fails on one rank fails or times out on the others too; here the others' stand-in
+                # rendezvous must not be left waiting: the failing rank still takes part in it, then reports failure)
+                _FakeComm(r, w, uid, device)
+                raise rccl.RcclError("init failed here")
+            return _FakeComm(r, w, uid, device)
+
+        def test(comm, graph=True, eager=True):
+            calls.append("graph" if graph else "eager")
+            t = torch.tensor([float(comm.rank + 1)])
+            dist.all_reduce(t)                               # the self-test's collective
+            stage = 5 if graph else 4
+            if fail_stage == stage and comm.rank == fail_rank:
+                raise rccl.RcclError("wrong sum on this rank")
+            assert float(t) == world * (world + 1) / 2
+
+        comm, why = rccl.negotiate_comm("cpu", graph=True, make_uid=make_uid, make_comm=make_comm, test=test)
+        out[rank] = (comm is not None, why, tuple(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_stage", [0, 2, 3, 4, 5])
+def test_direct_rccl_exchange_is_agreed_on_stage_by_stage(fail_stage):
+    """world 2 over gloo.  fail_stage 0: nothing fails -> both ranks get the communicator after the same five stages.  2..5: rank 1
+    (stage 2: rank 0, who draws the id) fails at that stage -> BOTH ranks return None with the stage named, and both made the same
+    calls: nobody entered the next collective alone (that would hang, not fail)."""
+    world, fail_rank = 2, 1
+    port = 31500 + (os.getpid() % 2000) + fail_stage
+    out = mp.Manager().dict()
+    mp.spawn(_negotiation_worker, args=(world, port, out, fail_rank, fail_stage), nprocs=world, join=True)
+    res = dict(out)
+    assert set(res) == {0, 1}
+    assert res[0][2] == res[1][2], "the ranks made different sequences of collective calls"
+    if fail_stage == 0:
+        assert res[0][0] and res[1][0] and res[0][2] == ("init", "eager", "graph")
+    else:
+        assert not res[0][0] and not res[1][0]
+        assert f"stage {fail_stage}" in res[0][1] and f"stage {fail_stage}" in res[1][1]
+        assert len(res[0][2]) == {2: 0, 3: 1, 4: 2, 5: 3}[fail_stage]
+
+
+def test_unique_id_travels_through_the_process_group():
+    """`rccl.exchange_unique_id` with the REAL ncclGetUniqueId where librccl loads without a device (else a stand-in id): rank 0's
+    128 bytes reach rank 1 unchanged."""
+    port = 33500 + (os.getpid() % 2000)
+    out = mp.Manager().dict()
+    mp.spawn(_uid_worker, args=(2, port, out), nprocs=2, join=True)
+    res = dict(out)
+    assert res[0] == res[1] and len(res[0][0]) == 128
+
+
+def _uid_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stratanet2_vegetation_coverage_maps_amd import rccl
+
+        def make_uid():
+            try:
+                return rccl.unique_id()
+            except Exception:                                # noqa: BLE001  (no usable librccl on this host)
+                return bytes(range(128))
+
+        uid, r, w = rccl.exchange_unique_id(None, make_uid)
+        out[rank] = (bytes(uid), w)
+    finally:
+        dist.destroy_process_group()

@@ -5,6 +5,7 @@ import torch
 
 from oracle import network
 from stratanet2_vegetation_coverage_maps_amd import PointNet2, losses, project_to_plotwise_coverages
+from stratanet2_vegetation_coverage_maps_amd import hip_ops as ops
 from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters
 from stratanet2_vegetation_coverage_maps_amd.pipeline import TrainPipeline
 from stratanet2_vegetation_coverage_maps_amd.synthetic import make_args, make_batch
@@ -207,3 +208,47 @@ def test_pipeline_with_host_feeder_matches_plain_loop(pair):
     assert all(np.isfinite(got)), got
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
     assert int(opt2.step_dev.item()) == steps
+
+
+def test_capture_guard_joins_and_refuses_a_stream_left_forked():
+    """`hip_ops.graph_capture` (what TrainPipeline.capture and bench.py's serial capture go through; DESIGN.md section 4, "the
+    capture_end crash of round 4"): a shared stream that the captured code forked into and did not join back is JOINED before
+    the capture ends (hipStreamEndCapture never sees an unjoined fork: on ROCm 7.2 that crashed the process instead of returning
+    an error) and the capture is refused with StrataHipError -- unless the stream is one the caller says it forks into on
+    purpose, in which case the graph is whole and replays.  A capture that starts while a shared stream is inside another
+    capture is refused before anything is recorded."""
+    from stratanet2_vegetation_coverage_maps_amd._lib import StrataHipError
+    dev = torch.device("cuda:0")
+    side = ops.shared_stream(dev, "side0")
+    x = torch.zeros(64, device=dev)
+    torch.cuda.synchronize()
+
+    def fork_and_forget(cap):
+        side.wait_stream(cap)
+        with torch.cuda.stream(side):
+            x.add_(1.0)                         # work on a forked stream that nothing joins back
+
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(StrataHipError, match="left work on shared stream"):
+        with ops.graph_capture(g, dev) as cap:
+            fork_and_forget(cap)
+    torch.cuda.synchronize()
+    assert float(x.sum()) == 0.0                # captured, never run; the graph was dropped
+    g2 = torch.cuda.CUDAGraph()
+    with ops.graph_capture(g2, dev, allowed_forks=("side0",)) as cap:
+        fork_and_forget(cap)                    # the guard's join makes the graph whole
+    for _ in range(2):
+        g2.replay()
+    torch.cuda.synchronize()
+    assert float(x.min()) == 2.0 and float(x.max()) == 2.0
+    assert ops.forked_streams(dev) == []
+    # a capture while a shared stream is already capturing: refused up front
+    outer = torch.cuda.CUDAGraph()
+    cap_stream = ops.shared_stream(dev, "capture")
+    with torch.cuda.stream(cap_stream):
+        with torch.cuda.graph(outer, stream=cap_stream):
+            with pytest.raises(StrataHipError, match="already part of a stream capture"):
+                with ops.graph_capture(torch.cuda.CUDAGraph(), dev):
+                    pass
+            x.add_(0.0)
+    torch.cuda.synchronize()
