@@ -157,8 +157,22 @@ def _spawn_ranks_if_needed():
     sys.exit(rc)
 
 
+# stdout carries EXACTLY ONE line, the JSON record: everything else a library may print there (RCCL prints a version banner to
+# stdout when its first communicator comes up) goes to stderr -- file descriptor 1 is pointed at stderr for the life of the
+# process and the record is written to a duplicate of the original stdout
+_RECORD_OUT = None
+
+
+def emit_record(obj):
+    out = _RECORD_OUT if _RECORD_OUT is not None else sys.stdout
+    print(json.dumps(obj), file=out, flush=True)
+
+
 if __name__ == "__main__":
     _spawn_ranks_if_needed()
+    sys.stdout.flush()
+    _RECORD_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
 import torch  # noqa: E402
 
@@ -813,7 +827,7 @@ def main():
         legs = secondary_legs(dev)
         if a.only_leg not in legs:
             raise SystemExit(f"--only-leg: one of {sorted(legs)}")
-        print(json.dumps({a.only_leg: legs[a.only_leg]()}), flush=True)
+        emit_record({a.only_leg: legs[a.only_leg]()})
         return
     B, N_POINTS = a.plots, a.points
     # depth+1 resident batches (the pipeline's slots)
@@ -1137,7 +1151,7 @@ def main():
             log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        emit_record(out)
     if getattr(opt, "comm", None) is not None:
         import gc
         pipe = graph = None                    # the graphs that hold the captured collective go first
