@@ -484,7 +484,9 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
     model.p2_diam_pix = args.diam_pix        # geometry passes also compute the projection's pixel ids (functions of x, y only)
     flatten_parameters(model)
     comm, force, exchange_desc = make_exchange(exchange, dev, world)
-    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world, comm=comm)     # config.py:84,97
+    # (no exchange between backward and update: the Adam kernel folds the gradient's images itself, one launch less per step)
+    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, world_size=world, comm=comm,     # config.py:84,97
+                   fold_gradient_images=(world == 1 and comm is None and not force))
     opt.force_exchange = force
     # batch j of rank r = plots [(j*world + r)*B, +B) of the seeded set
     slots = []

@@ -231,7 +231,10 @@ typedef struct sn2_fp {
     float *du_scratch;              /* backward workspace (B*R, max(ca, h_stride)) when knn_idx and dsrc are given */
     float *scatter_ws;              /* backward workspace when knn_idx and dsrc are given: SN2_INTERP_WS_WORDS(B,R,S)
                                        32-bit words (inverted index of the 3-NN table)                           */
-    int scatter_ready;              /* non-zero: scatter_ws already holds the index (sn2_interp_index)           */
+    int scatter_ready;              /* > 0: scatter_ws already holds the index (sn2_interp_index); 0: sn2_fp_backward builds it;
+                                       < 0: sn2_fp_backward leaves the per-row input gradients in du_scratch ((B*R, ca) rows)
+                                       and does NOT add them onto dsrc: the caller transposes the interpolation itself
+                                       (sn2_global_pool_backward does, for the plot's one source)                 */
     const int *bn_sums_done;        /* non-NULL (the `ok` word of sn2_head_bn_sums / sn2_fp_bn_sums): blk.dgamma /
                                        blk.dbeta already hold this BatchNorm's gradients, sn2_fp_backward launches no
                                        pass over the rows for them.  NULL: it does                                  */
@@ -278,6 +281,17 @@ int sn2_fp_backward(const sn2_fp *p, void *stream);
 int sn2_plot_max_forward(const float *h, const float *a, const float *c, int B, int R_per_plot, int C, float *out,
                          int *arg, void *stream);
 int sn2_plot_max_backward(const float *dout, const int *arg, int B, int R_per_plot, int C, float *dy, void *stream);
+
+/* The backward of the global level's pool in one launch (round 5): for FP3's per-row input gradients du (B*R, du_stride >= C) that
+ * sn2_fp_backward left in its du_scratch (scatter_ready < 0) --
+ *   dx (B,C) += sum over the plot's rows of du   (the transpose of knn_interpolate with k = 1 from the plot's one source, :137/:41),
+ *   dy (B*R,C), zero-filled by the caller: dy[b R + arg[b][c]][c] = dx[b][c]   (the backward of global_max_pool, :39),
+ *   dgamma, dbeta (C) += the BatchNorm sums over dy of the block whose pre-BatchNorm rows are h (B*R,C) with saved statistics
+ *   mean, invstd -- B terms per channel, dy being zero elsewhere; hand the block's sn2_fp_backward a non-NULL bn_sums_done.
+ * Replaces the gather inside sn2_fp_backward, sn2_plot_max_backward and the BatchNorm-sum pass of the global SA block.  C = 64. */
+int sn2_global_pool_backward(const float *du, int du_stride, const int *arg, const float *h, const float *mean,
+                             const float *invstd, int B, int R_per_plot, int C, float *dx, float *dy, float *dgamma,
+                             float *dbeta, void *stream);
 
 /* The reference architecture's global level in ONE launch, TRAINING mode (round 4): SA3 = MLP[35,64] on cat[x2, pos2]
  * (model/point_net2.py:133, 37-42), its BatchNorm, the plot's max (:39), FP3 = MLP[96,64] on cat[plot feature, x2] (:137,
@@ -511,8 +525,9 @@ typedef struct sn2_net_bwd {
     float *dy2, *dy3, *dx1, *dx2, *dx3, *dy_sa3;
     void *dy1, *du1;                     /* (B*N,36) rows of the activation type */
     float *du2, *du3;                    /* (B*M1,64), (B*M2,64) */
-    int *bn_ok;                          /* 3 words */
+    int *bn_ok;                          /* 4 words */
     float *src_ws1, *src_ws2;
+    int defer_grad_reduce;               /* set by the caller: leave the images unfolded (sn2_adam_step_images folds them) */
 } sn2_net_bwd;
 
 #define SN2_NET_FORK 1          /* geometry: level-2 chain on io.stream_b, per-point 3-NN chain on io.stream_c (needs io.ctx) */
@@ -556,6 +571,13 @@ int sn2_net_forward(const sn2_net_model *m, const sn2_net_dims *d, const sn2_net
 /* its backward pass (loss.backward(), learning/train.py:64): every parameter gradient into image 0 of b->arena */
 int sn2_net_backward(const sn2_net_model *m, const sn2_net_dims *d, const sn2_net_geo *g, const sn2_net_act *a,
                      const sn2_net_bwd *b, void *stream);
+
+/* sn2_grad_reduce + sn2_adam_step in one launch, for a step with no exchange between them: grad_images = the `replicas` images
+ * of the flat gradient (image stride `stride` floats); image 0 holds the folded gradient afterwards (same additions, same order
+ * as sn2_grad_reduce).  sn2_net_bwd.defer_grad_reduce makes sn2_net_backward leave the images unfolded for it. */
+int sn2_adam_step_images(float *param, float *grad_images, int replicas, int stride, float *exp_avg, float *exp_avg_sq, int n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int *step_dev, float grad_scale,
+                         void *stream);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,8 @@ class NetAct(Structure):  # sn2_net_act
 class NetBwd(Structure):  # sn2_net_bwd
     _fields_ = [("dcov", c_void_p), ("dproba", c_void_p), ("arena", c_void_p), ("arena_words", c_long), ("images", c_int),
                 ("image_stride", c_int)] + [(n, c_void_p) for n in (
-                    "dy2", "dy3", "dx1", "dx2", "dx3", "dy_sa3", "dy1", "du1", "du2", "du3", "bn_ok", "src_ws1", "src_ws2")]
+                    "dy2", "dy3", "dx1", "dx2", "dx3", "dy_sa3", "dy1", "du1", "du2", "du3", "bn_ok", "src_ws1", "src_ws2")] + [
+                        ("defer_grad_reduce", c_int)]
 
 
 class NetIO(Structure):  # sn2_net_io
@@ -130,6 +131,8 @@ SIGNATURES = {
     "sn2_fp_backward": [POINTER(FP), c_void_p],
     "sn2_plot_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "sn2_plot_max_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sn2_global_pool_backward": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p],
     "sn2_global_level_forward": [POINTER(FP), POINTER(FP), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_debug_global_spin_limit": [ctypes.c_uint],
     "sn2_head_forward": [POINTER(Head), c_void_p],
@@ -154,6 +157,8 @@ SIGNATURES = {
                           c_void_p, c_void_p],
     "sn2_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
                       c_void_p, c_float, c_void_p],
+    "sn2_adam_step_images": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
+                             c_void_p, c_float, c_void_p],
     "sn2_net_ctx_create": [POINTER(c_void_p)],
     "sn2_net_ctx_destroy": [c_void_p],
     "sn2_net_geo_carve": [POINTER(NetModel), POINTER(NetDims), c_void_p, POINTER(NetGeo), POINTER(ctypes.c_size_t)],

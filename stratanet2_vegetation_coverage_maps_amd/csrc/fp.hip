@@ -2289,7 +2289,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
                        p->blk.grad_replica_stride);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    if (KNN && p->dsrc) {
+    if (KNN && p->dsrc && p->scatter_ready >= 0) {       // (scatter_ready < 0: the caller transposes the interpolation itself)
         if (!p->scatter_ws) return SN2_EINVAL;
         const int S = p->S_per_plot, Rp = p->R_per_plot, B = p->B;
         if (S > 8192) return SN2_ELIMIT;

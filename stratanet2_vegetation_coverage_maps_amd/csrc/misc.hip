@@ -159,6 +159,67 @@ extern "C" int sn2_plot_max_backward(const float* dout, const int* arg, int B, i
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The backward of the global level's pool in ONE launch (round 5; it was interp_gather_long_kernel + plot_max_bwd_kernel +
+// fp_bwd_bn_small_kernel<64>: 15 us of three launches for 1 MB):
+//   dx[b][c] += sum_r du[b R + r][c]      the transpose of knn_interpolate with k = 1 from the plot's ONE source (all weights 1,
+//                                         model/point_net2.py:137 with :41's single position), rows added in a fixed order;
+//   dy[b R + arg[b][c]][c] = dx[b][c]     the backward of global_max_pool (:39); dy zero elsewhere (the caller's zero fill);
+//   dbeta[c] += sum_b dx[b][c],  dgamma[c] += sum_b dx[b][c] (h[b R + arg[b][c]][c] - mean[c]) invstd[c]
+//                                         the BatchNorm sums of the block whose pre-BatchNorm rows h are: dy has B C non-zeros,
+//                                         so the sums over its B R rows are sums over B terms per channel.
+// One workgroup of 16 waves per plot: thread = (row group, channel), eight row loads in flight.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void global_pool_bwd_kernel(const float* __restrict__ du, int du_stride,
+                                                               const int* __restrict__ arg, const float* __restrict__ h,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               int R, float* __restrict__ dx, float* __restrict__ dy,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float s_part[16][64];
+    const int b = blockIdx.x, ch = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const float* db = du + (size_t)b * R * du_stride + ch;
+    float a0 = 0.f, a1 = 0.f;
+    int r = rg;
+    for (; r + 7 * 16 < R; r += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = db[(size_t)(r + u * 16) * du_stride];
+        a0 += (v[0] + v[1]) + (v[2] + v[3]);
+        a1 += (v[4] + v[5]) + (v[6] + v[7]);
+    }
+    for (; r < R; r += 16) a0 += db[(size_t)r * du_stride];
+    s_part[rg][ch] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_part[k][ch];
+        const size_t i = (size_t)b * 64 + ch;
+        const float g = dx[i] + t;
+        dx[i] = g;
+        const int ra = arg[i];
+        if (ra >= 0 && ra < R) {
+            const size_t row = (size_t)b * R + ra;
+            dy[row * 64 + ch] = g;
+            if (g != 0.f) {
+                atomicAdd(&dbeta[ch], g);
+                atomicAdd(&dgamma[ch], g * ((h[row * 64 + ch] - mean[ch]) * invstd[ch]));
+            }
+        }
+    }
+}
+
+extern "C" int sn2_global_pool_backward(const float* du, int du_stride, const int* arg, const float* h, const float* mean,
+                                        const float* invstd, int B, int R_per_plot, int C, float* dx, float* dy, float* dgamma,
+                                        float* dbeta, void* stream) {
+    if (!du || !arg || !h || !mean || !invstd || !dx || !dy || !dgamma || !dbeta || B <= 0 || R_per_plot <= 0 || du_stride < C)
+        return SN2_EINVAL;
+    if (C != 64) return SN2_ELIMIT;
+    hipLaunchKernelGGL(global_pool_bwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, du, du_stride, arg, h, mean, invstd,
+                       R_per_plot, dx, dy, dgamma, dbeta);
+    SN2_RETURN_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // torch.optim.Adam (amsgrad=False, L2 weight decay folded into the gradient) on flat fp32 buffers.
 // ------------------------------------------------------------------------------------------------------------
 // The step counter lives on the device, so a captured hipGraph of the whole training step replays with the right bias
@@ -192,6 +253,60 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             __hip_atomic_store(&step[0], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+// The same step with the gradient still spread over `replicas` images (sn2_block.grad_replicas): folds them exactly as
+// grad_reduce_kernel does (same order of additions), writes the folded gradient back to image 0 -- the parameters' .grad views
+// are right after the step -- and updates.  One launch instead of sn2_grad_reduce + sn2_adam_step where nothing (no exchange
+// between ranks) needs the folded gradient in between.
+__global__ __launch_bounds__(256) void adam_images_kernel(float* __restrict__ p, float* __restrict__ flat, int replicas, int stride,
+                                                          float* __restrict__ m, float* __restrict__ v, int n, float lr, float b1,
+                                                          float b2, float eps, float wd, int* __restrict__ step, float gscale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int now = __hip_atomic_load(&step[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (i < n) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = 1;
+        for (; r + 4 <= replicas; r += 4) {
+            s0 += flat[(size_t)r * stride + i];
+            s1 += flat[(size_t)(r + 1) * stride + i];
+            s2 += flat[(size_t)(r + 2) * stride + i];
+            s3 += flat[(size_t)(r + 3) * stride + i];
+        }
+        for (; r < replicas; ++r) s0 += flat[(size_t)r * stride + i];
+        const float gsum = flat[i] + ((s0 + s1) + (s2 + s3));
+        flat[i] = gsum;
+        const float t = (float)now;
+        const float bc1 = 1.f - powf(b1, t);
+        const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
+        float grad = gsum * gscale;
+        const float pi = p[i];
+        grad = fmaf(wd, pi, grad);
+        const float mi = m[i] + (1.f - b1) * (grad - m[i]);
+        const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ticket = atomicAdd(&step[1], 1);
+        if (ticket == (int)gridDim.x - 1) {
+            __hip_atomic_store(&step[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&step[0], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" int sn2_adam_step_images(float* param, float* grad_images, int replicas, int stride, float* exp_avg, float* exp_avg_sq,
+                                    int n, float lr, float beta1, float beta2, float eps, float weight_decay, int* step_dev,
+                                    float grad_scale, void* stream) {
+    if (!param || !grad_images || !exp_avg || !exp_avg_sq || !step_dev || n <= 0 || replicas < 1 || (replicas > 1 && stride < n))
+        return SN2_EINVAL;
+    hipLaunchKernelGGL(adam_images_kernel, dim3(sn2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad_images, replicas,
+                       stride, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
+    SN2_RETURN_LAUNCH();
 }
 
 extern "C" int sn2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int n, float lr,

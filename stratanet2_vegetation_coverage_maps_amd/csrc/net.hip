@@ -585,17 +585,19 @@ extern "C" int sn2_net_backward(const sn2_net_model* m, const sn2_net_dims* d, c
     SN2_TRY(sn2_fp_backward(&p2, cur));
     SN2_TRY(sn2_fp_bn_sums(&p2, m->fp3.gamma, m->fp3.beta, aux_row(a, 4, 2), aux_row(a, 4, 3), b->arena + m->fp3.ggamma,
                            b->arena + m->fp3.gbeta, b->bn_ok + 2, cur));
-    // FP3 -> d x3, d x2
+    // FP3 -> d x2 and the per-row gradients of its interpolated part; the pool between FP3 and SA3 in one launch: d x3 = their sum
+    // over the plot (k = 1 from the plot's one source), routed to the SA3 rows that attained the maximum, and SA3's BatchNorm sums
+    // over those B x 64 entries
     sn2_fp pf3;
     fp_desc(&pf3, d, a, fp3_in(m, d, g, a), gd);
     pf3.dy = b->dy3, pf3.dsrc = b->dx3, pf3.dsrc_stride = 64, pf3.dskip = b->dx2, pf3.dskip_stride = 32;
-    pf3.du_scratch = b->du3, pf3.scatter_ws = g->inv3, pf3.scatter_ready = 1, pf3.bn_sums_done = b->bn_ok + 2;
+    pf3.du_scratch = b->du3, pf3.scatter_ws = g->inv3, pf3.scatter_ready = -1, pf3.bn_sums_done = b->bn_ok + 2;
     SN2_TRY(sn2_fp_backward(&pf3, cur));
-    // global max pool -> SA3 rows
-    SN2_TRY(sn2_plot_max_backward(b->dx3, a->arg3, B, M2, 64, b->dy_sa3, cur));
+    SN2_TRY(sn2_global_pool_backward(b->du3, 64, a->arg3, a->h_sa3, aux_row(a, 3, 2), aux_row(a, 3, 3), B, M2, 64, b->dx3, b->dy_sa3,
+                                     b->arena + m->sa3.ggamma, b->arena + m->sa3.gbeta, cur));
     sn2_fp p3;
     fp_desc(&p3, d, a, sa3_in(m, d, g, a), gd);
-    p3.dy = b->dy_sa3, p3.dsrc = b->dx2, p3.dsrc_stride = 32;
+    p3.dy = b->dy_sa3, p3.dsrc = b->dx2, p3.dsrc_stride = 32, p3.bn_sums_done = b->bn_ok + 3;
     SN2_TRY(sn2_fp_backward(&p3, cur));
     // SA2 -> d x1 ; SA1
     sn2_sa sa;
@@ -603,6 +605,7 @@ extern "C" int sn2_net_backward(const sn2_net_model* m, const sn2_net_dims* d, c
     SN2_TRY(sn2_sa_backward(&sa, cur));
     sa1_desc(&sa, m, d, g, a, gd, b->dx1);
     SN2_TRY(sn2_sa_backward(&sa, cur));
-    // the images of (dW, db) -> image 0
+    // the images of (dW, db) -> image 0 (unless the optimiser step folds them itself: sn2_adam_step_images)
+    if (b->defer_grad_reduce) return 0;
     return sn2_grad_reduce(b->arena, m->n_flat, GRAD_IMAGES, b->image_stride, cur);
 }

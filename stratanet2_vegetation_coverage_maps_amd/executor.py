@@ -436,10 +436,13 @@ def backward(model, s, dcov, dproba):
     if dproba is not None:
         dproba = ops._chk(dproba.contiguous(), F32, (R, 4), "dproba")
         cb.dproba = dproba.data_ptr()
+    defer = bool(getattr(model, "defer_grad_reduce", False))
+    cb.defer_grad_reduce = int(defer)
     _lib.check(lib.sn2_net_backward(byref(ms.c), byref(plan.dims), byref(geo_struct(s.geo)), byref(s.cact), byref(cb), ops._stream()),
                "sn2_net_backward")
     flat = arena[:ms.n_flat]
     s.flat_grad = flat
     model._last_flat_grad = flat
+    model._grad_images_pending = (arena, cb.images, cb.image_stride) if defer else None
     # (one split call instead of 32 slices: the views are made in C++)
     return [p if len(shape) == 1 else p.view(shape) for p, shape in zip(flat.split(ms.param_numels), ms.param_shapes)]

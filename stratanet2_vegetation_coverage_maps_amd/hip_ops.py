@@ -691,7 +691,7 @@ SOURCE_SIDE = True     # False: never hand out src_ws, i.e. every row rebuilds i
 
 def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_affine=None, knn=None, skip=None,
             dy=None, dsrc=None, dskip=None, du_scratch=None, with_grads=False, interp_index=None,
-            bn_sums_done=None, row_perm=None, force_src_ws=False) -> FP:
+            bn_sums_done=None, row_perm=None, force_src_ws=False, gather=True) -> FP:
     """src: (B*S_per_plot, >=ca) rows when knn is given, else (B*R_per_plot, >=ca); skip: (B*R_per_plot, >=cb) row view.
     h of dtype bfloat16 (then dy and du_scratch too): the per-point layer stores its three activation buffers in bfloat16
     (include/strata_hip.h: sn2_fp.act_bf16; BASELINE config 5) -- only the source-side form of a layer of more than
@@ -767,6 +767,8 @@ def fp_desc(block: BlockBuffers, B, R_per_plot, S_per_plot, ca, cb, src, h, src_
             else:
                 d._scatter_ws = torch.empty(words, dtype=F32, device=src.device)
             d.scatter_ws = _ptr(d._scatter_ws)
+            if not gather:
+                d.scatter_ready = -1          # the per-row input gradients stay in du_scratch: the caller transposes (global_pool_backward)
     d.dy, d.dsrc, d.dskip, d.du_scratch = _ptr(dy), _ptr(dsrc), _ptr(dskip), _ptr(du_scratch)
     return d
 
@@ -879,6 +881,19 @@ def plot_max_backward(dout, arg, B, R_per_plot, C, dy):
     _chk(arg, I32, (B, C), "arg")
     _chk(dy, F32, (B * R_per_plot, hs), "dy")
     _call("sn2_plot_max_backward", _ptr(dout), _ptr(arg), B, R_per_plot, C, _ptr(dy), _stream())
+
+
+def global_pool_backward(du, arg, h, mean, invstd, B, R_per_plot, dx, dy, dgamma, dbeta):
+    """include/strata_hip.h: sn2_global_pool_backward -- the backward of the pool between FP3 and SA3 in one launch."""
+    _chk(du, F32, (B * R_per_plot, 64), "du")
+    _chk(arg, I32, (B, 64), "arg")
+    _chk(h, F32, (B * R_per_plot, 64), "h")
+    for t, n in ((mean, "mean"), (invstd, "invstd"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk(t, F32, (64,), n)
+    _chk(dx, F32, (B, 64), "dx")
+    _chk(dy, F32, (B * R_per_plot, 64), "dy")
+    _call("sn2_global_pool_backward", _ptr(du), 64, _ptr(arg), _ptr(h), _ptr(mean), _ptr(invstd), B, R_per_plot, 64, _ptr(dx), _ptr(dy),
+          _ptr(dgamma), _ptr(dbeta), _stream())
 
 
 def dropout_mask_words(keep: torch.Tensor) -> torch.Tensor:
@@ -1142,6 +1157,19 @@ def loss_backward(pred, gt, proba, pdf, m: float, e: float, grad_total):
     _call("sn2_loss_backward", _ptr(pred), _ptr(gt), B, _ptr(proba), _ptr(pdf), R, float(m), float(e), _ptr(grad_total),
           _ptr(dpred), _ptr(dproba), _stream())
     return dpred, dproba
+
+
+def adam_step_images(param, arena, replicas, stride, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):
+    """include/strata_hip.h: sn2_adam_step_images -- fold the gradient's images and take the Adam step in one launch."""
+    n = param.numel()
+    for t, nme in ((param, "param"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, F32, (n,), nme)
+    _chk(arena, F32, None, "arena")
+    if arena.numel() < replicas * stride or stride < n:
+        raise ValueError("adam_step_images: arena smaller than its images")
+    _chk(step_dev, I32, (2,), "step_dev")
+    _call("sn2_adam_step_images", _ptr(param), _ptr(arena), int(replicas), int(stride), _ptr(exp_avg), _ptr(exp_avg_sq), n, lr, beta1,
+          beta2, eps, weight_decay, _ptr(step_dev), grad_scale, _stream())
 
 
 def loss_term_forward(kind: int, x: torch.Tensor, y: Optional[torch.Tensor]):

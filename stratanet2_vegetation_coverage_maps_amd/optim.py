@@ -74,7 +74,11 @@ def flatten_parameters(model) -> torch.Tensor:
 
 class FlatAdam:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None,
-                 world_size=1, comm=None):
+                 world_size=1, comm=None, fold_gradient_images=False):
+        """fold_gradient_images: with no exchange between backward and update (one rank, no communicator) let THIS step's kernel
+        fold the 32 images of the flat gradient (sn2_adam_step_images) instead of a launch of its own at the end of the backward
+        pass: `model.defer_grad_reduce = True`; the parameters' `.grad` views hold the whole gradient after `step()` (before
+        it: image 0 only).  Ignored when an exchange needs the folded gradient first."""
         self.model = model
         self.flat = getattr(model, "_flat_params", None)
         if self.flat is None:
@@ -91,6 +95,9 @@ class FlatAdam:
         self.force_exchange = False           # torch's all_reduce even at world 1 (needs an initialised one-rank process group)
         if comm is not None and comm.world != world_size:
             raise ValueError("FlatAdam: the RCCL communicator and world_size disagree")
+        self.fold_gradient_images = bool(fold_gradient_images) and world_size == 1 and comm is None
+        if self.fold_gradient_images:
+            model.defer_grad_reduce = True
 
     def reset(self):
         """Forget the optimiser state: moments, step count AND the Adam kernel's arrival ticket (`step_words[1]`: the last
@@ -113,11 +120,23 @@ class FlatAdam:
         for p in self.model.parameters():
             p.grad = None
         self.model._last_flat_grad = None
+        self.model._grad_images_pending = None
 
     def step(self):
         g = self.model._last_flat_grad
         if g is None:
             raise RuntimeError("FlatAdam.step: no gradient (run backward through PointNet2 first)")
+        pending = getattr(self.model, "_grad_images_pending", None)
+        if pending is not None and not (self.world_size > 1 or self.force_exchange or self.comm is not None):
+            arena, replicas, stride = pending
+            self.model._grad_images_pending = None
+            ops.adam_step_images(self.flat, arena, replicas, stride, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
+                                 self.betas[1], self.eps, self.weight_decay, self.step_words, 1.0)
+            return
+        if pending is not None:                # an exchange was switched on after the backward pass: fold first
+            arena, replicas, stride = pending
+            self.model._grad_images_pending = None
+            ops.grad_reduce(arena, g.numel(), (replicas, stride))
         scale = allreduce_flat_grad(g, self.world_size, self.process_group, self.comm, self.force_exchange)   # RCCL over xGMI when world > 1
         ops.adam_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
                       self.weight_decay, self.step_words, scale)

@@ -174,6 +174,11 @@ class PointNet2(nn.Module):
     # launches is what bounded the reference's loop as written (learning/train.py:44-71).  False: the per-call path below (also
     # taken while hip_ops.timing measures single entry points).
     executor = os.environ.get("SN2_EXECUTOR", "1") == "1"
+    # True (set by optim.FlatAdam(fold_gradient_images=True) where no exchange sits between backward and update): the backward
+    # pass leaves the 32 images of the flat gradient unfolded and the optimiser's kernel folds them (sn2_adam_step_images: one
+    # launch less per step); until that step `p.grad` holds image 0 only.
+    defer_grad_reduce = False
+    _grad_images_pending = None
     fuse_eval_head = os.environ.get("SN2_FUSE_EVAL_HEAD", "1") == "1"     # eval: FP1 + head in one kernel (sn2_fp_head_eval)
     # training: SA3, its BatchNorm, the plot max, FP3 and its BatchNorm in one launch (sn2_global_level_forward) instead of five;
     # its workgroups exchange the batch statistics among themselves -- False where other processes share the device
@@ -739,7 +744,7 @@ class PointNet2(nn.Module):
         ops.head_backward(hd)
         # FP1's BatchNorm gradients fall out of lin1's (hip_ops.head_bn_sums): no extra pass over the B*N rows
         bn1 = self.fp1_module.nn[0][2]
-        bn_ok = torch.empty(3, dtype=I32, device=dev)      # per BatchNorm: did the shortcut apply (else the same kernel's row pass)
+        bn_ok = torch.empty(4, dtype=I32, device=dev)      # per BatchNorm: did the shortcut apply (else the same kernel's row pass)
         ops.head_bn_sums(hd, bn1.weight.detach(), bn1.bias.detach(), s.b_fp1.aux[2], s.b_fp1.aux[3], views[id(bn1.weight)],
                          views[id(bn1.bias)], bn_ok[0:1])
         # FP1 -> d(fp2 output)
@@ -758,19 +763,26 @@ class PointNet2(nn.Module):
         bn3 = self.fp3_module.nn[0][2]      # and FP3's from FP2's
         ops.fp_bn_sums(d2, bn3.weight.detach(), bn3.bias.detach(), s.b_fp3.aux[2], s.b_fp3.aux[3], views[id(bn3.weight)],
                        views[id(bn3.bias)], bn_ok[2:3])
-        # FP3 -> d x3, d x2
+        # FP3 -> d x2 and the per-row gradients of its interpolated part (left in du3: scatter_ready = -1); then the pool between
+        # FP3 and SA3 in one launch (hip_ops.global_pool_backward): d x3, its routing to the SA3 rows that attained the maximum, and
+        # SA3's BatchNorm sums over those B x 64 entries
         dx3, dx2 = buf["dx3"].view(B, 64), buf["dx2"].view(B * M2, 32)
-        ops.fp_backward(self._fp3_desc(s, dy=dy3, dsrc=dx3, dskip=dx2,
-                                       du_scratch=torch.empty(B * M2, 64, dtype=F32, device=dev), with_grads=True,
-                                       interp_index=s.inv3, bn_sums_done=bn_ok[2:3]))
-        # global max pool -> SA3 rows
+        du3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
+        ops.fp_backward(self._fp3_desc(s, dy=dy3, dsrc=dx3, dskip=dx2, du_scratch=du3, with_grads=True,
+                                       interp_index=s.inv3, bn_sums_done=bn_ok[2:3], gather=False))
         dy_sa3 = buf["dy_sa3"].view(B * M2, 64)
-        ops.plot_max_backward(dx3, s.arg3, B, M2, 64, dy_sa3)
-        ops.fp_backward(self._sa3_desc(s, dy=dy_sa3, dsrc=dx2, with_grads=True))
+        bn_sa3 = self.sa3_module.nn[0][2]
+        ops.global_pool_backward(du3, s.arg3, s.h_sa3, s.b_sa3.aux[2], s.b_sa3.aux[3], B, M2, dx3, dy_sa3,
+                                 views[id(bn_sa3.weight)], views[id(bn_sa3.bias)])
+        ops.fp_backward(self._sa3_desc(s, dy=dy_sa3, dsrc=dx2, with_grads=True, bn_sums_done=bn_ok[3:4]))
         # SA2 -> d x1 ; SA1
         ops.sa_backward(self._sa2_desc(s, dout=dx2, dfeat=dx1, g=True))
         ops.sa_backward(self._sa1_desc(s, dout=dx1, g=True))
-        ops.grad_reduce(arena, flat.numel(), images)      # the images of (dW, db) -> image 0 = `flat`
+        if getattr(self, "defer_grad_reduce", False):
+            self._grad_images_pending = (arena,) + tuple(images)       # FlatAdam folds the images inside its own kernel
+        else:
+            ops.grad_reduce(arena, flat.numel(), images)      # the images of (dW, db) -> image 0 = `flat`
+            self._grad_images_pending = None
         s.flat_grad = flat
         self._last_flat_grad = flat
         return [views[id(p)] for p in params]

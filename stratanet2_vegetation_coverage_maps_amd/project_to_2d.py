@@ -74,11 +74,66 @@ def project_to_plotwise_coverages(pred_pointwise, clouds, args, model=None, geom
         return _PlotProject.apply(pred_pointwise, clouds_dev, args.diam_pix, pix)
 
 
+# The reference's inference loop calls `project_to_2d_rasters` once PER PLOT of a batch it has just sent through the model
+# (predict.py:109-126, predict_utils.py:94-102): `coverages_pointwise[idx]` of `model.get_batch_format(...)` with `clouds[idx]`.
+# Both arguments are views of the batch's tensors, so the FIRST such call rasterises the whole batch in one launch and brings the
+# (B,3,D,D) result to the host in one read; the calls for the other plots of the batch are answered from that array.  Same
+# kernel per plot as the single-plot call: the same bits (tests/test_inference.py).  One batch is remembered, by the IDENTITY of
+# the batch tensors (weak references: a new batch is a new tensor object even where the allocator hands out the same address)
+# and the version counter of the coverages.  BATCH_RASTERS = False: every call rasterises its own plot.
+BATCH_RASTERS = True
+_RASTER_BATCH = {"cov": None, "clouds": None, "version": None, "grid": None, "rasters": None}
+
+
+def _batch_view(t, row_len):
+    """(base, index) when `t` is plot `index` of a contiguous batch tensor `base` whose plots are `row_len` elements long."""
+    base = getattr(t, "_base", None)
+    if base is None or not base.is_contiguous() or row_len <= 0:
+        return None, None
+    off = t.storage_offset() - base.storage_offset()
+    if off % row_len:
+        return None, None
+    return base, off // row_len
+
+
+def _rasters_of_batch(cloud, coverages_pointwise, args):
+    """The plot's rasters out of a batched launch, or None when the arguments are not plots of batch tensors."""
+    if coverages_pointwise.dim() != 2 or coverages_pointwise.shape[0] != 4 or cloud.dim() != 2:
+        return None
+    N = coverages_pointwise.shape[1]
+    if coverages_pointwise.stride() != (1, 4) or cloud.shape[1] != N or cloud.stride() != (N, 1):
+        return None
+    cbase, i = _batch_view(coverages_pointwise, 4 * N)             # (B*N,4) rows as PointNet2.forward returns them
+    if cbase is None or cbase.dim() != 2 or cbase.shape[1] != 4 or cbase.dtype != torch.float32 or cbase.shape[0] % N:
+        return None
+    B = cbase.shape[0] // N
+    lbase, j = _batch_view(cloud, cloud.shape[0] * N)              # (B,C,N) as the DataLoader collates them
+    if lbase is None or lbase.dim() != 3 or lbase.shape[0] != B or lbase.shape[2] != N or i != j or not (0 <= i < B):
+        return None
+    grid = (int(args.diam_pix), int(args.diam_meters))
+    c = _RASTER_BATCH
+    hit = (c["cov"] is not None and c["cov"]() is cbase and c["clouds"]() is lbase and c["version"] == cbase._version and
+           c["grid"] == grid)
+    if not hit:
+        import weakref
+        dev = cbase.device
+        with torch.cuda.device(dev):
+            clouds_dev = _clouds_on_device(lbase, dev)             # the forward's own upload when it is still remembered
+            rasters, _ = ops.raster_project(cbase.detach(), clouds_dev, grid[0], grid[1])
+            host = rasters.double().cpu().numpy()                  # ONE device-to-host read for the batch
+        c.update(cov=weakref.ref(cbase), clouds=weakref.ref(lbase), version=cbase._version, grid=grid, rasters=host)
+    return c["rasters"][i].copy()
+
+
 def project_to_2d_rasters(cloud, coverages_pointwise, args):
     """cloud (>=2,N) normalised coordinates of ONE plot, coverages_pointwise (4,N) -> np.ndarray float64
     (3, diam_pix, diam_pix) [low, med, high], image[y, x], NaN where no point falls, rows flipped."""
     if not coverages_pointwise.is_cuda:
         raise StrataHipError("project_to_2d_rasters needs coverages_pointwise on a HIP device: no CPU fallback")
+    if BATCH_RASTERS:
+        r = _rasters_of_batch(cloud, coverages_pointwise, args)
+        if r is not None:
+            return r
     dev = coverages_pointwise.device
     with torch.cuda.device(dev):
         cov = coverages_pointwise.detach().float().t().contiguous()                 # (N,4)

@@ -254,3 +254,60 @@ def test_argument_errors_come_back_as_codes_not_faults():
             m._geometry(torch.zeros(2, 3, 2048, device=DEV), torch.zeros(2, 2, dtype=torch.int32, device=DEV), out=g)
     finally:
         point_net2.MAX_NEIGHBORS = old
+
+
+def test_adam_kernel_that_folds_the_gradient_images_is_the_two_launches():
+    """`sn2_adam_step_images` == `sn2_grad_reduce` + `sn2_adam_step` on the same images: parameters, both moments, the folded
+    gradient left in image 0 and the step counter, BIT FOR BIT (same additions in the same order).  Then end to end:
+    `FlatAdam(fold_gradient_images=True)` makes the backward pass (executor and per-call path) leave the images unfolded, and
+    after `step()` the parameters' `.grad` views hold the whole gradient."""
+    from stratanet2_vegetation_coverage_maps_amd.optim import FlatAdam, flatten_parameters
+    g = torch.Generator().manual_seed(5)
+    n, replicas = 14997, 32
+    stride = (n + 63) // 64 * 64
+    arena = (torch.randn(replicas * stride + 100, generator=g) * 1e-3).to(DEV)
+    res = []
+    for fused in (True, False):
+        p = torch.randn(n, generator=torch.Generator().manual_seed(6)).to(DEV)
+        m1, m2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        step = torch.zeros(2, dtype=torch.int32, device=DEV)
+        a = arena.clone()
+        for _ in range(2):
+            if fused:
+                ops.adam_step_images(p, a, replicas, stride, m1, m2, 1e-3, 0.9, 0.999, 1e-8, 1e-3, step)
+            else:
+                ops.grad_reduce(a, n, (replicas, stride))
+                ops.adam_step(p, a[:n], m1, m2, 1e-3, 0.9, 0.999, 1e-8, 1e-3, step)
+            a[stride:replicas * stride].mul_(0.5)                # (other images for the second step; image 0 keeps its fold)
+        torch.cuda.synchronize()
+        res.append((p, m1, m2, a[:n].clone(), step))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert res[0][4].tolist() == [2, 0]
+    # ---- end to end
+    B, N = 3, 4096
+    args = make_args(subsample_size=N, ratio1=0.25, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=12)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    sd = network.init_state_dict(3)
+    grads = {}
+    for fold in (True, False):
+        for ex in (True, False):
+            m = _model(args, sd, ex).train()
+            flatten_parameters(m)
+            opt = FlatAdam(m, lr=0.0, weight_decay=0.0, fold_gradient_images=fold)          # (lr 0: the weights stay comparable)
+            assert m.defer_grad_reduce == fold
+            for _ in range(2):
+                opt.zero_grad()
+                cov, proba = m(d)
+                pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+                loss, _ = losses.total_loss(pred, proba, d["coverages"].to(DEV), d["pdf_all"].to(DEV), args.m, args.e)
+                loss.backward()
+                assert (m._grad_images_pending is not None) == fold
+                opt.step()
+                assert m._grad_images_pending is None
+            torch.cuda.synchronize()
+            grads[(fold, ex)] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    ref = grads[(False, False)]
+    for k, v in grads.items():
+        assert float((v - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), k

@@ -730,3 +730,42 @@ def test_global_level_exchange_area_is_not_allocated_inside_a_capture():
     finally:
         ops._GLOBAL_WS.clear()
         ops._GLOBAL_WS.update(saved)
+
+
+def test_per_plot_rasters_of_a_batch_come_from_one_launch_and_are_the_same_bits():
+    """The reference's inference loop (predict.py:103-126) calls `project_to_2d_rasters(clouds[idx], coverages_pointwise[idx], args)`
+    per plot of the batch it just sent through the model.  The drop-in answers those calls from ONE batched launch + ONE
+    device-to-host read per batch (both arguments are views of the batch's tensors): same arrays as plot-by-plot launches, for
+    consecutive batches (a new batch is recognised by tensor identity, not by address), with autograd on as in the reference."""
+    from stratanet2_vegetation_coverage_maps_amd import project_to_2d as p2d
+    B, N = 5, 4096
+    args = make_args(subsample_size=N, ratio1=0.25, r1=1.0, ratio2=0.25, r2=2.0)
+    m = _model(args, network.init_state_dict(7)).eval()
+    calls = []
+    orig = ops.raster_project
+    ops.raster_project = lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1]
+    try:
+        for first in (0, 50, 0):                              # the third batch has the first one's data in new tensors
+            d = make_batch(B, N, first_plot=first)
+            cloud_data = {"cloud": d["cloud"], "xyz": d["xyz"], "fps_start": torch.zeros(2, B, dtype=torch.int64)}
+            clouds = cloud_data["cloud"]
+            cov, _ = m(cloud_data)
+            cov_b = m.get_batch_format(cov)
+            calls.clear()
+            got = [project_to_2d_rasters(clouds[i], cov_b[i], args) for i in range(B)]
+            assert calls == [B * N]                           # one launch over the whole batch
+            p2d.BATCH_RASTERS = False
+            try:
+                calls.clear()
+                want = [project_to_2d_rasters(clouds[i], cov_b[i], args) for i in range(B)]
+                assert calls == [N] * B
+            finally:
+                p2d.BATCH_RASTERS = True
+            for a, b in zip(got, want):
+                assert a.dtype == np.float64 and a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+            # a call that is NOT a plot of a batch (its own tensors) takes the single-plot path
+            calls.clear()
+            one = project_to_2d_rasters(clouds[1].clone(), cov_b[1].clone(), args)
+            assert calls == [N] and np.array_equal(one, want[1], equal_nan=True)
+    finally:
+        ops.raster_project = orig
