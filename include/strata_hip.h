@@ -305,11 +305,12 @@ int sn2_global_pool_backward(const float *du, int du_stride, const int *arg, con
  *         the library (the launch epoch lives there: allocate them once, at the size of the largest batch, and never again while
  *         graphs that captured their address exist); launches that share them must be on one stream at a time.
  *   A wait for the peers' sums is bounded (HIP does not promise that the B workgroups of a launch are resident together): a
- *   workgroup whose wait runs out counts itself in ctl[1] and leaves, and the call's SECOND launch -- one workgroup that reads
- *   two words and returns when nothing gave up -- then computes the whole level again, alone, with the same tiles and the same
- *   fixed-order sums: the results (rows, statistics, running statistics, counters) are those of an undisturbed launch, bit for
- *   bit, whatever happened (torch's BatchNorm has no such failure mode: model/point_net2.py:45-53).  ctl[1] stays as a sticky
- *   count a host may read where it synchronises anyway, to learn that launches are being repeated.
+ *   workgroup whose wait runs out counts itself in ctl[1] and leaves; every workgroup takes a ticket on its way out, and the
+ *   one that leaves LAST -- all its peers are gone -- finds the count changed and computes the whole level again, alone, with the
+ *   same tiles and the same fixed-order sums: the results (rows, statistics, running statistics, counters) are those of an
+ *   undisturbed launch, bit for bit, whatever happened (torch's BatchNorm has no such failure mode: model/point_net2.py:45-53).
+ *   An undisturbed launch pays one fence and one atomic per workgroup for it.  ctl[1] stays as a sticky count a host may read
+ *   where it synchronises anyway, to learn that launches are being repeated.
  * SN2_ELIMIT for other shapes, bfloat16 operands or more than 28 plots: use the separate calls. */
 #define SN2_GLOBAL_XCHG_WORDS(B) ((size_t)2 * (size_t)(B) * 4 * 128)
 #define SN2_GLOBAL_CTL_WORDS 8

@@ -1485,19 +1485,13 @@ __device__ __forceinline__ bool gl_collect(const gl_u64* gx, int n, unsigned tag
 // not promise that the B workgroups of a launch are resident together) or that finds a peer's POISON gives up: it counts itself
 // in ctl[1], publishes POISON instead of its FP3 sums and leaves; workgroup 0 updates a layer's running statistics only when
 // its own collection of that layer's sums was complete, and says which it updated in ctl[3].
-// REPAIR = true: the gated launch behind it (one workgroup, same stream).  ctl[1] == ctl[2] -- no wait gave up since the last
-// repair -- and it returns at once; otherwise it computes the WHOLE level alone, plot after plot, with the same tiles, the same
+// REPAIR = true: run by the workgroup that leaves the launch LAST (global_level_fwd_kernel's exit protocol) when ctl[1] != ctl[2]
+// -- a wait gave up since the last repair: it computes the WHOLE level alone, plot after plot, with the same tiles, the same
 // per-group sums published to and collected from the same exchange area and the same fixed-order finalisation -- the bits of
 // an undisturbed launch --, applies the running-statistics updates workgroup 0 did not (ctl[3]), and moves the epoch past
 // every tag a late workgroup of the failed launch may have written.
 template <bool REPAIR>
-__global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float gl_smem[];
-    if constexpr (REPAIR) {
-        if (__hip_atomic_load(&A.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-            __hip_atomic_load(&A.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            return;                              // the launch in front was undisturbed (the usual case: two loads)
-    }
+__device__ __forceinline__ void gl_level_body(const GlArgs& A, float* gl_smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 8), g = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
     float* s_q = gl_smem + grp * 64 * GL_QS;                     // the group's staged rows
@@ -1815,6 +1809,39 @@ __global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
             }
         }
     }
+}
+
+// The launch: one workgroup per plot runs the level (gl_level_body<false>); then the exit protocol -- every workgroup takes a
+// ticket on its way out, and the one that takes the LAST ticket (all its peers have left) looks at the give-up count: unchanged
+// since the last repair (the usual case: one barrier and one atomic per workgroup) and it leaves too; otherwise it runs the
+// whole level again alone (gl_level_body<true>).  (Round 5's first version repaired with a launch of its own behind this one:
+// 4.8 us for a kernel that reads two words -- more than the fused launch saves.)
+// No device-scope fence in that protocol (one per workgroup cost 3.5 us of the kernel's 27), and none is needed:
+//   * the words the repair DECIDES by (ctl[], the granules) are agent-scope atomics issued in front of the workgroup's barrier,
+//     hence complete before its ticket;
+//   * everything else a workgroup of the failed launch wrote with plain stores is either the value the repair writes itself --
+//     SA3's rows do not depend on the exchange; FP3's rows, x3, a / c / mean / invstd were only written by workgroups whose
+//     collection of the statistics was COMPLETE, i.e. from the same sums in the same order -- so a late store of it changes
+//     nothing, or it is guarded: the running statistics and counters of a layer are touched by workgroup 0 OR by the repair,
+//     never both (ctl[3], an atomic, says which).
+__global__ __launch_bounds__(1024) void global_level_fwd_kernel(GlArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+    __shared__ int s_repair;
+    gl_level_body<false>(A, gl_smem);
+    __syncthreads();                             // (every wave's atomics of the body are complete)
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(&A.ctl[4], 1u);
+        int repair = 0;
+        if (t == gridDim.x - 1) {                // every other workgroup of the launch has left its body
+            __hip_atomic_store(&A.ctl[4], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            repair = __hip_atomic_load(&A.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                     __hip_atomic_load(&A.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_repair = repair;
+    }
+    __syncthreads();
+    if (!s_repair) return;
+    gl_level_body<true>(A, gl_smem);
 }
 
 #ifdef SN2_SPLIT_STAMPS
@@ -3272,12 +3299,10 @@ extern "C" int sn2_global_level_forward(const sn2_fp* sa3, const sn2_fp* fp3, fl
     A.xchg = xchg, A.ctl = ctl;
     A.spin_limit = g_gl_spin_limit;
     const size_t lds = ((size_t)GL_FIXED_FLOATS + (size_t)B * GL_GROUPS * 128) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&global_level_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&global_level_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(global_level_fwd_kernel<false>, dim3(B), dim3(1024), lds, (hipStream_t)stream, A);
-    // the repair launch: one workgroup that reads two control words and leaves -- unless a wait of the launch above gave up
-    // (nothing guarantees that its B workgroups are resident together), in which case it computes the whole level again
-    hipLaunchKernelGGL(global_level_fwd_kernel<true>, dim3(1), dim3(1024), lds, (hipStream_t)stream, A);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&global_level_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // (the repair of a launch whose waits gave up -- nothing guarantees that its B workgroups are resident together -- is done
+    // inside the launch, by the workgroup that leaves last)
+    hipLaunchKernelGGL(global_level_fwd_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, A);
     SN2_RETURN_LAUNCH();
 }
 

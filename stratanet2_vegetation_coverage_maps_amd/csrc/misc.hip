@@ -5,12 +5,18 @@
 // BatchNorm1d finalisation (torch defaults: eps 1e-5, momentum 0.1, biased variance to normalise, unbiased variance
 // into running_var) -- model/point_net2.py:45-53.  The sums arrive as per-workgroup fp32 slots.
 // ------------------------------------------------------------------------------------------------------------
+// APPLY (round 5): the set-abstraction levels' last finalisation also writes the level's output, out = a ext + c on the (rows, C)
+// extremum (0 for a centroid that received no message) -- sa_finalize_kernel's job, a launch of its own until now.  The grid
+// is then several workgroups: EVERY one finalises (the same slots in the same order: the same a, c; ~100 KB of L2 reads each),
+// workgroup 0 alone writes the statistics and the running-statistics update, and each applies its share of the rows.
+template <bool APPLY>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ a, float* __restrict__ c, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, const float* __restrict__ slots, int nslots,
                                    const unsigned long long* __restrict__ count_dev, long count_imm, int training,
-                                   long long* __restrict__ num_batches_tracked) {
+                                   long long* __restrict__ num_batches_tracked, const float* __restrict__ ext = nullptr,
+                                   const int* __restrict__ arg = nullptr, float* __restrict__ out = nullptr, long n_out = 0) {
     // thread = (slot group g, column col of the 2C-wide slot row): consecutive threads read consecutive floats of one slot
     // row (coalesced; one lane per (channel, 16 slots) with a 2C-float stride took 13 us for 1024 slots), every thread adds
     // its slots g, g+G, ... in fp64 in a fixed order, then the G partials of a column are added in a fixed order: the
@@ -50,31 +56,79 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(int C, const float* _
             s2 += s_part[gg * W2 + C + o];
         }
     }
-    if (!live) return;
-    if (training && o == 0 && num_batches_tracked) *num_batches_tracked += 1;   // BatchNorm1d's counter: once per training forward
-    float mean, invstd, aa, cc;
-    if (training) {
-        const double n = count_dev ? (double)(*count_dev) : (double)count_imm;
-        sn2_bn_from_sums(s1, s2, n, gamma[o], beta[o], &running_mean[o], &running_var[o], aa, cc, mean, invstd);
-    } else {
-        mean = running_mean[o];
-        invstd = 1.0f / sqrtf(running_var[o] + 1e-5f);
-        aa = gamma[o] * invstd;
-        cc = beta[o] - mean * aa;
+    const bool lead = !APPLY || blockIdx.x == 0;
+    __shared__ float s_ac[2][64];
+    if (live) {
+        if (lead && training && o == 0 && num_batches_tracked) *num_batches_tracked += 1;   // BatchNorm1d's counter: once per training forward
+        float mean, invstd, aa, cc;
+        if (training) {
+            const double n = count_dev ? (double)(*count_dev) : (double)count_imm;
+            sn2_bn_from_sums(s1, s2, n, gamma[o], beta[o], lead ? &running_mean[o] : nullptr, lead ? &running_var[o] : nullptr, aa, cc,
+                             mean, invstd);
+        } else {
+            mean = running_mean[o];
+            invstd = 1.0f / sqrtf(running_var[o] + 1e-5f);
+            aa = gamma[o] * invstd;
+            cc = beta[o] - mean * aa;
+        }
+        if (lead) {
+            a[o] = aa;
+            c[o] = cc;
+            mean_out[o] = mean;
+            invstd_out[o] = invstd;
+        }
+        if constexpr (APPLY) s_ac[0][o] = aa, s_ac[1][o] = cc;
     }
-    a[o] = aa;
-    c[o] = cc;
-    mean_out[o] = mean;
-    invstd_out[o] = invstd;
+    if constexpr (APPLY) {
+        __syncthreads();
+        // out = a ext + c on this workgroup's share of the (rows, C) elements, four at a time (C is a multiple of 4)
+        const long n4 = n_out >> 2;
+        for (long i4 = (long)blockIdx.x * 1024 + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * 1024) {
+            const float4 e = reinterpret_cast<const float4*>(ext)[i4];
+            const int4 g4 = reinterpret_cast<const int4*>(arg)[i4];
+            const int o0 = (int)((i4 << 2) % C);
+            float4 r;
+            r.x = g4.x >= 0 ? fmaf(s_ac[0][o0], e.x, s_ac[1][o0]) : 0.f;
+            r.y = g4.y >= 0 ? fmaf(s_ac[0][o0 + 1], e.y, s_ac[1][o0 + 1]) : 0.f;
+            r.z = g4.z >= 0 ? fmaf(s_ac[0][o0 + 2], e.z, s_ac[1][o0 + 2]) : 0.f;
+            r.w = g4.w >= 0 ? fmaf(s_ac[0][o0 + 3], e.w, s_ac[1][o0 + 3]) : 0.f;
+            reinterpret_cast<float4*>(out)[i4] = r;
+        }
+    }
 }
 
 int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm, int training,
                     hipStream_t st) {
     if (!blk || blk->cout <= 0 || blk->cout > 64 || nslots < 0 || nslots > SN2_STAT_SLOTS) return SN2_EINVAL;
     if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(1), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
                        blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
-                       count_dev, count_imm, training, blk->num_batches_tracked);
+                       count_dev, count_imm, training, blk->num_batches_tracked, (const float*)nullptr, (const int*)nullptr,
+                       (float*)nullptr, 0L);
+    SN2_RETURN_LAUNCH();
+}
+
+// ... and the level's output out = a ext + c (0 where arg < 0) in the same launch; ext, arg, out: (rows, cout), cout % 4 == 0
+int sn2_bn_finalize_apply(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm, int training,
+                          const float* ext, const int* arg, float* out, long rows, hipStream_t st) {
+    if (!blk || blk->cout <= 0 || blk->cout > 64 || (blk->cout & 3) || nslots < 0 || nslots > SN2_STAT_SLOTS || !ext || !arg || !out ||
+        rows <= 0)
+        return SN2_EINVAL;
+    if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
+    const long n_out = rows * blk->cout;
+    // ~8 elements per thread; every workgroup of a TRAINING pass reads all the slots again (nslots x 2 cout floats: keep that
+    // to a few MB of L2 reads in total), an eval pass reads none: the grid follows the rows (parcel inference: 20 M elements)
+    int grid = sn2_cdiv(n_out, 1024 * 8);
+    long cap = 4096;
+    if (training) {
+        const long per_wg = (long)nslots * 2 * blk->cout * 4;
+        cap = (8L << 20) / (per_wg > 0 ? per_wg : 1);
+        cap = cap < 32 ? 32 : (cap > 256 ? 256 : cap);
+    }
+    grid = grid < 1 ? 1 : (grid > cap ? (int)cap : grid);
+    hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(grid), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
+                       blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
+                       count_dev, count_imm, training, blk->num_batches_tracked, ext, (const int*)arg, out, n_out);
     SN2_RETURN_LAUNCH();
 }
 

@@ -264,3 +264,6 @@ __device__ __forceinline__ void stats_to_slot(const float (&ssum)[C], const floa
 // affine (a, c), the saved (mean, invstd) and the running-statistics update.
 int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm,
                     int training, hipStream_t st);
+// the same + a set-abstraction level's output out = a ext + c (0 where arg < 0) over (rows, cout) in the same launch (misc.hip)
+int sn2_bn_finalize_apply(const sn2_block* blk, int nslots, const unsigned long long* count_dev, long count_imm, int training,
+                          const float* ext, const int* arg, float* out, long rows, hipStream_t st);

@@ -22,14 +22,7 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st);
 
 namespace {
 
-// out = a*ext + c  (0 for a centroid that received no message, as PointConv's scatter-max)
-__global__ void sa_finalize_kernel(const float* __restrict__ ext, const int* __restrict__ arg, const float* __restrict__ a,
-                                   const float* __restrict__ c, int rows, int C, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * C) return;
-    const int o = i % C;
-    out[i] = arg[i] >= 0 ? fmaf(a[o], ext[i], c[o]) : 0.f;
-}
+// (out = a*ext + c, 0 for a centroid that received no message as PointConv's scatter-max: misc.hip, bn_finalize_kernel<true>)
 
 // dbeta[o] = sum_i dout[i][o],  dgamma[o] = sum_i dout[i][o] * xhat(ext[i][o])  over the B*M extremum rows
 __global__ __launch_bounds__(256) void sa_bwd_prep_kernel(const float* __restrict__ dout, const float* __restrict__ ext,
@@ -97,11 +90,8 @@ int forward_t(const sn2_sa* p, int training, hipStream_t st) {
         SN2_TRY(sn2_bn_finalize(&p->blk[0], nb, p->total, 0, training, st));
     }
     SN2_TRY((sa_mfma_launch_fwd<CF, NL, C1, C2, 1>(p, training, st, &nb)));
-    SN2_TRY(sn2_bn_finalize(last, nb, p->total, 0, training, st));
-    const int rows = p->B * p->M, C = last->cout;
-    hipLaunchKernelGGL(sa_finalize_kernel, dim3(sn2_cdiv((long)rows * C, 256)), dim3(256), 0, st, p->ext, p->arg, last->a,
-                       last->c, rows, C, p->out);
-    SN2_RETURN_LAUNCH();
+    // the last block's statistics -> (a, c), and out = a ext + c, in ONE launch (round 5: bn_finalize + sa_finalize_kernel were two)
+    return sn2_bn_finalize_apply(last, nb, p->total, 0, training, p->ext, p->arg, p->out, (long)p->B * p->M, st);
 }
 
 template <int CF, int NL, int C1, int C2>
