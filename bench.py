@@ -505,8 +505,9 @@ def build_training(dev, local_rank, rank, world, B, n_points, arch, dtype, n_slo
         if geo is not None:
             cd["geometry"] = geo
         cov, proba = model(cd)
-        pred = project_to_plotwise_coverages(cov, inp["cloud"], args, geometry=geo)
-        loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
+        # projection + loss (learning/train.py:54-62): one autograd node over three launches when the geometry pass left the
+        # pixel ids (else project_to_plotwise_coverages + total_loss: seven)
+        loss, _, _ = losses.projected_total_loss(cov, proba, inp["cloud"], inp["gt"], inp["pdf"], args, geometry=geo, model=model)
         loss.backward(gradient=seed)
         return loss
 

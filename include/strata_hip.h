@@ -431,6 +431,20 @@ int sn2_loss_forward(const float *pred, const double *gt, int B, const float *pr
 int sn2_loss_backward(const float *pred, const double *gt, int B, const float *proba, const double *pdf, int R, double m,
                       double e, const double *grad_total, float *dpred, float *dproba, void *stream);
 
+/* Projection + loss of the training step (learning/train.py:54-62) in three launches instead of seven (round 5):
+ * sn2_projected_loss_forward = sn2_plot_project_forward_pix (pixel ids `pix` from sn2_plot_pixels) + sn2_loss_forward in two
+ * launches -- the scatter of the coverages and the pointwise loss sums side by side, then the per-plot finalisation whose last
+ * workgroup adds the loss up -- and sn2_projected_loss_backward = sn2_loss_backward + sn2_plot_project_backward in one pass over
+ * the points.  Same pred / arg / nocc / dcoverages / dproba bits as the separate calls; out[4] as sn2_loss_forward's to fp64
+ * re-association.  keys: SN2_P2_KEY_PARTS(N)*B*D*D*3 u64; partials: SN2_PROJECTED_LOSS_WS doubles (no initialisation). */
+#define SN2_PROJECTED_LOSS_WS (2 * 512 + 2)
+int sn2_projected_loss_forward(const float *coverages, const int *pix, const float *proba, const double *pdf, const double *gt,
+                               int B, int N, int D, double m, double e, unsigned long long *keys, int *arg, int *nocc,
+                               float *pred, double *partials, double *out, void *stream);
+int sn2_projected_loss_backward(const float *pred, const double *gt, int B, const float *proba, const double *pdf, int N, int D,
+                                double m, double e, const double *grad_total, const int *arg, const int *nocc, const int *pix,
+                                float *dcoverages, float *dproba, void *stream);
+
 /* ---- optimiser step of the timed training step -- torch.optim.Adam as configured in learning/train.py:180-185
  * (L2 weight decay added to the gradient), on flat buffers; grad_scale multiplies the gradient first (1/world). */
 int sn2_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int n, float lr, float beta1,

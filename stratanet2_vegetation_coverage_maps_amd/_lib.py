@@ -157,6 +157,10 @@ SIGNATURES = {
                           c_void_p, c_void_p],
     "sn2_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
                       c_void_p, c_float, c_void_p],
+    "sn2_projected_loss_forward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sn2_projected_loss_backward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_adam_step_images": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
                              c_void_p, c_float, c_void_p],
     "sn2_net_ctx_create": [POINTER(c_void_p)],

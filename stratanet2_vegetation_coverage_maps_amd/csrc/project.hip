@@ -310,6 +310,273 @@ extern "C" int sn2_plot_project_forward_pix(const float* pred_pointwise, const i
     SN2_RETURN_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Projection + loss of the training step in THREE launches instead of seven (round 5): learning/train.py:54-62,
+//   pred = project_to_plotwise_coverages(coverages_pointwise, clouds, args)                       model/project_to_2d.py:7-55
+//   loss = get_absolute_loss(pred, gt) + m get_NLL_loss(proba, pdf) + e get_entropy_loss(proba)   learning/loss_functions.py:9-57
+// and their gradients.  The chip's floor for ANY launch is ~4.5 us (an empty kernel), the seven kernels were 4-7 us each:
+//   launch 1  two independent jobs side by side: workgroups [0, parts B) scatter the coverages into per-slice key tables
+//             (scatter_max_pix_kernel's body), the rest sum the pointwise loss terms (loss_point_kernel's body);
+//   launch 2  per plot: maximum over the slices, arg-max points, mean over occupied pixels (p2_finalize_kernel's body) -- and
+//             the workgroup that leaves last adds the loss up (loss_final_kernel's body); the B x 5 words it needs from its
+//             peers travel as agent-scope atomics, complete before their ticket;
+//   backward  one pass over the points: d loss / d proba (loss_bwd_kernel's body) and d loss / d coverages (p2_backward_kernel's,
+//             with the B x 3 values of d loss / d pred it needs recomputed from pred and gt by every thread).
+// Same arithmetic per element as the separate kernels: the same pred, arg, dcov, dproba bits; the loss sums are grouped by
+// 1024 instead of 256 rows per workgroup (fp64: 1e-16).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int PL_LOSS_BLOCKS = 512;
+constexpr float PL_EPS_F = 0.0001f;
+constexpr double PL_EPS_D = 0.0001;
+
+__device__ __forceinline__ double pl_wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <bool NLL, bool ENT>
+__global__ __launch_bounds__(1024) void projected_loss_scatter_kernel(const float* __restrict__ vals, const int* __restrict__ pix,
+                                                                     int B, int N, int D, int parts,
+                                                                     unsigned long long* __restrict__ keys_part,
+                                                                     const float4* __restrict__ proba, const double* __restrict__ pdf,
+                                                                     int R, double* __restrict__ partials, int n_loss_blocks,
+                                                                     unsigned* __restrict__ ticket) {
+    extern __shared__ unsigned long long s_keys[];  // D*D*3 (the scatter workgroups)
+    const int n_scatter = parts * B;
+    if ((int)blockIdx.x < n_scatter) {
+        const int b = blockIdx.x / parts, part = blockIdx.x - b * parts;
+        const int ncell3 = D * D * 3;
+        for (int i = threadIdx.x; i < ncell3; i += 1024) s_keys[i] = 0ull;
+        __syncthreads();
+        const int per = (N + parts - 1) / parts;
+        const int lo = part * per, hi = min(N, lo + per);
+        for (int n = lo + threadIdx.x; n < hi; n += 1024) {
+            const int cell = pix[(size_t)b * N + n];
+            const float4 v = reinterpret_cast<const float4*>(vals)[(size_t)b * N + n];
+            const unsigned long long tag = (unsigned long long)(0xFFFFFFFFu - (unsigned)n);
+            atomicMax(&s_keys[cell * 3 + 0], ((unsigned long long)f2ord(v.x) << 32) | tag);
+            atomicMax(&s_keys[cell * 3 + 1], ((unsigned long long)f2ord(v.z) << 32) | tag);
+            atomicMax(&s_keys[cell * 3 + 2], ((unsigned long long)f2ord(v.w) << 32) | tag);
+        }
+        __syncthreads();
+        unsigned long long* g = keys_part + ((size_t)b * parts + part) * ncell3;
+        for (int i = threadIdx.x; i < ncell3; i += 1024) g[i] = s_keys[i];
+        return;
+    }
+    // ---- the pointwise loss terms: one row per lane, 16 B of probabilities + 24 B of densities
+    const int lb = blockIdx.x - n_scatter;
+    if (lb == 0 && threadIdx.x == 0) *ticket = 0u;                  // the finalisation's arrival counter (next launch)
+    __shared__ double s_part[2][16];
+    double nll = 0.0, ent = 0.0;
+    for (int i = lb * 1024 + threadIdx.x; i < R; i += n_loss_blocks * 1024) {
+        const float4 p = proba[i];
+        if constexpr (NLL) {
+            const double f0 = pdf[3 * (size_t)i], f1 = pdf[3 * (size_t)i + 1], f2 = pdf[3 * (size_t)i + 2];
+            const float pg = p.x + p.y;
+            const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
+            nll -= log(lik);
+        }
+        if constexpr (ENT) {
+            const float e2 = p.z * logf(p.z + PL_EPS_F) + (1.f - p.z) * logf(1.f - p.z + PL_EPS_F);
+            const float e3 = p.w * logf(p.w + PL_EPS_F) + (1.f - p.w) * logf(1.f - p.w + PL_EPS_F);
+            ent -= (double)e2 + (double)e3;
+        }
+    }
+    nll = pl_wave_sum_f64(nll);
+    ent = pl_wave_sum_f64(ent);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s_part[0][w] = nll, s_part[1][w] = ent;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, c = 0.0;
+        for (int k = 0; k < 16; ++k) a += s_part[0][k], c += s_part[1][k];
+        partials[2 * lb] = a;
+        partials[2 * lb + 1] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void projected_loss_finalize_kernel(const unsigned long long* __restrict__ keys, int B, int D,
+                                                                      int parts, int* __restrict__ arg, int* __restrict__ nocc,
+                                                                      float* __restrict__ pred, const double* __restrict__ gt,
+                                                                      const double* __restrict__ partials, int n_loss_blocks, int R,
+                                                                      double m, double e, unsigned* __restrict__ ticket,
+                                                                      double* __restrict__ out) {
+    __shared__ float s[5][4];
+    __shared__ int s_last;
+    __shared__ double s3[3][256];
+    const int b = blockIdx.x;
+    const int ncell = D * D;
+    float lo = 0.f, so = 0.f, me = 0.f, hi = 0.f, cnt = 0.f;
+    for (int c = threadIdx.x; c < ncell; c += 256) {
+        const size_t base = ((size_t)b * ncell + c) * 3;
+        const unsigned long long* kp = keys + ((size_t)b * parts * ncell + c) * 3;
+        unsigned long long k0 = kp[0], k1 = kp[1], k2 = kp[2];
+        for (int q = 1; q < parts; ++q) {
+            const unsigned long long* kq = kp + (size_t)q * ncell * 3;
+            const unsigned long long a0 = kq[0], a1 = kq[1], a2 = kq[2];
+            k0 = a0 > k0 ? a0 : k0;
+            k1 = a1 > k1 ? a1 : k1;
+            k2 = a2 > k2 ? a2 : k2;
+        }
+        if (k0) {
+            const float l = ord2f((uint32_t)(k0 >> 32));
+            lo += l;
+            so += 1.0f - l;
+            me += ord2f((uint32_t)(k1 >> 32));
+            hi += ord2f((uint32_t)(k2 >> 32));
+            cnt += 1.f;
+            arg[base + 0] = (int)(0xFFFFFFFFu - (uint32_t)(k0 & 0xFFFFFFFFull));
+            arg[base + 1] = (int)(0xFFFFFFFFu - (uint32_t)(k1 & 0xFFFFFFFFull));
+            arg[base + 2] = (int)(0xFFFFFFFFu - (uint32_t)(k2 & 0xFFFFFFFFull));
+        } else {
+            arg[base + 0] = arg[base + 1] = arg[base + 2] = -1;
+        }
+    }
+    lo = wave_sum(lo);
+    so = wave_sum(so);
+    me = wave_sum(me);
+    hi = wave_sum(hi);
+    cnt = wave_sum(cnt);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s[0][w] = lo, s[1][w] = so, s[2][w] = me, s[3][w] = hi, s[4][w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[5];
+        for (int q = 0; q < 5; ++q) t[q] = (s[q][0] + s[q][1]) + (s[q][2] + s[q][3]);
+        const float n = fmaxf(t[4], 1.f);
+        // (agent-scope stores: the workgroup that adds the loss up reads them from another CU, maybe another XCD)
+        for (int q = 0; q < 4; ++q)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(pred) + b * 4 + q, __float_as_uint(t[q] / n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(nocc + b, (int)t[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (atomicAdd(ticket, 1u) == (unsigned)B - 1u) ? 1 : 0;      // (the stores above are this thread's: program order)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup out: the loss value (loss_final_kernel)
+    double nll = 0.0, ent = 0.0, ab = 0.0;
+    for (int i = threadIdx.x; i < n_loss_blocks; i += 256) nll += partials[2 * i], ent += partials[2 * i + 1];
+    for (int i = threadIdx.x; i < 3 * B; i += 256) {
+        const int bb = i / 3, c = i - 3 * bb, col = c == 0 ? 0 : c + 1;
+        const float pv = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(pred) + 4 * bb + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const double d = (double)pv - gt[4 * bb + col];
+        ab += sqrt(d * d + PL_EPS_D);
+    }
+    s3[0][threadIdx.x] = nll, s3[1][threadIdx.x] = ent, s3[2][threadIdx.x] = ab;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            s3[0][threadIdx.x] += s3[0][threadIdx.x + o];
+            s3[1][threadIdx.x] += s3[1][threadIdx.x + o];
+            s3[2][threadIdx.x] += s3[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double l_abs = s3[2][0] / (3.0 * B), l_nll = n_loss_blocks > 0 ? s3[0][0] / R : 0.0;
+        const double l_ent = n_loss_blocks > 0 ? (double)(float)(s3[1][0] / (2.0 * R)) : 0.0;
+        out[0] = l_abs + m * l_nll + e * l_ent;
+        out[1] = l_abs;
+        out[2] = l_nll;
+        out[3] = l_ent;
+    }
+}
+
+template <bool NLL, bool ENT>
+__global__ __launch_bounds__(256) void projected_loss_bwd_kernel(const float* __restrict__ pred, const double* __restrict__ gt, int B,
+                                                                 const float4* __restrict__ proba, const double* __restrict__ pdf,
+                                                                 int N, int D, double m, double e, const double* __restrict__ gout,
+                                                                 const int* __restrict__ arg, const int* __restrict__ nocc,
+                                                                 const int* __restrict__ pix, float4* __restrict__ dcov,
+                                                                 float4* __restrict__ dproba) {
+    const size_t R = (size_t)B * N;
+    const double g = gout[0];
+    const double cn = g * m / (double)R, ce = g * e / (2.0 * (double)R);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < R; i += (size_t)gridDim.x * 256) {
+        const float4 p = proba[i];
+        double d0 = 0.0, d2 = 0.0, d3 = 0.0;
+        if constexpr (NLL) {
+            const double f0 = pdf[3 * i], f1 = pdf[3 * i + 1], f2 = pdf[3 * i + 2];
+            const float pg = p.x + p.y;
+            const double lik = ((double)pg * f0 + (double)p.z * f1) + (double)p.w * f2;
+            const double il = -cn / lik;
+            d0 = il * f0, d2 = il * f1, d3 = il * f2;
+        }
+        if constexpr (ENT) {
+            const float h2 = -(logf(p.z + PL_EPS_F) + p.z / (p.z + PL_EPS_F) - logf(1.f - p.z + PL_EPS_F) - (1.f - p.z) / (1.f - p.z + PL_EPS_F));
+            const float h3 = -(logf(p.w + PL_EPS_F) + p.w / (p.w + PL_EPS_F) - logf(1.f - p.w + PL_EPS_F) - (1.f - p.w) / (1.f - p.w + PL_EPS_F));
+            d2 += ce * (double)h2, d3 += ce * (double)h3;
+        }
+        float4 d;
+        d.x = d.y = (float)d0;
+        d.z = (float)d2;
+        d.w = (float)d3;
+        dproba[i] = d;
+        // d loss / d coverages: the point receives its pixel's gradient iff it is the pixel's arg-max (p2_backward_kernel), with
+        // d loss / d pred of its plot recomputed here (loss_bwd_kernel's formula: column 1, bare soil, has no target)
+        const int b = (int)(i / N), n = (int)(i - (size_t)b * N);
+        const float4 pr = reinterpret_cast<const float4*>(pred)[b];
+        const double e0 = (double)pr.x - gt[4 * b + 0], e2 = (double)pr.z - gt[4 * b + 2], e3 = (double)pr.w - gt[4 * b + 3];
+        const float gx = (float)(g * e0 / sqrt(e0 * e0 + PL_EPS_D) / (3.0 * B));
+        const float gz = (float)(g * e2 / sqrt(e2 * e2 + PL_EPS_D) / (3.0 * B));
+        const float gw = (float)(g * e3 / sqrt(e3 * e3 + PL_EPS_D) / (3.0 * B));
+        const int* a = arg + ((size_t)b * D * D + pix[i]) * 3;
+        const float inv = 1.0f / fmaxf((float)nocc[b], 1.f);
+        float4 o;
+        o.x = a[0] == n ? (gx - 0.f) * inv : 0.f;      // (g.x - g.y) with g.y = 0: bare soil carries no gradient of its own
+        o.y = 0.f;
+        o.z = a[1] == n ? gz * inv : 0.f;
+        o.w = a[2] == n ? gw * inv : 0.f;
+        dcov[i] = o;
+    }
+}
+}  // namespace
+
+extern "C" int sn2_projected_loss_forward(const float* coverages, const int* pix, const float* proba, const double* pdf,
+                                          const double* gt, int B, int N, int D, double m, double e, unsigned long long* keys,
+                                          int* arg, int* nocc, float* pred, double* partials, double* out, void* stream) {
+    if (!coverages || !pix || !proba || !gt || !keys || !arg || !nocc || !pred || !partials || !out || B <= 0 || N <= 0 || D <= 0)
+        return SN2_EINVAL;
+    if (D * D > MAX_CELLS || (long)B * N >= (1L << 31)) return SN2_ELIMIT;
+    const bool nll = m != 0.0, ent = e != 0.0;
+    if (nll && !pdf) return SN2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = grid_slices(N), R = B * N;
+    int nlb = (nll || ent) ? sn2_cdiv(R, 1024) : 0;
+    if (nlb > PL_LOSS_BLOCKS) nlb = PL_LOSS_BLOCKS;
+    unsigned* ticket = reinterpret_cast<unsigned*>(partials + 2 * PL_LOSS_BLOCKS);
+    const int grid = parts * B + (nlb > 0 ? nlb : 1);              // (at least one loss workgroup: it clears the ticket)
+    const size_t lds = (size_t)D * D * 3 * 8;
+    const float4* p4 = reinterpret_cast<const float4*>(proba);
+    if (nll && ent) hipLaunchKernelGGL((projected_loss_scatter_kernel<true, true>), dim3(grid), dim3(1024), lds, st, coverages, pix, B, N, D, parts, keys, p4, pdf, nlb > 0 ? R : 0, partials, nlb > 0 ? nlb : 1, ticket);
+    else if (nll) hipLaunchKernelGGL((projected_loss_scatter_kernel<true, false>), dim3(grid), dim3(1024), lds, st, coverages, pix, B, N, D, parts, keys, p4, pdf, nlb > 0 ? R : 0, partials, nlb > 0 ? nlb : 1, ticket);
+    else if (ent) hipLaunchKernelGGL((projected_loss_scatter_kernel<false, true>), dim3(grid), dim3(1024), lds, st, coverages, pix, B, N, D, parts, keys, p4, pdf, nlb > 0 ? R : 0, partials, nlb > 0 ? nlb : 1, ticket);
+    else hipLaunchKernelGGL((projected_loss_scatter_kernel<false, false>), dim3(grid), dim3(1024), lds, st, coverages, pix, B, N, D, parts, keys, p4, pdf, 0, partials, 1, ticket);
+    hipLaunchKernelGGL(projected_loss_finalize_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long*)keys, B, D, parts, arg, nocc,
+                       pred, gt, (const double*)partials, nlb, R, m, e, ticket, out);
+    SN2_RETURN_LAUNCH();
+}
+
+extern "C" int sn2_projected_loss_backward(const float* pred, const double* gt, int B, const float* proba, const double* pdf, int N,
+                                           int D, double m, double e, const double* grad_total, const int* arg, const int* nocc,
+                                           const int* pix, float* dcoverages, float* dproba, void* stream) {
+    if (!pred || !gt || !proba || !grad_total || !arg || !nocc || !pix || !dcoverages || !dproba || B <= 0 || N <= 0 || D <= 0)
+        return SN2_EINVAL;
+    const bool nll = m != 0.0, ent = e != 0.0;
+    if (nll && !pdf) return SN2_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int grid = sn2_cdiv((long)B * N, 256);
+    if (grid > 2048) grid = 2048;
+    const float4* p4 = reinterpret_cast<const float4*>(proba);
+    float4 *dc = reinterpret_cast<float4*>(dcoverages), *dp = reinterpret_cast<float4*>(dproba);
+    if (nll && ent) hipLaunchKernelGGL((projected_loss_bwd_kernel<true, true>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, N, D, m, e, grad_total, arg, nocc, pix, dc, dp);
+    else if (nll) hipLaunchKernelGGL((projected_loss_bwd_kernel<true, false>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, N, D, m, e, grad_total, arg, nocc, pix, dc, dp);
+    else if (ent) hipLaunchKernelGGL((projected_loss_bwd_kernel<false, true>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, N, D, m, e, grad_total, arg, nocc, pix, dc, dp);
+    else hipLaunchKernelGGL((projected_loss_bwd_kernel<false, false>), dim3(grid), dim3(256), 0, st, pred, gt, B, p4, pdf, N, D, m, e, grad_total, arg, nocc, pix, dc, dp);
+    SN2_RETURN_LAUNCH();
+}
+
 extern "C" int sn2_plot_project_backward(const float* dpred, const int* arg, const int* nocc, const int* pix, int B, int N,
                                          int D, float* dpointwise, void* stream) {
     if (!dpred || !arg || !nocc || !pix || !dpointwise || B <= 0 || N <= 0 || D <= 0) return SN2_EINVAL;

@@ -1159,6 +1159,40 @@ def loss_backward(pred, gt, proba, pdf, m: float, e: float, grad_total):
     return dpred, dproba
 
 
+PROJECTED_LOSS_WS = 2 * 512 + 2      # SN2_PROJECTED_LOSS_WS
+
+
+def projected_loss_forward(cov, pix, proba, pdf, gt, B: int, N: int, diam_pix: int, m: float, e: float):
+    """include/strata_hip.h: sn2_projected_loss_forward -> (out (4,) fp64 = total, absolute, NLL, entropy; pred (B,4); arg, nocc)."""
+    R, D = B * N, int(diam_pix)
+    _chk(cov, F32, (R, 4), "coverages")
+    _chk(pix, I32, (R,), "pix")
+    _chk(proba, F32, (R, 4), "proba")
+    _chk(pdf, F64, (R, 3), "pdf")
+    _chk(gt, F64, (B, 4), "gt")
+    dev = cov.device
+    keys = torch.empty(p2_key_parts(N) * B * D * D * 3, dtype=I64, device=dev)
+    arg = torch.empty(B * D * D * 3, dtype=I32, device=dev)
+    nocc = torch.empty(B, dtype=I32, device=dev)
+    pred = torch.empty(B, 4, dtype=F32, device=dev)
+    partials = torch.empty(PROJECTED_LOSS_WS, dtype=F64, device=dev)
+    out = torch.empty(4, dtype=F64, device=dev)
+    _call("sn2_projected_loss_forward", _ptr(cov), _ptr(pix), _ptr(proba), _ptr(pdf), _ptr(gt), B, N, D, float(m), float(e), _ptr(keys),
+          _ptr(arg), _ptr(nocc), _ptr(pred), _ptr(partials), _ptr(out), _stream())
+    return out, pred, arg, nocc
+
+
+def projected_loss_backward(pred, gt, proba, pdf, B: int, N: int, diam_pix: int, m: float, e: float, grad_total, arg, nocc, pix):
+    """include/strata_hip.h: sn2_projected_loss_backward -> (d loss / d coverages, d loss / d proba), (B*N,4) each."""
+    R = B * N
+    _chk(grad_total, F64, None, "grad_total")
+    dcov = torch.empty(R, 4, dtype=F32, device=pred.device)
+    dproba = torch.empty(R, 4, dtype=F32, device=pred.device)
+    _call("sn2_projected_loss_backward", _ptr(pred), _ptr(gt), B, _ptr(proba), _ptr(pdf), N, int(diam_pix), float(m), float(e),
+          _ptr(grad_total), _ptr(arg), _ptr(nocc), _ptr(pix), _ptr(dcov), _ptr(dproba), _stream())
+    return dcov, dproba
+
+
 def adam_step_images(param, arena, replicas, stride, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale=1.0):
     """include/strata_hip.h: sn2_adam_step_images -- fold the gradient's images and take the Adam step in one launch."""
     n = param.numel()

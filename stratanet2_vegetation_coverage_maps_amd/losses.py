@@ -166,3 +166,53 @@ def total_loss(pred_coverages, proba_pointwise, gt, pdf_all, m=0.10, e=0.2 / 5):
         total, l_abs, l_log, l_e = _TotalLoss.apply(pred_coverages.float().contiguous(), proba_pointwise.float().contiguous(),
                                                     gt, pdf_all, float(m), float(e))
     return total, (l_abs, l_log, l_e)
+
+
+class _ProjectedLoss(torch.autograd.Function):
+    """`project_to_plotwise_coverages` + `total_loss` as ONE autograd node over three launches (csrc/project.hip:
+    sn2_projected_loss_forward / _backward) instead of two nodes over seven."""
+
+    @staticmethod
+    def forward(ctx, cov, proba, pix, gt, pdf, B, N, D, m, e):
+        out, pred, arg, nocc = ops.projected_loss_forward(cov, pix, proba, pdf, gt, B, N, D, m, e)
+        ctx.save_for_backward(pred, proba, gt, pdf, arg, nocc, pix)
+        ctx.dims = (B, N, D, m, e)
+        ctx.set_materialize_grads(False)
+        total, l_abs, l_log, l_e = out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(l_abs, l_log, l_e, pred)
+        return total, l_abs, l_log, l_e, pred
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        if g is None:
+            return (None,) * 10
+        pred, proba, gt, pdf, arg, nocc, pix = ctx.saved_tensors
+        B, N, D, m, e = ctx.dims
+        dcov, dproba = ops.projected_loss_backward(pred, gt, proba, pdf, B, N, D, m, e, g.to(torch.float64).contiguous(), arg, nocc, pix)
+        return (dcov, dproba) + (None,) * 8
+
+
+def projected_total_loss(coverages_pointwise, proba_pointwise, clouds, gt, pdf_all, args, geometry=None, model=None):
+    """`pred = project_to_plotwise_coverages(coverages_pointwise, clouds, args)` followed by `total_loss(pred, proba_pointwise, gt,
+    pdf_all, args.m, args.e)` (learning/train.py:54-62) -> (total, (absolute, NLL, entropy), pred).  With the pixel ids of a
+    geometry pass at hand (`geometry.p2_pix`: `model.p2_diam_pix = args.diam_pix`) the two are ONE autograd node over three
+    launches -- the scatter of the coverages beside the pointwise loss sums, the per-plot finalisation whose last workgroup adds
+    the loss up, and one backward pass that writes both gradients; same pred, same gradients (bits), the loss to fp64
+    re-association.  Without them: the two calls."""
+    from .project_to_2d import project_to_plotwise_coverages
+    pix = getattr(geometry, "p2_pix", None) if geometry is not None else None
+    B = clouds.shape[0]
+    N = clouds.shape[2]
+    ok = (pix is not None and getattr(geometry, "p2_diam_pix", None) == int(args.diam_pix) and pix.numel() == B * N and
+          coverages_pointwise.is_cuda and proba_pointwise.is_cuda)
+    if not ok:
+        pred = project_to_plotwise_coverages(coverages_pointwise, clouds, args, model=model, geometry=geometry)
+        total, parts = total_loss(pred, proba_pointwise, gt, pdf_all, args.m, args.e)
+        return total, parts, pred
+    dev = coverages_pointwise.device
+    with torch.cuda.device(dev):
+        gt = gt.to(device=dev, dtype=torch.float64).contiguous()
+        pdf_all = pdf_all.to(device=dev, dtype=torch.float64).contiguous()
+        total, l_abs, l_log, l_e, pred = _ProjectedLoss.apply(coverages_pointwise.float().contiguous(), proba_pointwise.float().contiguous(),
+                                                              pix, gt, pdf_all, B, N, int(args.diam_pix), float(args.m), float(args.e))
+    return total, (l_abs, l_log, l_e), pred

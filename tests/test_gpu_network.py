@@ -769,3 +769,48 @@ def test_per_plot_rasters_of_a_batch_come_from_one_launch_and_are_the_same_bits(
             assert calls == [N] and np.array_equal(one, want[1], equal_nan=True)
     finally:
         ops.raster_project = orig
+
+
+def test_projection_and_loss_as_one_node_is_the_two_nodes():
+    """`losses.projected_total_loss` (three launches: the scatter beside the pointwise loss sums, the finalisation whose last
+    workgroup adds the loss up, one backward pass for both gradients) against `project_to_plotwise_coverages` + `total_loss`
+    (seven): the plot-wise predictions and BOTH gradients are the same bits, the loss terms agree to fp64 re-association --
+    with all terms on, and with the NLL or the entropy switched off; a geometry handle without pixel ids falls back."""
+    B, N = 6, 10000
+    args = make_args(subsample_size=N)
+    d = make_batch(B, N, first_plot=31)
+    clouds = d["cloud"].cuda()
+    g = torch.Generator().manual_seed(3)
+    gt, pdf = d["coverages"].cuda(), d["pdf_all"].cuda()
+    from types import SimpleNamespace
+    mm, pix = ops.plot_pixels(clouds, args.diam_pix)
+    geo = SimpleNamespace(p2_pix=pix, p2_diam_pix=int(args.diam_pix))
+    for m_, e_ in ((0.1, 0.04), (0.0, 0.04), (0.1, 0.0)):
+        args.m, args.e = m_, e_
+        res = []
+        for fused in (True, False):
+            cov = torch.rand(B * N, 4, generator=g).cuda().requires_grad_(True) if not res else res[0][5].detach().clone().requires_grad_(True)
+            proba = (torch.softmax(torch.randn(B * N, 4, generator=g), 1).cuda() if not res else res[0][6].detach().clone()).requires_grad_(True)
+            if fused:
+                total, parts, pred = losses_dev().projected_total_loss(cov, proba, clouds, gt, pdf, args, geometry=geo)
+            else:
+                pred = project_to_plotwise_coverages(cov, clouds, args, geometry=geo)
+                total, parts = losses_dev().total_loss(pred, proba, gt, pdf, args.m, args.e)
+            (3.0 * total).backward()
+            res.append((total.item(), [p.item() for p in parts], pred.detach().clone(), cov.grad.clone(), proba.grad.clone(), cov, proba))
+        a, b = res
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]), (m_, e_)
+        assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(b[0]))
+        for x, y in zip(a[1], b[1]):
+            assert abs(x - y) <= 1e-12 * max(1.0, abs(y))
+    args.m, args.e = 0.1, 0.04
+    cov = torch.rand(B * N, 4, generator=g).cuda().requires_grad_(True)
+    proba = torch.softmax(torch.randn(B * N, 4, generator=g), 1).cuda()
+    total, _, pred = losses_dev().projected_total_loss(cov, proba, clouds, gt, pdf, args, geometry=None)      # no ids: the two calls
+    ref = project_to_plotwise_coverages(cov, clouds, args)
+    assert torch.equal(pred, ref)
+
+
+def losses_dev():
+    from stratanet2_vegetation_coverage_maps_amd import losses as dev_losses
+    return dev_losses
