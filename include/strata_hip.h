@@ -335,6 +335,9 @@ typedef struct sn2_head {
                                        bit j set = hidden channel j of the row is KEPT; NULL = no dropout (eval, p = 0) */
     float drop_scale;               /* 1/(1-p) applied to the kept channels (0 when p = 1)                         */
     int act_bf16;                   /* non-zero: the rows of f and dy are bfloat16 (as sn2_fp.act_bf16 of the block that wrote f) */
+    float *zero_fill; long zero_fill_words; /* sn2_head_forward only, or NULL / 0: a buffer (16-byte aligned, a multiple of 4 words)
+                                       that the forward kernel also clears -- the backward pass's zero-filled arena (sn2_net_bwd),
+                                       so that no launch of its own has to clear it in front of the backward pass */
 } sn2_head;
 int sn2_head_forward(const sn2_head *p, void *stream);
 /* EVAL only: the per-point layer (p: the 34 + 8 -> 34 block with its 3-NN table, source-side workspace p->src_ws required) and
@@ -529,6 +532,9 @@ typedef struct sn2_net_act {
     float *src_ws1, *src_ws2;            /* SN2_FP_SRC_WS_WORDS of FP1 / FP2, or NULL (sn2_fp.src_ws) */
     float *cov, *proba;                  /* OUT (B*N,4): coverages_pointwise, proba_pointwise -- set by the caller, not carved */
     const int *drop_mask;                /* sn2_head.drop_mask or NULL -- set by the caller */
+    float *bwd_arena; long bwd_arena_words; /* set by the caller or NULL / 0 (training forward): the arena of the backward pass that will
+                                            follow (sn2_net_bwd.arena, arena_words): the forward's last kernel clears it, and that
+                                            backward pass is told so (sn2_net_bwd.arena_is_zero) */
 } sn2_net_act;
 
 /* The buffers of one backward pass: `arena` (zero-filled INSIDE sn2_net_backward) = 32 images of the flat parameter gradient,
@@ -543,6 +549,8 @@ typedef struct sn2_net_bwd {
     int *bn_ok;                          /* 4 words */
     float *src_ws1, *src_ws2;
     int defer_grad_reduce;               /* set by the caller: leave the images unfolded (sn2_adam_step_images folds them) */
+    int arena_is_zero;                   /* set by the caller: the forward pass cleared `arena` (sn2_net_act.bwd_arena) and nothing has
+                                            touched it since: sn2_net_backward does not clear it again */
 } sn2_net_bwd;
 
 #define SN2_NET_FORK 1          /* geometry: level-2 chain on io.stream_b, per-point 3-NN chain on io.stream_c (needs io.ctx) */

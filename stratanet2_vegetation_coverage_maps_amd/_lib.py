@@ -45,7 +45,7 @@ class Head(Structure):  # sn2_head
                 ("coverages", c_void_p), ("proba", c_void_p), ("dcoverages", c_void_p), ("dproba", c_void_p),
                 ("dy", c_void_p), ("dW1", c_void_p), ("db1", c_void_p), ("dW2", c_void_p), ("db2", c_void_p),
                 ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("drop_mask", c_void_p), ("drop_scale", c_float),
-                ("act_bf16", c_int)]
+                ("act_bf16", c_int), ("zero_fill", c_void_p), ("zero_fill_words", c_long)]
 
 
 class NetLayer(Structure):  # sn2_net_layer
@@ -79,14 +79,14 @@ class NetGeo(Structure):  # sn2_net_geo
 class NetAct(Structure):  # sn2_net_act
     _fields_ = [(n, c_void_p) for n in (
         "aux", "stats", "ext1", "arg1", "x1", "ext2", "arg2", "x2", "h_sa3", "h3", "x3", "arg3", "h2", "h1", "src_ws1", "src_ws2",
-        "cov", "proba", "drop_mask")]
+        "cov", "proba", "drop_mask", "bwd_arena")] + [("bwd_arena_words", c_long)]
 
 
 class NetBwd(Structure):  # sn2_net_bwd
     _fields_ = [("dcov", c_void_p), ("dproba", c_void_p), ("arena", c_void_p), ("arena_words", c_long), ("images", c_int),
                 ("image_stride", c_int)] + [(n, c_void_p) for n in (
                     "dy2", "dy3", "dx1", "dx2", "dx3", "dy_sa3", "dy1", "du1", "du2", "du3", "bn_ok", "src_ws1", "src_ws2")] + [
-                        ("defer_grad_reduce", c_int)]
+                        ("defer_grad_reduce", c_int), ("arena_is_zero", c_int)]
 
 
 class NetIO(Structure):  # sn2_net_io

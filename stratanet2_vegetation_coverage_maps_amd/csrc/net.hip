@@ -530,6 +530,7 @@ extern "C" int sn2_net_forward(const sn2_net_model* m, const sn2_net_dims* d, co
         fp_desc(&p1, d, a, fp1_in(m, d, g, a, a->src_ws1), nograd);
         SN2_TRY(sn2_fp_forward(&p1, training, cur));
         head_desc(&hd, m, d, a, training);
+        if (training && a->bwd_arena && a->bwd_arena_words > 0) hd.zero_fill = a->bwd_arena, hd.zero_fill_words = a->bwd_arena_words;
         SN2_TRY(sn2_head_forward(&hd, cur));
     }
     // the chains' ends (the inverted indices: the backward pass reads them on this stream; and the side streams' last reads of
@@ -554,8 +555,10 @@ extern "C" int sn2_net_backward(const sn2_net_model* m, const sn2_net_dims* d, c
     const int B = d->B, M2 = d->M2;
     hipStream_t cur = (hipStream_t)stream;
     // one zero-filled arena: the images of the flat parameter gradient + every accumulate-into buffer of the chain
-    sn2_fill_words(b->arena, 0u, (size_t)b->arena_words, cur);
-    NET_HIP(hipGetLastError());
+    if (!b->arena_is_zero) {
+        sn2_fill_words(b->arena, 0u, (size_t)b->arena_words, cur);
+        NET_HIP(hipGetLastError());
+    }
     const GradDst gd{b->arena, b->image_stride};
     // head
     sn2_head hd;

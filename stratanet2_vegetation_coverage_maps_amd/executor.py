@@ -361,7 +361,7 @@ def geometry(model, ms, xyz, fps_start, out=None, fork=None, shared=False, defer
     return g
 
 
-def forward(model, ms, xyz, cloud, fps_start, training, geo=None, drop_keep=None):
+def forward(model, ms, xyz, cloud, fps_start, training, geo=None, drop_keep=None, need_grad=True):
     """`PointNet2._forward_impl` as one call (sn2_net_forward) -> (coverages_pointwise, proba_pointwise, NetSaved)."""
     dev = xyz.device
     B, _, N = xyz.shape
@@ -403,6 +403,12 @@ def forward(model, ms, xyz, cloud, fps_start, training, geo=None, drop_keep=None
     if drop_keep is not None:
         ops._chk(drop_keep, I32, (B * N,), "drop_mask")
         ca.drop_mask = drop_keep.data_ptr()
+    bwd_arena = None
+    if training and need_grad:
+        # the zero-filled arena of the backward pass that will follow: cleared by the forward's last kernel instead of a launch
+        # of its own in front of that pass
+        bwd_arena = torch.empty(plan.bwd_arena_words, dtype=F32, device=dev)
+        ca.bwd_arena, ca.bwd_arena_words = bwd_arena.data_ptr(), plan.bwd_arena_words
     io = _io(model, dev, training, flags, cloud=cloud, fps_start=fs, fork=fork)
     if training and model.fuse_global_level:
         ws = ops.global_level_ws(dev, owner=model)
@@ -415,6 +421,7 @@ def forward(model, ms, xyz, cloud, fps_start, training, geo=None, drop_keep=None
     s.drop_keep = drop_keep
     s.xyz = xyz
     s.ms = ms
+    s.bwd_arena = bwd_arena
     return cov, proba, s
 
 
@@ -423,7 +430,11 @@ def backward(model, s, dcov, dproba):
     plan, ms = s.plan, s.ms
     dev = s.xyz.device
     R = plan.B * plan.N
-    arena = torch.empty(plan.bwd_arena_words, dtype=F32, device=dev)        # zero-filled inside the call
+    arena = s.__dict__.get("bwd_arena")                                       # cleared by the forward pass's last kernel ...
+    s.bwd_arena = None                                                        # (once: a second backward over this forward clears its own)
+    pre_zeroed = arena is not None
+    if arena is None:
+        arena = torch.empty(plan.bwd_arena_words, dtype=F32, device=dev)    # ... or zero-filled inside the call
     scratch = torch.empty(plan.bwd_scratch_bytes, dtype=U8, device=dev)
     cb = NetBwd()
     sz, sz2 = ctypes.c_size_t(), ctypes.c_size_t()
@@ -438,6 +449,7 @@ def backward(model, s, dcov, dproba):
         cb.dproba = dproba.data_ptr()
     defer = bool(getattr(model, "defer_grad_reduce", False))
     cb.defer_grad_reduce = int(defer)
+    cb.arena_is_zero = int(pre_zeroed)
     _lib.check(lib.sn2_net_backward(byref(ms.c), byref(plan.dims), byref(geo_struct(s.geo)), byref(s.cact), byref(cb), ops._stream()),
                "sn2_net_backward")
     flat = arena[:ms.n_flat]

@@ -96,7 +96,7 @@ class _PointNet2Fn(torch.autograd.Function):
     def forward(ctx, model, xyz, cloud, fps_start, geo, drop_keep, *params):
         training = model.training
         need_grad = any(ctx.needs_input_grad[6:])   # grad mode is off inside Function.forward; this is the reliable test
-        cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training, geo, drop_keep)
+        cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training, geo, drop_keep, need_grad=need_grad)
         ctx.model = model
         saved.training = training
         ctx.saved = saved if need_grad else None
@@ -582,9 +582,9 @@ class PointNet2(nn.Module):
             raise ValueError(f"fps_start must have shape (2,{B})")
         return xyz_d, fs
 
-    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None, drop_keep=None):
+    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None, drop_keep=None, need_grad=True):
         if self._use_executor():
-            cov, proba, s = X.forward(self, self._net_model(), xyz, cloud, fps_start, training, geo, drop_keep)
+            cov, proba, s = X.forward(self, self._net_model(), xyz, cloud, fps_start, training, geo, drop_keep, need_grad=need_grad)
             if self.log_embeddings:
                 self.last_G_tensor = s.x3
             return cov, proba, s

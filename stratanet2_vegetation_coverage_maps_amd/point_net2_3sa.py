@@ -224,7 +224,7 @@ class PointNet2ThreeSA(PointNet2):
         return xyz_d, fs
 
     # ------------------------------------------------------------------------------------------ forward
-    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None, drop_keep=None):
+    def _forward_impl(self, xyz, cloud, fps_start, training, geo=None, drop_keep=None, need_grad=True):
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2, M3 = self._sizes3(N)

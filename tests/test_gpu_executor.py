@@ -311,3 +311,28 @@ def test_adam_kernel_that_folds_the_gradient_images_is_the_two_launches():
     ref = grads[(False, False)]
     for k, v in grads.items():
         assert float((v - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), k
+
+
+def test_backward_twice_over_one_forward_clears_its_own_arena():
+    """The forward pass's last kernel clears the arena of the backward pass that follows (sn2_head.zero_fill); a SECOND backward
+    over the same forward (`retain_graph=True`) must not accumulate into the used one: the gradients double exactly."""
+    B, N = 2, 4096
+    args = make_args(subsample_size=N, ratio1=0.25, r1=1.0, ratio2=0.25, r2=2.0)
+    d = make_batch(B, N, first_plot=2)
+    d["fps_start"] = torch.zeros(2, B, dtype=torch.int64)
+    m = _model(args, network.init_state_dict(1), True).train()
+    cov, proba = m(d)
+    saved = cov.grad_fn.saved
+    assert saved.bwd_arena is not None
+    loss = cov.square().sum() + proba[:, 2].sum()
+    loss.backward(retain_graph=True)
+    torch.cuda.synchronize()
+    assert saved.bwd_arena is None
+    g1 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    # (the per-call path releases what it saved after one backward; the executor's saved state stays valid: keep it for this)
+    cov.grad_fn.saved = saved
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        scale = max(float(g1[k].abs().max()), 1e-12)
+        assert float((p.grad - 2.0 * g1[k]).abs().max()) <= 2e-5 * scale, k
