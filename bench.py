@@ -705,7 +705,8 @@ def dropin_predict_leg(dev, plots=512, points=10000, batch=20, repeat=3):
     inference/predict_utils.py:94-102): `model.eval()`, no `torch.no_grad()` (the reference has none), CPU-resident batches of
     `args.batch_size` = 20 plots (config.py:85) x `subsample_size` = 10 000 points as its DataLoader collates them,
     `model(cloud_data)`, `get_batch_format`, then PER PLOT `project_to_2d_rasters(clouds[idx], coverages_pointwise[idx], args)`,
-    which returns a numpy array (one device-to-host read per plot, project_to_2d.py:78-113).  The GIS steps behind it (weights
+    which returns a numpy array (project_to_2d.py:78-113; the drop-in answers a batch's per-plot calls from ONE batched launch
+    and ONE device-to-host read, made at the first of them: both arguments are views of the batch's tensors).  The GIS steps behind it (weights
     band, geotransform, GeoTIFF file: GDAL / rasterio) are out of scope and not run.  `config4_parcel_inference` is the same work
     through `inference.predict_parcel` (512 plots per launch, rasters and mosaic on the device)."""
     args = make_args(cuda=dev.index or 0, subsample_size=points)           # reference defaults: ratios .25/.25, r sqrt2/sqrt8
@@ -743,8 +744,8 @@ def dropin_predict_leg(dev, plots=512, points=10000, batch=20, repeat=3):
             "runs_s": [round(t, 4) for t in times], "statistic": f"median of {repeat} passes over {n} plots",
             "last_raster_finite_pixels": int(np.isfinite(rasters).sum()),
             "what": f"predict.py:96-126 as written: eval mode, autograd on, {batch} plots x {points} pts per batch from HOST tensors, "
-                    "model(cloud_data), get_batch_format, project_to_2d_rasters per plot (numpy out, one D2H read per plot); "
-                    "GIS file output not run"}
+                    "model(cloud_data), get_batch_format, project_to_2d_rasters per plot (numpy out; one launch + one D2H read per BATCH, "
+                    "made at the batch's first call); GIS file output not run"}
 
 
 def secondary_legs(dev):

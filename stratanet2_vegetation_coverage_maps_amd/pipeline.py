@@ -267,9 +267,10 @@ class TrainPipeline:
 
     def drain(self, check: bool = False):
         """Make the main stream wait for every geometry pass in flight.  check=True (where the caller synchronises with the
-        device anyway): also read the FPS status word and warn when passes had to be repeated (hip_ops.fps_gave_up)."""
+        device anyway): also read the FPS status word and the fused global level's give-up count and warn when passes had to be repeated
+        (hip_ops.fps_gave_up, hip_ops.global_level_gave_up: the results are right either way)."""
         for st in self.side:
             torch.cuda.current_stream(self.dev).wait_stream(st)
         if check:
             ops.fps_gave_up(self.dev)
-            ops.global_level_gave_up(self.dev)      # (raises: the fused global level's statistics exchange gave up)
+            ops.global_level_gave_up(self.dev)      # (warns once per growth: launches of the fused global level were repaired)
