@@ -134,6 +134,8 @@ int sn2_ball_query(const float *src_soa, int B, int N, const float *cpos_soa, in
 /* total = sum of cnt[0..n): the number of messages of a set of neighbour lists (what sn2_ball_query leaves in `total` for
  * the lists of one call; needed again when the lists of one call are handed on in parts). */
 int sn2_count_sum(const int *cnt, int n, unsigned long long *total, void *stream);
+/* the same for G consecutive lists of n counts each in one launch: total[h * total_stride] = sum of cnt[h*n .. (h+1)*n) */
+int sn2_count_sum_group(const int *cnt, int G, int n, unsigned long long *total, size_t total_stride, void *stream);
 
 /* k nearest sources (k = 1..3) + inverse squared distance weights -- the no_grad part of
  * torch_geometric.nn.knn_interpolate, model/point_net2.py:63.
@@ -211,6 +213,9 @@ typedef struct sn2_sa {
 #define SN2_SA_PACKED_ITEMS(M) ((M) / 8 + 2)
 #define SN2_SA_ORDER_WORDS(B, M) ((size_t)4 * (B) * (M) + (size_t)16 * (B) * SN2_SA_PACKED_ITEMS(M) + 8)
 int sn2_sa_order(const int *cnt, int B, int M, int *order, void *stream);
+/* G consecutive batches of B plots each in one launch pair: cnt (G*B*M), batch h's work items at order + h * stride_words
+ * (stride_words >= SN2_SA_ORDER_WORDS(B,M)): what a geometry pass over several batches of a pipelined loop calls */
+int sn2_sa_order_group(const int *cnt, int G, int B, int M, int *order, size_t stride_words, void *stream);
 int sn2_sa_forward(const sn2_sa *p, int training, void *stream);
 int sn2_sa_backward(const sn2_sa *p, void *stream);
 
@@ -272,6 +277,12 @@ int sn2_interp_index(const int *knn_idx, const float *knn_w, const float *src_po
 /* the same index over PERMUTED target rows: list entries name row_perm[b*R + r] instead of r (sn2_fp.row_perm; NULL = identity) */
 int sn2_interp_index_perm(const int *knn_idx, const float *knn_w, const float *src_pos, const int *row_perm, int B,
                           int R_per_plot, int S_per_plot, float *ws, void *stream);
+/* the same for G consecutive batches of B plots each in ONE set of launches (round 5): knn_idx / knn_w / src_pos / row_perm are the
+ * group's arrays (G*B plots, batch-major), batch h's index is written to ws + h * ws_stride_words (an ordinary B-plot workspace:
+ * its consumers do not change; ws_stride_words >= SN2_INTERP_WS_WORDS(B,R,S), a multiple of 4).  The geometry pass of a
+ * pipelined loop covers several batches per launch: 12 launches per pass instead of 12 per batch. */
+int sn2_interp_index_group(const int *knn_idx, const float *knn_w, const float *src_pos, const int *row_perm, int G, int B,
+                           int R_per_plot, int S_per_plot, float *ws, size_t ws_stride_words, void *stream);
 int sn2_fp_forward(const sn2_fp *p, int training, void *stream);
 int sn2_fp_backward(const sn2_fp *p, void *stream);
 

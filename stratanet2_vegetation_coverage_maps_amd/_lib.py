@@ -116,17 +116,20 @@ SIGNATURES = {
                        c_void_p],
     "sn2_three_nn": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_count_sum": [c_void_p, c_int, c_void_p, c_void_p],
+    "sn2_count_sum_group": [c_void_p, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "sn2_three_nn_xy": [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "sn2_prepare_plots": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p],
     "sn2_znorm": [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                   c_void_p, c_void_p],
     "sn2_sa_order": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "sn2_sa_order_group": [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "sn2_sa_forward": [POINTER(SA), c_int, c_void_p],
     "sn2_sa_backward": [POINTER(SA), c_void_p],
     "sn2_grad_reduce": [c_void_p, c_int, c_int, c_int, c_void_p],
     "sn2_interp_index": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "sn2_interp_index_perm": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sn2_interp_index_group": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "sn2_fp_forward": [POINTER(FP), c_int, c_void_p],
     "sn2_fp_backward": [POINTER(FP), c_void_p],
     "sn2_plot_max_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],

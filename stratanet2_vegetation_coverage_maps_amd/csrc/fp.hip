@@ -332,15 +332,43 @@ __global__ __launch_bounds__(WAVES * 64) void fp_bwd_main_kernel(
 // atomics onto random rows are worse), and dsrc is written exactly once per row.
 constexpr int INV_SLICE_ROWS = 2048;
 
+// The workspace of ONE batch's inverted index (SN2_INTERP_WS_WORDS(B, Rp, S) 32-bit words), carved the same way on the host
+// (carve_interp_index below) and inside the kernels that build it:
+//   H [B*SL*S] | off [B*S] | cnt [B*S] | inv_row [3*B*Rp] | inv_w [3*B*Rp] | (16-byte aligned) items [B*S] int4 | chunks [B*CM] int4
+// GROUPED builds (round 5: sn2_interp_index_group): one launch covers G consecutive batches of B plots each -- plot bg of the
+// launch is plot bg % B of batch bg / B, whose workspace starts ws_stride words behind the previous batch's -- so that the
+// position-only pass of a pipelined loop, which samples eight batches in one FPS launch, builds their inverted indices in 12
+// launches instead of 96.  Every batch's workspace is an ordinary B-plot workspace: its consumers do not change.
+struct InvWs {
+    int *H, *off, *cnt, *inv_row;
+    float* inv_w;
+    int4 *items, *chunks;
+};
+__host__ __device__ __forceinline__ InvWs inv_ws_of(float* ws, int B, int Rp, int S) {
+    const int SL = (Rp + INV_SLICE_ROWS - 1) / INV_SLICE_ROWS;
+    InvWs x;
+    x.H = reinterpret_cast<int*>(ws);
+    x.off = x.H + (size_t)B * SL * S;
+    x.cnt = x.off + (size_t)B * S;
+    x.inv_row = x.cnt + (size_t)B * S;
+    x.inv_w = reinterpret_cast<float*>(x.inv_row + (size_t)3 * B * Rp);
+    x.items = reinterpret_cast<int4*>((reinterpret_cast<uintptr_t>(x.inv_w + (size_t)3 * B * Rp) + 15) & ~(uintptr_t)15);
+    x.chunks = x.items + (size_t)B * S;
+    return x;
+}
+
 __global__ __launch_bounds__(1024) void inv_hist_kernel(int R_per_plot, int S, const int* __restrict__ knn_idx,
-                                                        const float* __restrict__ knn_w, int* __restrict__ H) {
+                                                        const float* __restrict__ knn_w, float* __restrict__ ws, int Bb,
+                                                        size_t ws_stride) {
     extern __shared__ int s_hist[];
-    const int b = blockIdx.y, sl = blockIdx.x, SL = gridDim.x;
+    const int bg = blockIdx.y, sl = blockIdx.x, SL = gridDim.x;
+    const int hb = bg / Bb, b = bg - hb * Bb;                    // batch of the group, plot of the batch
+    int* H = inv_ws_of(ws + (size_t)hb * ws_stride, Bb, R_per_plot, S).H;
     for (int i = threadIdx.x; i < S; i += 1024) s_hist[i] = 0;
     __syncthreads();
     const int r_lo = sl * INV_SLICE_ROWS, r_hi = min(R_per_plot, r_lo + INV_SLICE_ROWS);
     for (int rl = r_lo + threadIdx.x; rl < r_hi; rl += 1024) {
-        const size_t r = (size_t)b * R_per_plot + rl;
+        const size_t r = (size_t)bg * R_per_plot + rl;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (j == 0 || knn_w[r * 3 + j] != 0.f) atomicAdd(&s_hist[knn_idx[r * 3 + j]], 1);
@@ -352,11 +380,16 @@ __global__ __launch_bounds__(1024) void inv_hist_kernel(int R_per_plot, int S, c
 
 // H[plot][slice][s] -> exclusive prefix over slices (in place);  off[plot*S + s] = plot*3*R + exclusive scan of the totals;
 // cnt[plot*S + s] = total
-__global__ __launch_bounds__(1024) void inv_scan_kernel(int R_per_plot, int S, int SL, int* __restrict__ H,
-                                                        int* __restrict__ off, int* __restrict__ cnt) {
+__global__ __launch_bounds__(1024) void inv_scan_kernel(int R_per_plot, int S, int SL, float* __restrict__ ws, int Bb,
+                                                        size_t ws_stride) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hb = bg / Bb, b = bg - hb * Bb;
+    const InvWs x = inv_ws_of(ws + (size_t)hb * ws_stride, Bb, R_per_plot, S);
+    int* __restrict__ H = x.H;
+    int* __restrict__ off = x.off;
+    int* __restrict__ cnt = x.cnt;
     if (threadIdx.x == 0) s_carry = b * 3 * R_per_plot;
     __syncthreads();
     for (int s0 = 0; s0 < S; s0 += 1024) {
@@ -389,17 +422,22 @@ __global__ __launch_bounds__(1024) void inv_scan_kernel(int R_per_plot, int S, i
 }
 
 __global__ __launch_bounds__(1024) void inv_fill_kernel(int R_per_plot, int S, const int* __restrict__ knn_idx,
-                                                        const float* __restrict__ knn_w, const int* __restrict__ H,
-                                                        const int* __restrict__ off, int* __restrict__ inv_row,
-                                                        float* __restrict__ inv_w, const int* __restrict__ row_perm) {
+                                                        const float* __restrict__ knn_w, float* __restrict__ ws, int Bb,
+                                                        size_t ws_stride, const int* __restrict__ row_perm) {
     extern __shared__ int s_cur[];
-    const int b = blockIdx.y, sl = blockIdx.x, SL = gridDim.x;
+    const int bg = blockIdx.y, sl = blockIdx.x, SL = gridDim.x;
+    const int hb = bg / Bb, b = bg - hb * Bb;
+    const InvWs x = inv_ws_of(ws + (size_t)hb * ws_stride, Bb, R_per_plot, S);
+    const int* __restrict__ H = x.H;
+    const int* __restrict__ off = x.off;
+    int* __restrict__ inv_row = x.inv_row;
+    float* __restrict__ inv_w = x.inv_w;
     const int* hp = H + ((size_t)b * SL + sl) * S;
     for (int i = threadIdx.x; i < S; i += 1024) s_cur[i] = off[(size_t)b * S + i] + hp[i];
     __syncthreads();
     const int r_lo = sl * INV_SLICE_ROWS, r_hi = min(R_per_plot, r_lo + INV_SLICE_ROWS);
     for (int rl = r_lo + threadIdx.x; rl < r_hi; rl += 1024) {
-        const size_t r = (size_t)b * R_per_plot + rl;
+        const size_t r = (size_t)bg * R_per_plot + rl;
         const float w0 = knn_w[r * 3 + 0], w1 = knn_w[r * 3 + 1], w2 = knn_w[r * 3 + 2];
         const float inv = 1.0f / ((w0 + w1) + w2);
         const float w[3] = {w0, w1, w2};
@@ -434,15 +472,20 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {
 constexpr int INV_CHUNK = 63;
 __host__ __device__ constexpr int inv_chunks_per_plot(int Rp, int S) { return (3 * Rp + INV_CHUNK - 1) / INV_CHUNK + S; }
 
-__global__ __launch_bounds__(1024) void inv_order_kernel(const float4* __restrict__ pos, int S, int CM, const int* __restrict__ off,
-                                                         const int* __restrict__ cnt, int4* __restrict__ items,
-                                                         int4* __restrict__ chunks) {
+__global__ __launch_bounds__(1024) void inv_order_kernel(const float4* __restrict__ pos, int S, int CM, int R_per_plot,
+                                                         float* __restrict__ ws, int Bb, size_t ws_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_key[];   // [S rounded up to 4] keys | [S] source of every rank
     __shared__ float s_lo[3][16], s_hi[3][16];
     __shared__ int s_w[16];
     __shared__ int s_carry;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float4* pb = pos + (size_t)b * S;
+    const int bg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hb = bg / Bb, b = bg - hb * Bb;
+    const InvWs x = inv_ws_of(ws + (size_t)hb * ws_stride, Bb, R_per_plot, S);
+    const int* __restrict__ off = x.off;
+    const int* __restrict__ cnt = x.cnt;
+    int4* __restrict__ items = x.items;
+    int4* __restrict__ chunks = x.chunks;
+    const float4* pb = pos + (size_t)bg * S;
     const int S4 = (S + 3) & ~3;
     int* s_ord = reinterpret_cast<int*>(s_key + S4);
     if (pos) {
@@ -2183,23 +2226,26 @@ InterpIndex carve_interp_index(float* ws, int B, int Rp, int S) {
     x.CM = inv_chunks_per_plot(Rp, S);
     return x;
 }
+// G batches of B plots each in one set of launches (G = 1: one batch); batch h's workspace at ws + h * ws_stride words
 int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_pos, int B, int Rp, int S, float* ws,
-                       hipStream_t st, const int* row_perm = nullptr) {
+                       hipStream_t st, const int* row_perm = nullptr, int G = 1, size_t ws_stride = 0) {
     if (S > 8192) return SN2_ELIMIT;
+    if (G < 1 || (G > 1 && (ws_stride & 3))) return SN2_EINVAL;           // (every batch's workspace 16-byte aligned)
     const int SL = sn2_cdiv(Rp, INV_SLICE_ROWS);
-    const InterpIndex x = carve_interp_index(ws, B, Rp, S);
-    hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, x.H);
-    hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(1024), 0, st, Rp, S, SL, x.H, x.off, x.cnt);
-    hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, (const int*)x.H,
-                       (const int*)x.off, x.inv_row, x.inv_w, row_perm);
+    const int CM = inv_chunks_per_plot(Rp, S);
+    if ((long)G * B >= 65535) return SN2_ELIMIT;                           // grid.y
+    hipLaunchKernelGGL(inv_hist_kernel, dim3(SL, G * B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, ws, B, ws_stride);
+    hipLaunchKernelGGL(inv_scan_kernel, dim3(G * B), dim3(1024), 0, st, Rp, S, SL, ws, B, ws_stride);
+    hipLaunchKernelGGL(inv_fill_kernel, dim3(SL, G * B), dim3(1024), (size_t)S * 4, st, Rp, S, knn_idx, knn_w, ws, B, ws_stride,
+                       row_perm);
     // keys + the source of every rank: 64 KB of dynamic LDS at the S = 8192 limit (+ ~450 B static): above the 48 KB a kernel
     // gets without asking
     const size_t order_lds = (size_t)(((S + 3) & ~3) + S) * 4;
     if (order_lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)order_lds);
-    hipLaunchKernelGGL(inv_order_kernel, dim3(B), dim3(1024), order_lds, st,
-                       reinterpret_cast<const float4*>(src_pos), S, x.CM, (const int*)x.off, (const int*)x.cnt, x.items, x.chunks);
+    hipLaunchKernelGGL(inv_order_kernel, dim3(G * B), dim3(1024), order_lds, st, reinterpret_cast<const float4*>(src_pos), S, CM, Rp,
+                       ws, B, ws_stride);
     SN2_RETURN_LAUNCH();
 }
 
@@ -2379,6 +2425,13 @@ extern "C" int sn2_interp_index_perm(const int* knn_idx, const float* knn_w, con
                                      int R_per_plot, int S_per_plot, float* ws, void* stream) {
     if (!knn_idx || !knn_w || !ws || B <= 0 || R_per_plot <= 0 || S_per_plot <= 0) return SN2_EINVAL;
     return build_interp_index(knn_idx, knn_w, src_pos, B, R_per_plot, S_per_plot, ws, (hipStream_t)stream, row_perm);
+}
+
+extern "C" int sn2_interp_index_group(const int* knn_idx, const float* knn_w, const float* src_pos, const int* row_perm, int G, int B,
+                                      int R_per_plot, int S_per_plot, float* ws, size_t ws_stride_words, void* stream) {
+    if (!knn_idx || !knn_w || !ws || G <= 0 || B <= 0 || R_per_plot <= 0 || S_per_plot <= 0) return SN2_EINVAL;
+    if (G > 1 && ws_stride_words < SN2_INTERP_WS_WORDS(B, R_per_plot, S_per_plot)) return SN2_EINVAL;
+    return build_interp_index(knn_idx, knn_w, src_pos, B, R_per_plot, S_per_plot, ws, (hipStream_t)stream, row_perm, G, ws_stride_words);
 }
 
 extern "C" int sn2_fp_forward(const sn2_fp* p, int training, void* stream) {

@@ -128,12 +128,16 @@ int backward_t(const sn2_sa* p, hipStream_t st) {
 //   then the trailer: [0] = max_b(SOLO + QUAD items of plot b), [1] = max_b(OCT + HEX items of plot b).
 // ------------------------------------------------------------------------------------------------------------
 namespace {
+// (grouped launches, round 5: plot bg of the launch is plot bg % B of batch bg / B, whose table starts `stride` ints behind the
+// previous batch's -- sn2_sa_order_group)
 __global__ __launch_bounds__(1024) void sa_order_sort_kernel(const int* __restrict__ cnt, int B, int M, int P2,
-                                                             int* __restrict__ order) {
+                                                             int* __restrict__ order_all, size_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_key[];       // [P2]
     __shared__ int s_n[3];                                                  // centroids of the classes SOLO, QUAD, OCT
-    const int b = blockIdx.x, tid = threadIdx.x, NT = (int)blockDim.x;     // 1024 threads, or 256 when there are many plots
-    const int* cb = cnt + (size_t)b * M;
+    const int bg = blockIdx.x, tid = threadIdx.x, NT = (int)blockDim.x;    // 1024 threads, or 256 when there are many plots
+    const int hb = bg / B, b = bg - hb * B;
+    int* __restrict__ order = order_all + (size_t)hb * stride;
+    const int* cb = cnt + (size_t)bg * M;
     if (tid < 3) s_n[tid] = 0;
     __syncthreads();
     int n_here[3] = {0, 0, 0};
@@ -195,11 +199,19 @@ __global__ __launch_bounds__(1024) void sa_order_sort_kernel(const int* __restri
 }
 }  // namespace
 
+static int sa_order_impl(const int* cnt, int G, int B, int M, int* order, size_t stride, hipStream_t st);
 extern "C" int sn2_sa_order(const int* cnt, int B, int M, int* order, void* stream) {
     if (!cnt || !order || B <= 0 || M <= 0) return SN2_EINVAL;
+    return sa_order_impl(cnt, 1, B, M, order, SN2_SA_ORDER_WORDS(B, M), (hipStream_t)stream);
+}
+// G consecutive batches of B plots each in one launch pair: cnt (G*B*M), batch h's table at order + h * stride_words
+extern "C" int sn2_sa_order_group(const int* cnt, int G, int B, int M, int* order, size_t stride_words, void* stream) {
+    if (!cnt || !order || G <= 0 || B <= 0 || M <= 0 || stride_words < SN2_SA_ORDER_WORDS(B, M)) return SN2_EINVAL;
+    return sa_order_impl(cnt, G, B, M, order, stride_words, (hipStream_t)stream);
+}
+static int sa_order_impl(const int* cnt, int G, int B, int M, int* order, size_t stride, hipStream_t st) {
     if (M > 16384) return SN2_ELIMIT;                     // the plot's keys must fit LDS (and 14 bits)
-    hipStream_t st = (hipStream_t)stream;
-    sn2_fill_words(order, 0xFFFFFFFFu, (size_t)SN2_SA_ORDER_WORDS(B, M), st);                                      // all -1
+    sn2_fill_words(order, 0xFFFFFFFFu, (size_t)(G - 1) * stride + (size_t)SN2_SA_ORDER_WORDS(B, M), st);         // all -1
     int P2 = 2;
     while (P2 < M) P2 <<= 1;
     if ((size_t)P2 * 4 > 48 * 1024)
@@ -208,7 +220,8 @@ extern "C" int sn2_sa_order(const int* cnt, int B, int M, int* order, void* stre
     // one workgroup per plot.  With hundreds of plots (the parcel loop) a 1024-thread workgroup waits for a CU with sixteen free
     // wave slots while the four-wave workgroups of concurrent kernels keep taking every slot that frees up (0.27 ms instead of
     // 0.03 for 256 plots of 2500 centroids): many plots -> 256 threads each
-    hipLaunchKernelGGL(sa_order_sort_kernel, dim3(B), dim3(sn2_small_sort_wg(B) ? 256 : 1024), (size_t)P2 * 4, st, cnt, B, M, P2, order);
+    hipLaunchKernelGGL(sa_order_sort_kernel, dim3(G * B), dim3(sn2_small_sort_wg(B) ? 256 : 1024), (size_t)P2 * 4, st, cnt, B, M, P2,
+                       order, stride);
     SN2_RETURN_LAUNCH();
 }
 

@@ -439,6 +439,15 @@ def count_sum(cnt: torch.Tensor, total: torch.Tensor):
     _call("sn2_count_sum", _ptr(cnt), cnt.numel(), _ptr(total), _stream())
 
 
+def count_sum_group(cnt: torch.Tensor, G: int, n: int, totals: torch.Tensor, stride: int):
+    """include/strata_hip.h: sn2_count_sum_group -- totals[h * stride] = sum of cnt[h*n : (h+1)*n], h < G, in one launch."""
+    _chk(cnt, I32, (G * n,), "cnt")
+    _chk(totals, I64, None, "totals")
+    if totals.numel() < (G - 1) * stride + 1:
+        raise ValueError("count_sum_group: totals too small")
+    _call("sn2_count_sum_group", _ptr(cnt), G, n, _ptr(totals), stride, _stream(), key="sn2_count_sum")
+
+
 def three_nn_ws_words(B: int, S: int, T: int = 0) -> int:
     """SN2_THREE_NN_XY_WS_WORDS (T > 0) / SN2_THREE_NN_WS_WORDS (T = 0) of include/strata_hip.h."""
     return B * (4 * S + 5 * T + 1032)
@@ -611,6 +620,16 @@ def sa_order(cnt: torch.Tensor, B: int, M: int, out: Optional[torch.Tensor] = No
     return out
 
 
+def sa_order_group(cnt: torch.Tensor, G: int, B: int, M: int, out_all: torch.Tensor, stride: int):
+    """include/strata_hip.h: sn2_sa_order_group -- the work items of G consecutive batches of B plots in one launch pair; batch h's
+    table = out_all[h * stride : h * stride + sa_order_len(B, M)]."""
+    _chk(cnt, I32, (G * B * M,), "cnt")
+    if stride < sa_order_len(B, M):
+        raise ValueError("sa_order_group: stride smaller than a table")
+    _chk(out_all, I32, (G * stride,), "out order tables")
+    _call("sn2_sa_order_group", _ptr(cnt), G, B, M, _ptr(out_all), stride, _stream(), key="sn2_sa_order")
+
+
 def sa_desc(blocks, feat, cf, spos, cpos_aos, nbr, cnt, total, B, Nsrc, M, ext, arg, out, dout=None, dfeat=None,
             with_grads=False, order=None) -> SA:
     """feat: (B*Nsrc, >=cf) row view; spos: (B*Nsrc, >=4) row view holding x,y,z,."""
@@ -684,6 +703,24 @@ def interp_index(knn, B: int, R_per_plot: int, S_per_plot: int, out: Optional[to
     _call("sn2_interp_index_perm", _ptr(knn[0]), _ptr(knn[1]), _ptr(src_pos), _ptr(row_perm), B, R_per_plot, S_per_plot, _ptr(out),
           _stream(), key="sn2_interp_index")
     return out
+
+
+def interp_index_group(knn, G: int, B: int, R_per_plot: int, S_per_plot: int, out_all: torch.Tensor, stride: int,
+                       src_pos: Optional[torch.Tensor] = None, row_perm: Optional[torch.Tensor] = None):
+    """include/strata_hip.h: sn2_interp_index_group -- the inverted indices of G consecutive batches of B plots in ONE set of four
+    launches; knn / src_pos / row_perm: the group's arrays; batch h's index = out_all[h * stride : h * stride + interp_ws_words(...)]."""
+    R = G * B * R_per_plot
+    _chk(knn[0], I32, (R, 3), "knn_idx")
+    _chk(knn[1], F32, (R, 3), "knn_w")
+    if src_pos is not None:
+        _chk(src_pos, F32, (G * B * S_per_plot, 4), "src_pos")
+    if row_perm is not None:
+        _chk(row_perm, I32, (R,), "row_perm")
+    if stride % 4 or stride < interp_ws_words(B, R_per_plot, S_per_plot):
+        raise ValueError("interp_index_group: stride must be a multiple of 4 words and hold one index")
+    _chk(out_all, F32, (G * stride,), "out indices")
+    _call("sn2_interp_index_group", _ptr(knn[0]), _ptr(knn[1]), _ptr(src_pos), _ptr(row_perm), G, B, R_per_plot, S_per_plot, _ptr(out_all),
+          stride, _stream(), key="sn2_interp_index")
 
 
 SOURCE_SIDE = True     # False: never hand out src_ws, i.e. every row rebuilds its interpolated input (tests compare both)

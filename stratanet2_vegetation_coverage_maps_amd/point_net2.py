@@ -481,6 +481,19 @@ class PointNet2(nn.Module):
         M1, M2 = self._sizes(N)
         gp = self.alloc_geometry(group * B, N, dev)
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
+        # the per-batch products -- message totals, SA work items, inverted 3-NN indices -- of all `group` batches live in ONE
+        # strided buffer each, so that the pass builds them with one (set of) launch(es) per kind instead of one per batch
+        # (hip_ops.*_group; round 5: 18 small launches per pass of eight batches instead of 144); a batch's slice is an ordinary
+        # per-batch table
+        up4 = lambda n: (n + 3) // 4 * 4          # noqa: E731
+        so1, so2 = ops.sa_order_len(B, M1), ops.sa_order_len(B, M2)
+        si = [up4(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1))]
+        grp = _Saved()
+        grp.G, grp.so1, grp.so2, grp.si = group, so1, so2, si
+        grp.ord1, grp.ord2 = e(group * so1, dt=I32), e(group * so2, dt=I32)
+        grp.inv = [e(group * w) for w in si]
+        grp.totals = torch.zeros(group, 2, dtype=I64, device=dev)
+        gp._grp = grp
         halves = []
         for h in range(group):
             g = _Saved()
@@ -492,10 +505,11 @@ class PointNet2(nn.Module):
             g.knn3 = (gp.knn3[0][r2], gp.knn3[1][r2])
             g.knn2 = (gp.knn2[0][r1], gp.knn2[1][r1])
             g.knn1 = (gp.knn1[0][rn], gp.knn1[1][rn])
-            g.totals = torch.zeros(2, dtype=I64, device=dev)
-            g.tot1, g.tot2 = g.totals[0:1], g.totals[1:2]
-            g.ord1, g.ord2 = e(ops.sa_order_len(B, M1), dt=I32), e(ops.sa_order_len(B, M2), dt=I32)
-            g.inv3, g.inv2, g.inv1 = (e(ops.interp_ws_words(B, R, S)) for R, S in ((M2, 1), (M1, M2), (N, M1)))
+            g.totals = grp.totals[h]
+            g.tot1, g.tot2 = grp.totals[h, 0:1], grp.totals[h, 1:2]
+            g.ord1, g.ord2 = grp.ord1[h * so1:(h + 1) * so1], grp.ord2[h * so2:(h + 1) * so2]
+            g.inv3, g.inv2, g.inv1 = (grp.inv[k][h * si[k]:h * si[k] + ops.interp_ws_words(B, R, S)]
+                                      for k, (R, S) in enumerate(((M2, 1), (M1, M2), (N, M1))))
             g.ws1 = g.ws2 = g.nn_ws = None
             g.rank1 = gp.rank1[rn] if (gp.rank1 is not None and self._fp1_source_side(B * N)) else None
             self._alloc_input_only(g, B, N, dev)
@@ -522,18 +536,22 @@ class PointNet2(nn.Module):
         ops.three_nn(gp.pos3, gp.pos2_soa, 1, out=gp.knn3)
         ops.three_nn(gp.pos2_soa, gp.pos1_soa, 3, out=gp.knn2, ws=gp.nn_ws[0])
         ops.three_nn(gp.pos1_soa, xyz2, 3, out=gp.knn1, ws=gp.nn_ws[1])
+        grp, G = gp._grp, len(halves)
+        tot_flat = grp.totals.view(-1)                       # (G,2): [h][0] = level-1 messages of batch h, [h][1] = level-2
+        ops.count_sum_group(gp.cnt1, G, B * M1, tot_flat, 2)
+        ops.count_sum_group(gp.cnt2, G, B * M2, tot_flat[1:], 2)
+        ops.sa_order_group(gp.cnt1, G, B, M1, grp.ord1, grp.so1)
+        ops.sa_order_group(gp.cnt2, G, B, M2, grp.ord2, grp.so2)
+        ops.interp_index_group(gp.knn3, G, B, M2, 1, grp.inv[0], grp.si[0])
+        ops.interp_index_group(gp.knn2, G, B, M1, M2, grp.inv[1], grp.si[1])
+        rank = gp.rank1 if halves[0].rank1 is not None else None
+        ops.interp_index_group(gp.knn1, G, B, N, M1, grp.inv[2], grp.si[2], src_pos=gp.pos1_aos, row_perm=rank)
         for h, g in enumerate(halves):
             g.xyz = xyz2[h * B:(h + 1) * B]
             g.has_rows0 = False
+            g.has_inverted = True
             if clouds is not None:
                 self._input_only(g, clouds[h], g.xyz)
-            ops.count_sum(g.cnt1, g.tot1)
-            ops.count_sum(g.cnt2, g.tot2)
-            ops.sa_order(g.cnt1, B, M1, out=g.ord1)
-            ops.sa_order(g.cnt2, B, M2, out=g.ord2)
-            ops.interp_index(g.knn3, B, M2, 1, out=g.inv3)
-            ops.interp_index(g.knn2, B, M1, M2, out=g.inv2)
-            ops.interp_index(g.knn1, B, N, M1, out=g.inv1, src_pos=g.pos1_aos, row_perm=g.rank1)
         return halves
 
     def prefetch_geometry(self, cloud_data, lane: int = 0):
