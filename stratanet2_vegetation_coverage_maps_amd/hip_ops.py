@@ -421,7 +421,9 @@ def ball_query(src_soa: torch.Tensor, cpos_soa: torch.Tensor, r: float, cap: int
     else:
         nbr = torch.empty(B * M, cap, dtype=I32, device=dev)
         cnt = torch.empty(B * M, dtype=I32, device=dev)
-    if total is None:
+    if total is False:
+        total = None                          # no message total wanted (a grouped pass sums the counts per batch: count_sum_group)
+    elif total is None:
         total = torch.zeros(1, dtype=I64, device=dev)
     else:
         _chk(total, I64, (1,), "total")

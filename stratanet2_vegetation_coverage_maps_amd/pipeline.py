@@ -73,6 +73,25 @@ class TrainPipeline:
                     self.geo[G * pb + h] = parts[h]
                 self.xyz2.append(torch.empty(G * B, 3, N, dtype=slot_inputs[0]["xyz"].dtype, device=dev))
                 self.fs2.append(torch.zeros(slot_inputs[0]["fps_start"].shape[0], G * B, dtype=torch.int32, device=dev))
+            # The positions (and, where the slots carry them, the clouds) of the G batches of a pass live in ONE tensor per pass
+            # group, and the slots' entries are VIEWS of it (round 5): the pass reads the group's tensor directly -- no G + G
+            # device-to-device copies in front of every pass -- and its input-only pieces run once over the whole group.
+            self.cloud2 = []
+            self._fs_synced = [False] * (self.slots // G)
+            has_cloud = all("cloud" in d for d in slot_inputs)
+            for pb in range(self.slots // G):
+                c2 = None
+                if has_cloud:
+                    c0 = slot_inputs[G * pb]["cloud"]
+                    c2 = torch.empty((G * B,) + tuple(c0.shape[1:]), dtype=c0.dtype, device=dev)
+                for h in range(G):
+                    d = slot_inputs[G * pb + h]
+                    self.xyz2[pb][h * B:(h + 1) * B].copy_(d["xyz"])
+                    d["xyz"] = self.xyz2[pb][h * B:(h + 1) * B]
+                    if c2 is not None:
+                        c2[h * B:(h + 1) * B].copy_(d["cloud"])
+                        d["cloud"] = c2[h * B:(h + 1) * B]
+                self.cloud2.append(c2)
         else:
             self.geo = [model.alloc_geometry(B, N, dev) for _ in range(self.slots)]
         self.B = B
@@ -162,9 +181,15 @@ class TrainPipeline:
                 if self.feeder is not None:
                     for name, t in self.feeder(i + h).items():
                         d[name].copy_(t, non_blocking=not self.feeder_blocking)
-                self.xyz2[pb][h * B:(h + 1) * B].copy_(d["xyz"], non_blocking=True)
-                self.fs2[pb][:, h * B:(h + 1) * B].copy_(d["fps_start"], non_blocking=True)
-            kw = {"clouds": [self.inputs[k]["cloud"] for k in ks]} if self.input_only else {}
+                # (d["xyz"] / d["cloud"] ARE slices of the group's tensors: nothing to copy; the start indices -- 2 x B ints in a
+                # (2, G B) table -- are copied when a feeder may have changed them, and once otherwise)
+                if self.feeder is not None or not self._fs_synced[pb]:
+                    self.fs2[pb][:, h * B:(h + 1) * B].copy_(d["fps_start"], non_blocking=True)
+            self._fs_synced[pb] = True
+            kw = {}
+            if self.input_only:
+                group_cloud = self.cloud2[pb] is not None and getattr(self.model, "geometry_pair_takes_group_cloud", False)
+                kw = {"cloud2": self.cloud2[pb]} if group_cloud else {"clouds": [self.inputs[k]["cloud"] for k in ks]}
             self.model._geometry_pair(self.xyz2[pb], self.fs2[pb], self.geo_pairs[pb], tuple(self.geo[k] for k in ks), **kw)
             for k in ks:
                 self.geo_ready[k].record(st)

@@ -179,6 +179,7 @@ class PointNet2(nn.Module):
     # launch less per step); until that step `p.grad` holds image 0 only.
     defer_grad_reduce = False
     _grad_images_pending = None
+    geometry_pair_takes_group_cloud = True      # `_geometry_pair(..., cloud2=)`: the input-only pieces once per group of batches
     fuse_eval_head = os.environ.get("SN2_FUSE_EVAL_HEAD", "1") == "1"     # eval: FP1 + head in one kernel (sn2_fp_head_eval)
     # training: SA3, its BatchNorm, the plot max, FP3 and its BatchNorm in one launch (sn2_global_level_forward) instead of five;
     # its workgroups exchange the batch statistics among themselves -- False where other processes share the device
@@ -512,16 +513,22 @@ class PointNet2(nn.Module):
                                       for k, (R, S) in enumerate(((M2, 1), (M1, M2), (N, M1))))
             g.ws1 = g.ws2 = g.nn_ws = None
             g.rank1 = gp.rank1[rn] if (gp.rank1 is not None and self._fp1_source_side(B * N)) else None
-            self._alloc_input_only(g, B, N, dev)
+            # the input-only pieces of the feature pass: the batch's slices of the GROUP's buffers (one launch each for the whole
+            # group when the pass is handed the group's clouds in one tensor: `_geometry_pair(..., cloud2=)`)
+            g.rows0, g.has_rows0 = gp.rows0[rn], False
+            g.p2_pix = gp.p2_pix[rn] if gp.p2_pix is not None else None
+            g.p2_mm = gp.p2_mm[pl] if gp.p2_mm is not None else None
+            g.p2_diam_pix = None
             g.ready = None
             halves.append(g)
         return gp, tuple(halves)
 
-    def _geometry_pair(self, xyz2, fps_start2, gp, halves, clouds=None):
+    def _geometry_pair(self, xyz2, fps_start2, gp, halves, clouds=None, cloud2=None):
         """`_geometry` for len(halves) batches at once: xyz2 (G B,3,N), fps_start2 (2,G B); FPS, ball queries and 3-NN tables
         run on all plots in one launch each (into `gp`), the per-batch products (message totals, SA work items, inverted 3-NN
         indices) per batch.  Same tables as G `_geometry` calls.  clouds: the G batches' (B,10,N) device tensors -> also the
-        input-only pieces of their feature passes (`_input_only`)."""
+        input-only pieces of their feature passes (`_input_only`), batch by batch; cloud2 (G B,10,N): the same for the whole group
+        in one launch each (the batches' clouds live in one tensor: what TrainPipeline arranges)."""
         B2, _, N = xyz2.shape
         B = B2 // len(halves)
         M1, M2 = self._sizes(N)
@@ -529,9 +536,10 @@ class PointNet2(nn.Module):
             raise ValueError("geometry buffers do not match this batch pair")
         # 8 waves per plot: this pass runs beside other batches' feature kernels (sn2_fps_waves)
         ops.fps(xyz2, M1, fps_start2[0], out=(gp.idx1, gp.pos1_soa, gp.pos1_aos, gp.ws1), waves=self.fps_waves_shared)
-        ops.ball_query(xyz2, gp.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, gp.tot1, fps_ws=gp.ws1, out=(gp.nbr1, gp.cnt1))
+        # (no message total of the GROUP: the batches' totals come from count_sum_group below)
+        ops.ball_query(xyz2, gp.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, False, fps_ws=gp.ws1, out=(gp.nbr1, gp.cnt1))
         ops.fps(gp.pos1_soa, M2, fps_start2[1], out=(gp.idx2, gp.pos2_soa, gp.pos2_aos, gp.ws2))
-        ops.ball_query(gp.pos1_soa, gp.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, gp.tot2, fps_ws=gp.ws2,
+        ops.ball_query(gp.pos1_soa, gp.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, False, fps_ws=gp.ws2,
                        out=(gp.nbr2, gp.cnt2))
         ops.three_nn(gp.pos3, gp.pos2_soa, 1, out=gp.knn3)
         ops.three_nn(gp.pos2_soa, gp.pos1_soa, 3, out=gp.knn2, ws=gp.nn_ws[0])
@@ -546,11 +554,14 @@ class PointNet2(nn.Module):
         ops.interp_index_group(gp.knn2, G, B, M1, M2, grp.inv[1], grp.si[1])
         rank = gp.rank1 if halves[0].rank1 is not None else None
         ops.interp_index_group(gp.knn1, G, B, N, M1, grp.inv[2], grp.si[2], src_pos=gp.pos1_aos, row_perm=rank)
+        if cloud2 is not None:
+            self._input_only(gp, cloud2, xyz2)                    # one launch each over the whole group
         for h, g in enumerate(halves):
             g.xyz = xyz2[h * B:(h + 1) * B]
-            g.has_rows0 = False
+            g.has_rows0 = cloud2 is not None
+            g.p2_diam_pix = gp.p2_diam_pix if cloud2 is not None else None
             g.has_inverted = True
-            if clouds is not None:
+            if clouds is not None and cloud2 is None:
                 self._input_only(g, clouds[h], g.xyz)
         return halves
 

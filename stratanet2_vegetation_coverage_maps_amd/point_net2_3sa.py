@@ -52,6 +52,8 @@ class PointNet2ThreeSA(PointNet2):
             self.cuda(self.cuda_device)
 
     N_FPS = 3
+    executor = False                             # (the one-call executor covers the reference architecture)
+    geometry_pair_takes_group_cloud = False
     BF16_BLOCKS = ("sa1_module.conv.local_nn", "sa2_module.conv.local_nn", "sa3_module.conv.local_nn", "sa4_module.nn",
                    "fp4_module.nn", "fp3_module.nn", "fp2_module.nn")
 
