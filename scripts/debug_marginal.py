@@ -16,7 +16,7 @@ torch.manual_seed(0)
 model = PointNet2(args).train()
 model.p2_diam_pix = args.diam_pix          # as bench.py: the geometry passes also compute the projection's pixel ids
 flatten_parameters(model)
-opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3)
+opt = FlatAdam(model, lr=1e-3, weight_decay=1e-3, fold_gradient_images=True)      # as bench.py
 dev = torch.device("cuda:0")
 depth = 3
 
@@ -31,8 +31,7 @@ def fstep(inp, geo=None):
     opt.zero_grad()
     cd = {"cloud": inp["cloud"], "xyz": inp["xyz"], "fps_start": inp["fps_start"], "geometry": geo}
     cov, proba = model(cd)
-    pred = project_to_plotwise_coverages(cov, inp["cloud"], args, geometry=geo)
-    loss, _ = losses.total_loss(pred, proba, inp["gt"], inp["pdf"], args.m, args.e)
+    loss, _, _ = losses.projected_total_loss(cov, proba, inp["cloud"], inp["gt"], inp["pdf"], args, geometry=geo, model=model)
     loss.backward()
     return loss
 
@@ -59,10 +58,12 @@ print(f"all entry points: {base:.4f} ms/step ({pipe.group} batches per geometry 
 if os.environ.get("ONLY_BASE"):
     pipe.drain(); torch.cuda.synchronize(); sys.exit(0)
 real = {}
-groups = [("fps",), ("ball_query",), ("count_sum",), ("sa_order",), ("three_nn",), ("interp_index",), ("pack_rows", "plot_pixels"),
-          ("ball_query", "count_sum", "sa_order", "three_nn", "interp_index"),
-          ("fps", "ball_query", "count_sum", "sa_order", "three_nn", "interp_index"),
-          ("fps", "ball_query", "count_sum", "sa_order", "three_nn", "interp_index", "pack_rows", "plot_pixels")]
+# (round 5: a pass over several batches builds the per-batch products with the *_group entry points)
+CS, SO, II = ("count_sum_group", "sa_order_group", "interp_index_group") if GROUP > 1 else ("count_sum", "sa_order", "interp_index")
+groups = [("fps",), ("ball_query",), (CS,), (SO,), ("three_nn",), (II,), ("pack_rows", "plot_pixels"),
+          ("ball_query", CS, SO, "three_nn", II),
+          ("fps", "ball_query", CS, SO, "three_nn", II),
+          ("fps", "ball_query", CS, SO, "three_nn", II, "pack_rows", "plot_pixels")]
 for gnames in groups:
     for name in gnames:
         real[name] = getattr(ops, name)

@@ -543,6 +543,8 @@ class PointNet2(nn.Module):
                        out=(gp.nbr2, gp.cnt2))
         ops.three_nn(gp.pos3, gp.pos2_soa, 1, out=gp.knn3)
         ops.three_nn(gp.pos2_soa, gp.pos1_soa, 3, out=gp.knn2, ws=gp.nn_ws[0])
+        # (the targets in the FPS pass's existing Morton order -- `dst_fps_ws=gp.ws1`, no target sort -- made the pipelined step
+        # SLOWER, 0.739 against 0.718 ms: the search's query boxes grow more than the sort costs; round 5)
         ops.three_nn(gp.pos1_soa, xyz2, 3, out=gp.knn1, ws=gp.nn_ws[1])
         grp, G = gp._grp, len(halves)
         tot_flat = grp.totals.view(-1)                       # (G,2): [h][0] = level-1 messages of batch h, [h][1] = level-2
