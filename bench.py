@@ -403,7 +403,10 @@ def cpu_baseline():
 # workgroup per plot and a fixed number of sequential rounds, so a pass over 8 batches takes as long as a pass over one, and
 # what its workgroups cost the feature pass beside them is the TIME they are resident, not the CUs they hold (DESIGN.md
 # section 4): 1 batch per pass 0.96 ms/step, 2: 0.831, 4: 0.792, 8: 0.776, 16: 0.806 (128 plots: a third of the chip's CUs).
-PIPE_GROUP = int(os.environ.get("SN2_PIPE_GROUP", "8"))
+# Round 5: with the per-batch products of a pass built by grouped launches (18 small launches per pass instead of 18 per batch)
+# larger groups pay again: 200 steps 0.7216 / ~0.717 / 0.7156 / 0.7595 at G = 8 / 10 / 12 / 16, the driver's 20 steps 0.741 /
+# 0.740 / 0.7285 at G = 4 / 5 / 10 -- 10 divides both step counts, so both commands run the same mode.
+PIPE_GROUP = int(os.environ.get("SN2_PIPE_GROUP", "10"))
 
 
 def pipe_group_for(steps):
@@ -412,7 +415,7 @@ def pipe_group_for(steps):
     driver-timed line ran 20 steps with 8 batches per pass: three passes = 24 batches of geometry for 20 feature passes)."""
     if "SN2_PIPE_GROUP" in os.environ or steps % PIPE_GROUP == 0:
         return PIPE_GROUP
-    for g in (5, 10, 4, 6, 7, 3, 2):
+    for g in (8, 5, 12, 4, 6, 7, 3, 2):
         if steps % g == 0:
             return g
     return PIPE_GROUP

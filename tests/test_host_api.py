@@ -122,8 +122,9 @@ def test_bench_gives_a_timed_region_its_share_of_geometry():
     turns the phase into how far ahead the passes run.  (CPU: arithmetic only.)"""
     import importlib
     bench = importlib.import_module("bench")
-    assert bench.pipe_group_for(200) == 8 and bench.pipe_group_for(20) == 5 and bench.pipe_group_for(100) == 5
-    assert bench.pipe_group_for(50) == 5 and bench.pipe_group_for(21) == 7 and bench.pipe_group_for(13) == 8   # a prime: no divisor
+    assert bench.pipe_group_for(200) == 10 and bench.pipe_group_for(20) == 10 and bench.pipe_group_for(100) == 10
+    assert bench.pipe_group_for(50) == 10 and bench.pipe_group_for(21) == 7 and bench.pipe_group_for(24) == 8
+    assert bench.pipe_group_for(13) == 10                                                                        # a prime: no divisor
     for warmup, steps in ((5, 20), (20, 200), (10, 100), (6, 50), (0, 8)):
         G = bench.pipe_group_for(steps)
         ph = bench.pipe_phase_for(G, warmup, steps)
