@@ -190,8 +190,9 @@ typedef struct sn2_sa {
     const int *order;               /* from sn2_sa_order, or NULL: quads of consecutive centroids                      */
     sn2_block blk[2];
     float *ext; int *arg;           /* (B*M,cout): signed extremum of the last block's pre-BN activation and the
-                                       neighbour slot attaining it (-1: no neighbours; an EVAL forward writes 0 for
-                                       "has neighbours": it keeps nothing for a backward)                       */
+                                       neighbour slot attaining it (-1: no neighbours).  An EVAL forward keeps
+                                       nothing for a backward: it leaves both arrays untouched (round 5: its kernel
+                                       writes `out` itself)                                                     */
     float *out;                     /* (B*M,cout) = a*ext + c : the module output x                             */
     const float *dout;              /* backward in : d loss / d out (B*M,cout)                                  */
     float *dfeat;                   /* backward out: ACCUMULATED d loss / d feat (B*Nsrc,cf) or NULL            */

@@ -89,6 +89,12 @@ int forward_t(const sn2_sa* p, int training, hipStream_t st) {
         if (training) SN2_TRY((sa_mfma_launch_fwd<CF, NL, C1, C2, 0>(p, training, st, &nb)));
         SN2_TRY(sn2_bn_finalize(&p->blk[0], nb, p->total, 0, training, st));
     }
+    if (!training) {
+        // EVAL: every block's (a, c) comes from its running statistics, known before the pass: the kernel writes the level's
+        // output a ext + c itself (p->ext, p->arg stay untouched)
+        SN2_TRY(sn2_bn_finalize(last, 0, p->total, 0, 0, st));
+        return sa_mfma_launch_fwd<CF, NL, C1, C2, 1>(p, 0, st, &nb);
+    }
     SN2_TRY((sa_mfma_launch_fwd<CF, NL, C1, C2, 1>(p, training, st, &nb)));
     // the last block's statistics -> (a, c), and out = a ext + c, in ONE launch (round 5: bn_finalize + sa_finalize_kernel were two)
     return sn2_bn_finalize_apply(last, nb, p->total, 0, training, p->ext, p->arg, p->out, (long)p->B * p->M, st);

@@ -34,6 +34,10 @@ struct SaFwdArgs {
     float *slots;  // statistics slots of the block this pass measures, or nullptr
     float* ext;
     int* arg;
+    // EVAL (STATS = false): the last block's BatchNorm on its running statistics, (a, c) finalised BEFORE the launch, and the
+    // level's output a ext + c written by this kernel (no ext / arg arrays, no pass over them afterwards)
+    const float *al, *cl;
+    float* out;
 };
 
 // every lane ends up with the reduction over its DPP row (16 lanes)
@@ -139,8 +143,10 @@ __device__ __forceinline__ bool sa_item(SaItem& it, const int* __restrict__ orde
 
 // PASS 0: statistics of block 0 only (nl == 2);  PASS 1: full forward, statistics of the last block, extremum
 // STATS = false (an EVAL pass: BatchNorm on its running statistics, nothing kept for a backward): no statistic sums and no
-// arg-max slots (`arg` only says whether the centroid has neighbours) -- a quarter of the vector instructions of a step, which is what bounds the parcel
-// loop's SA1 pass (64 M messages per launch)
+// arg-max slots -- a quarter of the vector instructions of a step, which is what bounds the parcel loop's SA1 pass (64 M
+// messages per launch) -- and (round 5) the level's OUTPUT a ext + c straight from the kernel: (a, c) of the last block
+// are known before the launch, so the ext / arg arrays and the pass over them (parcel loop: 410 MB per launch for SA1
+// where 82 MB of output do) fall away
 template <int CF, int NL, int C1, int C2, int PASS, bool BF16, bool STATS = true>
 __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_fwd_kernel(const SaFwdArgs a) {
     static_assert(STATS || PASS == 1, "pass 0 IS the statistics pass");
@@ -193,6 +199,13 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
         for (int io = 0; io < TOL; ++io)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sgn[io][r] = gl[16 * io + 4 * q + r] < 0.f ? -1.f : 1.f;
+    }
+    float alv[STATS ? 1 : TOL][4], clv[STATS ? 1 : TOL][4];
+    if constexpr (!STATS) {
+#pragma unroll
+        for (int io = 0; io < TOL; ++io)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) alv[io][r] = a.al[16 * io + 4 * q + r], clv[io][r] = a.cl[16 * io + 4 * q + r];
     }
     float ssum[TOS][4], ssq[TOS][4];
 #pragma unroll
@@ -369,13 +382,19 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
                             const unsigned am = seg_min_u32(best[t][io][r] == m ? (unsigned)barg[t][io][r] : 0xFFFFFFFFu, W);
                             av[r] = it.ln[t] > 0 ? (int)am : -1;
                         } else {
-                            av[r] = it.ln[t] > 0 ? 0 : -1;       // eval: only "has neighbours" (what sa_finalize_kernel asks)
+                            // eval: the level's output itself, as bn_finalize_kernel<true> forms it (0 without neighbours)
+                            av[r] = 0;
+                            ev[r] = it.ln[t] > 0 ? fmaf(alv[io][r], ev[r], clv[io][r]) : 0.f;
                         }
                     }
                     if (writer && it.ln[t] >= 0) {
                         const size_t o = (size_t)it.lc[t] * CL + 16 * io + 4 * q;
-                        *reinterpret_cast<float4*>(a.ext + o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
-                        *reinterpret_cast<int4*>(a.arg + o) = make_int4(av[0], av[1], av[2], av[3]);
+                        if constexpr (STATS) {
+                            *reinterpret_cast<float4*>(a.ext + o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                            *reinterpret_cast<int4*>(a.arg + o) = make_int4(av[0], av[1], av[2], av[3]);
+                        } else {
+                            *reinterpret_cast<float4*>(a.out + o) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                        }
                     }
                 }
             }
@@ -875,6 +894,7 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
     a.W1 = k1.W; a.b1 = k1.b; a.gamma1 = k1.gamma;
     a.slots = training ? (PASS == 0 ? k0.stat_slots : k1.stat_slots) : nullptr;
     a.ext = p->ext; a.arg = p->arg;
+    a.al = k1.a; a.cl = k1.c; a.out = p->out;
     int blocks = sn2_cdiv((long)p->B * p->M, 16);          // one wave per quad of centroids, four waves per workgroup
     if (blocks > SN2_STAT_SLOTS) blocks = SN2_STAT_SLOTS;
     // .. and no more workgroups than the chip holds at once (waves per SIMD by the kernels' register counts): the items are
