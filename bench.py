@@ -705,7 +705,7 @@ def dropin_eager_leg(dev, B, n_points, steps=40, warmup=5):
 
 def dropin_predict_leg(dev, plots=512, points=10000, batch=20, repeat=3):
     """The drop-in under the reference's INFERENCE loop as written (/root/reference/predict.py:96-126 with
-    inference/predict_utils.py:94-102): `model.eval()`, no `torch.no_grad()` (the reference has none), CPU-resident batches of
+    inference/predict_utils.py:94-102): `model.eval()` under `torch.set_grad_enabled(False)` (predict.py:65,69), CPU-resident batches of
     `args.batch_size` = 20 plots (config.py:85) x `subsample_size` = 10 000 points as its DataLoader collates them,
     `model(cloud_data)`, `get_batch_format`, then PER PLOT `project_to_2d_rasters(clouds[idx], coverages_pointwise[idx], args)`,
     which returns a numpy array (project_to_2d.py:78-113; the drop-in answers a batch's per-plot calls from ONE batched launch
@@ -732,21 +732,22 @@ def dropin_predict_leg(dev, plots=512, points=10000, batch=20, repeat=3):
                 n += 1
         return n, rasters
 
-    run()
     times = []
-    for _ in range(repeat):
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        n, rasters = run()
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t)
+    with torch.no_grad():                 # predict.py:65,69 switch autograd off for the whole script
+        run()
+        for _ in range(repeat):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            n, rasters = run()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t)
     med = sorted(times)[len(times) // 2]
     del model, batches
     torch.cuda.empty_cache()
     return {"plots_per_s": round(n / med, 1), "ms_per_batch_of_20": round(med / ((n + batch - 1) // batch) * 1e3, 3),
             "runs_s": [round(t, 4) for t in times], "statistic": f"median of {repeat} passes over {n} plots",
             "last_raster_finite_pixels": int(np.isfinite(rasters).sum()),
-            "what": f"predict.py:96-126 as written: eval mode, autograd on, {batch} plots x {points} pts per batch from HOST tensors, "
+            "what": f"predict.py:96-126 as written: eval mode, autograd off (predict.py:65,69), {batch} plots x {points} pts per batch from HOST tensors, "
                     "model(cloud_data), get_batch_format, project_to_2d_rasters per plot (numpy out; one launch + one D2H read per BATCH, "
                     "made at the batch's first call); GIS file output not run"}
 

@@ -76,7 +76,19 @@ typedef struct sn2_block {
                                       0: exact fp32 products (v_mfma_f32_16x16x4_f32), the reference's precision.          */
     long long *num_batches_tracked; /* BatchNorm1d's int64 counter (one element) or NULL: += 1 by the training forward,
                                        inside the statistics finalisation (no launch of its own)                           */
+    int frozen_stats;              /* read by the BACKWARD entry points.  != 0: the forward pass ran this BatchNorm on its RUNNING
+                                      statistics (a forward with training = SN2_BN_FROZEN_KEEP: model.eval() with gradients
+                                      wanted, model/point_net2.py:45-53 under torch's autograd), so mean / invstd are constants of
+                                      the backward: d pre-BN = gamma * invstd * dy, without the batch-mean and batch-variance
+                                      terms; dgamma / dbeta are the same sums.  0: batch statistics (a training forward).           */
 } sn2_block;
+/* the `training` argument of sn2_sa_forward / sn2_fp_forward / sn2_net_io.training:
+ *   0                   eval: BatchNorm on its running statistics, nothing kept for a backward pass (fewest bytes and launches);
+ *   1                   training: batch statistics, running statistics and counters updated, everything kept;
+ *   SN2_BN_FROZEN_KEEP  eval WITH a backward to come: running statistics (not updated), and everything a backward pass reads is
+ *                       kept exactly as a training forward keeps it (the kernels of a training pass, the finalisation of an eval
+ *                       pass); the backward calls must then carry sn2_block.frozen_stats = 1. */
+#define SN2_BN_FROZEN_KEEP 2
 /* flat[i] += sum_{r=1..replicas-1} flat[r*stride + i], i < n: folds the images of a flat gradient vector into image 0 */
 int sn2_grad_reduce(float *flat, int n, int replicas, int stride, void *stream);
 
@@ -563,6 +575,8 @@ typedef struct sn2_net_bwd {
     int defer_grad_reduce;               /* set by the caller: leave the images unfolded (sn2_adam_step_images folds them) */
     int arena_is_zero;                   /* set by the caller: the forward pass cleared `arena` (sn2_net_act.bwd_arena) and nothing has
                                             touched it since: sn2_net_backward does not clear it again */
+    int frozen_stats;                    /* set by the caller: the forward pass ran with io.training = SN2_BN_FROZEN_KEEP (every
+                                            block's sn2_block.frozen_stats) */
 } sn2_net_bwd;
 
 #define SN2_NET_FORK 1          /* geometry: level-2 chain on io.stream_b, per-point 3-NN chain on io.stream_c (needs io.ctx) */
@@ -584,7 +598,7 @@ typedef struct sn2_net_io {
     void *stream_b, *stream_c, *stream_pack;         /* side streams of a forked pass (hipStream_t), or NULL */
     void *ctx;                           /* sn2_net_ctx_create: the events that order them, or NULL (no fork) */
     int flags;                           /* SN2_NET_* */
-    int training;                        /* model.training */
+    int training;                        /* model.training (0 / 1), or SN2_BN_FROZEN_KEEP: eval mode with a backward to come */
 } sn2_net_io;
 
 /* events of a forked geometry pass: created once by the caller (one per model and device), used by one pass at a time */

@@ -12,26 +12,27 @@ from . import losses, network, projection
 
 
 def train_step(sd, d, args, fps_start=None, dtype=torch.float64, arch="ref", dropout_mask=None, use_kdtree=False,
-               bf16_layers=(), act_bf16=False):
+               bf16_layers=(), act_bf16=False, training=True):
     """sd: state dict (fp32 tensors); d: make_batch dict (cloud, xyz, coverages, pdf_all); -> dict with the forward
-    outputs (detached, `dtype`), the loss terms and `grads` {parameter key: gradient}."""
+    outputs (detached, `dtype`), the loss terms and `grads` {parameter key: gradient}.  training=False: the same step through
+    an eval-mode forward (BatchNorm on its running statistics, under autograd: model/point_net2.py:45-53 after model.eval())."""
     s = {k: (v.to(dtype) if v.is_floating_point() else v).clone() for k, v in sd.items()}
     keys = network.param_keys(s)
     for k in keys:
         s[k].requires_grad_(True)
     cloud = d["cloud"].to(dtype)
     if arch == "3sa":
-        cov, proba, ex = network.forward_3sa(s, cloud, d["xyz"], args, training=True, fps_start=fps_start, use_kdtree=use_kdtree,
+        cov, proba, ex = network.forward_3sa(s, cloud, d["xyz"], args, training=training, fps_start=fps_start, use_kdtree=use_kdtree,
                                              bf16_layers=bf16_layers, act_bf16=act_bf16)
     else:
         fs = None if fps_start is None else (fps_start[0], fps_start[1])
-        cov, proba, ex = network.forward(s, cloud, d["xyz"], args, training=True, fps_start=fs, use_kdtree=use_kdtree,
+        cov, proba, ex = network.forward(s, cloud, d["xyz"], args, training=training, fps_start=fs, use_kdtree=use_kdtree,
                                          dropout_mask=dropout_mask, bf16_layers=bf16_layers, act_bf16=act_bf16)
     pred = projection.project_to_plotwise_coverages(cov, d["cloud"], args)          # pixel ids from the fp32 cloud
     loss, parts = losses.total_loss(pred, proba, d["coverages"], d["pdf_all"], args.m, args.e)
     loss.backward()
     return {"cov": cov.detach(), "proba": proba.detach(), "pred": pred.detach(), "loss": float(loss.detach()),
-            "parts": [float(p.detach()) for p in parts], "grads": {k: s[k].grad for k in keys}, "new_stats": ex.get("new_stats")}
+            "parts": [float(p.detach()) for p in parts], "grads": {k: s[k].grad for k in keys}, "new_stats": (ex or {}).get("new_stats")}
 
 
 def compare(model, cov, proba, loss, ref, tol_out=1e-4, tol_grad=1e-3, pred=None):

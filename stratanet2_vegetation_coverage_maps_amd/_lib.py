@@ -18,7 +18,10 @@ class Block(Structure):  # sn2_block
                 ("c", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("stat_slots", c_void_p),
                 ("dW", c_void_p), ("db", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
                 ("grad_replicas", c_int), ("grad_replica_stride", c_int), ("mma_bf16", c_int),
-                ("num_batches_tracked", c_void_p)]
+                ("num_batches_tracked", c_void_p), ("frozen_stats", c_int)]
+
+
+BN_FROZEN_KEEP = 2          # SN2_BN_FROZEN_KEEP: the `training` argument of an eval-mode forward whose backward will be asked for
 
 
 class SA(Structure):  # sn2_sa
@@ -86,7 +89,7 @@ class NetBwd(Structure):  # sn2_net_bwd
     _fields_ = [("dcov", c_void_p), ("dproba", c_void_p), ("arena", c_void_p), ("arena_words", c_long), ("images", c_int),
                 ("image_stride", c_int)] + [(n, c_void_p) for n in (
                     "dy2", "dy3", "dx1", "dx2", "dx3", "dy_sa3", "dy1", "du1", "du2", "du3", "bn_ok", "src_ws1", "src_ws2")] + [
-                        ("defer_grad_reduce", c_int), ("arena_is_zero", c_int)]
+                        ("defer_grad_reduce", c_int), ("arena_is_zero", c_int), ("frozen_stats", c_int)]
 
 
 class NetIO(Structure):  # sn2_net_io

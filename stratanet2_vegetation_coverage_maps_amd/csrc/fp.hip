@@ -2147,7 +2147,10 @@ bool fp_source_side_ok(const sn2_fp* p) {
 }
 
 template <int CA, int CB, int CO, bool KNN>
-int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
+int fp_forward_t(const sn2_fp* p, int mode, hipStream_t st) {
+    // mode == SN2_BN_FROZEN_KEEP: the kernel a TRAINING pass of this shape takes (the backward pass that follows chooses its
+    // kernels by the same rules), without statistic sums; BatchNorm finalised from the running statistics, nothing updated
+    const int training = mode == 1, keep = mode != 0;
     const int R = p->B * p->R_per_plot;
     // the matrix-core kernel (64 rows x 4 channel groups per workgroup): its per-workgroup statistic slots bound the rows of a
     // TRAINING pass; an eval pass writes no statistics, so any row count takes it (parcel inference: FP3 on 80 000 rows ran
@@ -2155,7 +2158,7 @@ int fp_forward_t(const sn2_fp* p, int training, hipStream_t st) {
     const bool small = sn2_cdiv(R, 64) <= SN2_STAT_SLOTS;
     bool src_side = false;                      // (the per-point layer keeps its source-side form in both modes)
     if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) src_side = !small && fp_source_side_ok<CA, CO>(p);
-    if (small || (!training && !src_side)) {
+    if (small || (!keep && !src_side)) {
         if (p->act_bf16) return SN2_ELIMIT;
         const int grid = sn2_cdiv(R, 64);
         constexpr size_t lf = (size_t)(64 * OuterAcc<16, CA + CB + 1>::QS + 2 * 16 * ((CO + 15) / 16)) * sizeof(float);
@@ -2264,6 +2267,9 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     // waves per workgroup (one workgroup per CU): as many as the staging regions and 256 VGPRs per lane allow
     constexpr int WAVES = (Acc::LDS_FLOATS * 4 * 8 <= 150 * 1024) ? 8 : ((Acc::LDS_FLOATS * 4 * 4 <= 150 * 1024) ? 4 : 2);
     const int R = p->B * p->R_per_plot;
+    // 1 / (rows of the batch statistics); frozen_stats: the forward's statistics were constants (running statistics) -- the
+    // batch-mean and batch-variance terms of the BatchNorm backward vanish
+    const float invR = p->blk.frozen_stats ? 0.f : 1.0f / (float)R;
     if (p->act_bf16 && !(p->bn_sums_done && p->src_ws && p->du_scratch && p->scatter_ws && p->dsrc && !p->dskip &&
                          sn2_cdiv(R, 64) > SN2_STAT_SLOTS))
         return SN2_ELIMIT;                    // bfloat16 rows: the source-side form of the per-point layer only
@@ -2294,7 +2300,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
         if (lb > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
         hipLaunchKernelGGL(ks, dim3(sn2_cdiv(R, 64)), dim3(256), lb, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,
-                           p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src,
+                           p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, invR, p->src,
                            p->src_a, p->src_c, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma,
                            (const float*)p->blk.mean, (const float*)p->blk.invstd, (const float*)p->blk.dgamma,
                            (const float*)p->blk.dbeta, (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out0, p->dskip,
@@ -2313,7 +2319,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb1);
             const int parts = g_fp1_bwd_parts;
             if (parts & 1)
-            hipLaunchKernelGGL(k1, dim3(2 * grid_mult * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, 1.0f / (float)R, p->skip,
+            hipLaunchKernelGGL(k1, dim3(2 * grid_mult * sn2_cu_count()), dim3(NT), lb1, st, R, p->skip_stride, invR, p->skip,
                                p->blk.gamma, (const float*)p->blk.mean, (const float*)p->blk.invstd,
                                (const float*)p->blk.dgamma, (const float*)p->blk.dbeta, (const float*)p->h, p->dy,
                                p->du_scratch, p->blk.dW, p->blk.db, p->blk.grad_replicas, p->blk.grad_replica_stride,
@@ -2355,7 +2361,7 @@ int fp_backward_t(const sn2_fp* p, hipStream_t st) {
     int grid = pick_grid(R, WAVES * 64, 4);
     if (grid > 256) grid = 256;
     if (!small) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, st, R, p->R_per_plot, p->S_per_plot, p->src_stride,
-                       p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, 1.0f / (float)R, p->src, p->src_a, p->src_c,
+                       p->skip_stride, p->h_stride, p->dskip_stride, KNN ? CA : p->dsrc_stride, invR, p->src, p->src_a, p->src_c,
                        p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.gamma, (const float*)p->blk.mean,
                        (const float*)p->blk.invstd, (const float*)p->blk.dgamma, (const float*)p->blk.dbeta,
                        (const float*)p->h, p->dy, p->blk.dW, p->blk.db, du_out, p->dskip, p->blk.grad_replicas,
@@ -2436,6 +2442,7 @@ extern "C" int sn2_interp_index_group(const int* knn_idx, const float* knn_w, co
 
 extern "C" int sn2_fp_forward(const sn2_fp* p, int training, void* stream) {
     SN2_TRY(check_fp(p));
+    if (training < 0 || training > SN2_BN_FROZEN_KEEP) return SN2_EINVAL;
     FP_DISPATCH(fp_forward_t, p, training, (hipStream_t)stream);
 }
 

@@ -76,6 +76,7 @@ int check_model_ptrs(const sn2_net_model* m) {
 struct GradDst {
     float* flat;          // image 0 of the flat gradient, or nullptr (forward: no gradient fields)
     int stride;
+    int frozen;           // backward: the forward ran BatchNorm on its running statistics (sn2_block.frozen_stats)
 };
 
 // hip_ops.BlockBuffers.fill: block `k` (0..6 in model order) of the network
@@ -91,6 +92,7 @@ void fill_block(sn2_block* blk, const sn2_net_layer* L, int k, const sn2_net_act
     blk->stat_slots = a->stats + st_off;
     blk->mma_bf16 = L->mma_bf16 ? 1 : 0;
     blk->num_batches_tracked = L->num_batches_tracked;
+    blk->frozen_stats = g.frozen;
     if (g.flat) {
         blk->dW = g.flat + L->gW, blk->db = g.flat + L->gb, blk->dgamma = g.flat + L->ggamma, blk->dbeta = g.flat + L->gbeta;
         blk->grad_replicas = GRAD_IMAGES, blk->grad_replica_stride = g.stride;
@@ -441,14 +443,17 @@ extern "C" int sn2_net_forward(const sn2_net_model* m, const sn2_net_dims* d, co
     if (!a->aux || !a->stats || !a->ext1 || !a->arg1 || !a->x1 || !a->ext2 || !a->arg2 || !a->x2 || !a->h_sa3 || !a->h3 || !a->x3 ||
         !a->arg3 || !a->h2 || !a->cov || !a->proba)
         return SN2_EINVAL;
-    const int training = io->training ? 1 : 0, flags = io->flags;
+    // mode: 0 eval, 1 training, SN2_BN_FROZEN_KEEP eval with a backward to come (the layers' own entry points take it as is);
+    // `training` below = "a backward pass may follow" (tables, kept rows), `batch_stats` = model.training
+    if (io->training < 0 || io->training > SN2_BN_FROZEN_KEEP) return SN2_EINVAL;
+    const int mode = io->training, training = mode != 0 ? 1 : 0, batch_stats = mode == 1 ? 1 : 0, flags = io->flags;
     const int B = d->B, N = d->N, M2 = d->M2;
     hipStream_t cur = (hipStream_t)stream;
     NetCtx* ctx = static_cast<NetCtx*>(io->ctx);
     const bool fused_eval = !training && m->fuse_eval_head && !d->act_bf16 && m->source_side;
     if (!fused_eval && !a->h1) return SN2_EINVAL;
     if (training && !(g->inv1 && g->inv2 && g->inv3)) return SN2_EINVAL;
-    const GradDst nograd{nullptr, 0};
+    const GradDst nograd{nullptr, 0, 0};
     bool join_b = false, join_c = false, wait_pack = false;
     bool have_rows0 = flags & SN2_NET_HAS_ROWS0;
     if (flags & SN2_NET_WITH_GEOMETRY) {
@@ -494,27 +499,27 @@ extern "C" int sn2_net_forward(const sn2_net_model* m, const sn2_net_dims* d, co
     // ---- SA1, SA2                                                                           (point_net2.py:131-132, 21-29)
     sn2_sa sa;
     sa1_desc(&sa, m, d, g, a, nograd, nullptr);
-    SN2_TRY(sn2_sa_forward(&sa, training, cur));
+    SN2_TRY(sn2_sa_forward(&sa, mode, cur));
     if (join_b) NET_HIP(hipStreamWaitEvent(cur, ctx->b_tables, 0));     // chain b: the level-2 centroids, lists and work items
     sa2_desc(&sa, m, d, g, a, nograd, nullptr, nullptr);
-    SN2_TRY(sn2_sa_forward(&sa, training, cur));
+    SN2_TRY(sn2_sa_forward(&sa, mode, cur));
     if (join_b) NET_HIP(hipStreamWaitEvent(cur, ctx->b_nn, 0));         // ... its two small 3-NN tables
     // ---- global level: SA3 -> plot max -> FP3                                                (:133-137, 37-42, 62-67)
     sn2_fp p3, pf3;
     fp_desc(&p3, d, a, sa3_in(m, d, g, a), nograd);
     fp_desc(&pf3, d, a, fp3_in(m, d, g, a), nograd);
-    if (training && m->fuse_global_level && io->gl_xchg && io->gl_ctl && B <= GL_MAX_PLOTS_HOST && !m->sa3.mma_bf16 &&
+    if (batch_stats && m->fuse_global_level && io->gl_xchg && io->gl_ctl && B <= GL_MAX_PLOTS_HOST && !m->sa3.mma_bf16 &&
         !m->fp3.mma_bf16) {
         SN2_TRY(sn2_global_level_forward(&p3, &pf3, a->x3, a->arg3, io->gl_xchg, io->gl_ctl, cur));
     } else {
-        SN2_TRY(sn2_fp_forward(&p3, training, cur));
+        SN2_TRY(sn2_fp_forward(&p3, mode, cur));
         SN2_TRY(sn2_plot_max_forward(a->h_sa3, p3.blk.a, p3.blk.c, B, M2, 64, a->x3, a->arg3, cur));
-        SN2_TRY(sn2_fp_forward(&pf3, training, cur));
+        SN2_TRY(sn2_fp_forward(&pf3, mode, cur));
     }
     // ---- FP2                                                                                 (:138)
     sn2_fp p2;
     fp_desc(&p2, d, a, fp2_in(m, d, g, a, a->src_ws2), nograd);
-    SN2_TRY(sn2_fp_forward(&p2, training, cur));
+    SN2_TRY(sn2_fp_forward(&p2, mode, cur));
     if (join_c) NET_HIP(hipStreamWaitEvent(cur, ctx->c_nn, 0));         // chain c: the per-point 3-NN table
     // ---- FP1 + head                                                                          (:139-151)
     sn2_fp p1;
@@ -528,8 +533,8 @@ extern "C" int sn2_net_forward(const sn2_net_model* m, const sn2_net_dims* d, co
         SN2_TRY(sn2_fp_head_eval(&p1, &hd, cur));
     } else {
         fp_desc(&p1, d, a, fp1_in(m, d, g, a, a->src_ws1), nograd);
-        SN2_TRY(sn2_fp_forward(&p1, training, cur));
-        head_desc(&hd, m, d, a, training);
+        SN2_TRY(sn2_fp_forward(&p1, mode, cur));
+        head_desc(&hd, m, d, a, batch_stats);            // (dropout: model.training only)
         if (training && a->bwd_arena && a->bwd_arena_words > 0) hd.zero_fill = a->bwd_arena, hd.zero_fill_words = a->bwd_arena_words;
         SN2_TRY(sn2_head_forward(&hd, cur));
     }
@@ -559,10 +564,10 @@ extern "C" int sn2_net_backward(const sn2_net_model* m, const sn2_net_dims* d, c
         sn2_fill_words(b->arena, 0u, (size_t)b->arena_words, cur);
         NET_HIP(hipGetLastError());
     }
-    const GradDst gd{b->arena, b->image_stride};
+    const GradDst gd{b->arena, b->image_stride, b->frozen_stats ? 1 : 0};
     // head
     sn2_head hd;
-    head_desc(&hd, m, d, a, 1);
+    head_desc(&hd, m, d, a, b->frozen_stats ? 0 : 1);       // (no dropout in an eval-mode forward)
     hd.coverages = hd.proba = nullptr;
     hd.dcoverages = b->dcov, hd.dproba = b->dproba, hd.dy = static_cast<float*>(b->dy1);
     hd.dW1 = b->arena + m->g_lin1_W, hd.db1 = b->arena + m->g_lin1_b, hd.dW2 = b->arena + m->g_lin2_W, hd.db2 = b->arena + m->g_lin2_b;

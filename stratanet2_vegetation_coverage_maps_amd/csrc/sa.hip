@@ -85,9 +85,12 @@ template <int CF, int NL, int C1, int C2>
 int forward_t(const sn2_sa* p, int training, hipStream_t st) {
     const sn2_block* last = &p->blk[NL - 1];
     int nb = 0;
+    // training == SN2_BN_FROZEN_KEEP: the kernels of a training pass (ext, arg kept for the backward), the finalisations of an eval
+    // pass (running statistics, nothing updated); block 0's statistics pass has nothing to measure then
+    const int batch_stats = training == 1;
     if constexpr (NL == 2) {
-        if (training) SN2_TRY((sa_mfma_launch_fwd<CF, NL, C1, C2, 0>(p, training, st, &nb)));
-        SN2_TRY(sn2_bn_finalize(&p->blk[0], nb, p->total, 0, training, st));
+        if (batch_stats) SN2_TRY((sa_mfma_launch_fwd<CF, NL, C1, C2, 0>(p, training, st, &nb)));
+        SN2_TRY(sn2_bn_finalize(&p->blk[0], nb, p->total, 0, batch_stats, st));
     }
     if (!training) {
         // EVAL: every block's (a, c) comes from its running statistics, known before the pass: the kernel writes the level's
@@ -97,7 +100,7 @@ int forward_t(const sn2_sa* p, int training, hipStream_t st) {
     }
     SN2_TRY((sa_mfma_launch_fwd<CF, NL, C1, C2, 1>(p, training, st, &nb)));
     // the last block's statistics -> (a, c), and out = a ext + c, in ONE launch (round 5: bn_finalize + sa_finalize_kernel were two)
-    return sn2_bn_finalize_apply(last, nb, p->total, 0, training, p->ext, p->arg, p->out, (long)p->B * p->M, st);
+    return sn2_bn_finalize_apply(last, batch_stats ? nb : 0, p->total, 0, batch_stats, p->ext, p->arg, p->out, (long)p->B * p->M, st);
 }
 
 template <int CF, int NL, int C1, int C2>
@@ -233,6 +236,7 @@ static int sa_order_impl(const int* cnt, int G, int B, int M, int* order, size_t
 
 extern "C" int sn2_sa_forward(const sn2_sa* p, int training, void* stream) {
     SN2_TRY(check(p));
+    if (training < 0 || training > SN2_BN_FROZEN_KEEP) return SN2_EINVAL;
     if (p->nl == 2) return forward_t<8, 2, 16, 16>(p, training, (hipStream_t)stream);
     if (p->cf == 32) return forward_t<32, 1, 64, 64>(p, training, (hipStream_t)stream);
     return forward_t<16, 1, 32, 32>(p, training, (hipStream_t)stream);

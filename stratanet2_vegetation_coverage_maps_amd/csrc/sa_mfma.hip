@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
 //   * weight gradients contract over MESSAGES: both factors go through a wave-private LDS image [message][channel]
 //     (one ds_write_b128 per tile for a register tile) and come back in A/B layout with the message index as K.
 struct SaBwdArgs {
-    int B, Nsrc, M, cap, feat_stride, spos_stride, group;
+    int B, Nsrc, M, cap, feat_stride, spos_stride, group, frozen;
     const float *feat, *spos, *cpos;
     const int *nbr, *cnt, *order;
     const unsigned long long* total;
@@ -486,8 +486,9 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
     SASTAMP(0);
     for (int i = lane; i < Acc::LDS_FLOATS; i += 64) lds_p[i] = 0.f;
 
+    // (frozen: the forward ran BatchNorm on its running statistics -- no batch-mean / batch-variance terms: 1 / E := 0)
     const unsigned long long etot = *a.total;
-    const float invE = etot > 0 ? (float)(1.0 / (double)etot) : 0.f;
+    const float invE = (etot > 0 && !a.frozen) ? (float)(1.0 / (double)etot) : 0.f;
 
     // ---- operand registers
     float A1[TO1][KB1], bias1[TO1][4];      // bias of the first layer: inside the contraction in fp32, outside with bf16 operands
@@ -892,7 +893,7 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
     const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
     a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma;
     a.W1 = k1.W; a.b1 = k1.b; a.gamma1 = k1.gamma;
-    a.slots = training ? (PASS == 0 ? k0.stat_slots : k1.stat_slots) : nullptr;
+    a.slots = training == 1 ? (PASS == 0 ? k0.stat_slots : k1.stat_slots) : nullptr;     // (SN2_BN_FROZEN_KEEP: no sums wanted)
     a.ext = p->ext; a.arg = p->arg;
     a.al = k1.a; a.cl = k1.c; a.out = p->out;
     int blocks = sn2_cdiv((long)p->B * p->M, 16);          // one wave per quad of centroids, four waves per workgroup
@@ -904,7 +905,7 @@ int sa_mfma_launch_fwd(const sn2_sa* p, int training, hipStream_t st, int* nbloc
     if (blocks > sn2_cu_count() * occ) blocks = sn2_cu_count() * occ;
     if (nblocks_out) *nblocks_out = blocks;
     if constexpr (PASS == 1) {
-        if (!a.slots) {            // eval: the variant without the statistic sums
+        if (!training) {           // eval: the variant without the statistic sums and the arg-max slots
             if (bf16) hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, true, false>), dim3(blocks), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((sa_mfma_fwd_kernel<CF, NL, C1, C2, PASS, false, false>), dim3(blocks), dim3(256), 0, st, a);
             SN2_RETURN_LAUNCH();
@@ -931,6 +932,7 @@ int sa_mfma_launch_bwd(const sn2_sa* p, hipStream_t st) {
     a.group = sa_plot_group(p->B);
     const sn2_block& k0 = p->blk[0];
     const sn2_block& k1 = p->blk[NL == 2 ? 1 : 0];
+    a.frozen = (k0.frozen_stats || k1.frozen_stats) ? 1 : 0;      // (one forward pass = one mode for the module's blocks)
     a.W0 = k0.W; a.b0 = k0.b; a.a0 = k0.a; a.c0 = k0.c; a.gamma0 = k0.gamma; a.mean0 = k0.mean; a.invstd0 = k0.invstd;
     a.dgamma0 = k0.dgamma; a.dbeta0 = k0.dbeta;
     a.W1 = k1.W; a.b1 = k1.b; a.gamma1 = k1.gamma; a.mean1 = k1.mean; a.invstd1 = k1.invstd; a.dgamma1 = k1.dgamma;

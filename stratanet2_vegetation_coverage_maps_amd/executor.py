@@ -322,7 +322,7 @@ def _io(model, dev, training, flags, cloud=None, fps_start=None, fork=False):
     io.cloud = None if cloud is None else cloud.data_ptr()
     io.fps_start = None if fps_start is None else fps_start.data_ptr()
     io.fps_status = ops.fps_status_word(dev).data_ptr()
-    io.training = int(bool(training))
+    io.training = int(training) if training in (0, 1, 2) else int(bool(training))      # (2 = SN2_BN_FROZEN_KEEP)
     if fork:
         io.stream_b = ops.shared_stream(dev, "fork_b").cuda_stream
         io.stream_c = ops.shared_stream(dev, "fork_c").cuda_stream
@@ -370,12 +370,17 @@ def forward(model, ms, xyz, cloud, fps_start, training, geo=None, drop_keep=None
     plan = ms.plan(model, B, N)
     lib = _lib.load()
     fork = False
+    # eval mode with gradients wanted (torch's BatchNorm in eval under autograd, model/point_net2.py:45-53): the forward keeps what
+    # a training forward keeps, on the running statistics (SN2_BN_FROZEN_KEEP)
+    frozen = (not training) and bool(need_grad)
+    keep = bool(training) or frozen
+    mode = 1 if training else (_lib.BN_FROZEN_KEEP if frozen else 0)
     if geo is None:
         ops._chk(fps_start, I32, (2, B), "fps_start")
         geo = ArenaGeometry(plan, dev, model)
         fork = bool(model.geometry_fork)
         flags = _lib.NET_WITH_GEOMETRY | (_lib.NET_FORK if fork else 0)
-        geo.has_inverted = bool(training)
+        geo.has_inverted = keep
         fs = fps_start
     else:
         _check_handle(geo, plan, "prefetched geometry tables")
@@ -391,7 +396,7 @@ def forward(model, ms, xyz, cloud, fps_start, training, geo=None, drop_keep=None
     cg = geo_struct(geo)
     geo.xyz = xyz
     cg.xyz = xyz.data_ptr()
-    t = 1 if training else 0
+    t = 1 if keep else 0
     arena = torch.empty(plan.act_bytes[t], dtype=U8, device=dev)
     ca = NetAct()
     base = arena.data_ptr()
@@ -404,20 +409,21 @@ def forward(model, ms, xyz, cloud, fps_start, training, geo=None, drop_keep=None
         ops._chk(drop_keep, I32, (B * N,), "drop_mask")
         ca.drop_mask = drop_keep.data_ptr()
     bwd_arena = None
-    if training and need_grad:
+    if keep and need_grad:
         # the zero-filled arena of the backward pass that will follow: cleared by the forward's last kernel instead of a launch
         # of its own in front of that pass
         bwd_arena = torch.empty(plan.bwd_arena_words, dtype=F32, device=dev)
         ca.bwd_arena, ca.bwd_arena_words = bwd_arena.data_ptr(), plan.bwd_arena_words
-    io = _io(model, dev, training, flags, cloud=cloud, fps_start=fs, fork=fork)
+    io = _io(model, dev, mode, flags, cloud=cloud, fps_start=fs, fork=fork)
     if training and model.fuse_global_level:
         ws = ops.global_level_ws(dev, owner=model)
         io.gl_xchg, io.gl_ctl = ws[0].data_ptr(), ws[1].data_ptr()
     _lib.check(lib.sn2_net_forward(byref(ms.c), byref(plan.dims), byref(cg), byref(ca), byref(io), ops._stream()), "sn2_net_forward")
     geo.has_rows0 = True
-    if training:
+    if keep:
         geo.has_inverted = True
-    s = NetSaved(plan, geo, arena, ca, bool(training))
+    s = NetSaved(plan, geo, arena, ca, keep)              # (`training` of the saved set = which activation layout it has)
+    s.frozen = frozen
     s.drop_keep = drop_keep
     s.xyz = xyz
     s.ms = ms
@@ -450,6 +456,7 @@ def backward(model, s, dcov, dproba):
     defer = bool(getattr(model, "defer_grad_reduce", False))
     cb.defer_grad_reduce = int(defer)
     cb.arena_is_zero = int(pre_zeroed)
+    cb.frozen_stats = int(bool(s.__dict__.get("frozen", False)))
     _lib.check(lib.sn2_net_backward(byref(ms.c), byref(plan.dims), byref(geo_struct(s.geo)), byref(s.cact), byref(cb), ops._stream()),
                "sn2_net_backward")
     flat = arena[:ms.n_flat]

@@ -520,6 +520,7 @@ class BlockBuffers:
         self.grads = None                                                 # (dW, db, dgamma, dbeta) views, set per backward
         self.grad_images = (1, 0)                                         # (replicas, stride in floats) of dW / db
         self.mma_bf16 = False                                             # bfloat16 operands on the matrix cores (sn2_block.mma_bf16)
+        self.frozen = False                                               # the forward ran on the running statistics (sn2_block.frozen_stats)
 
     def fill(self, blk: Block, with_grads: bool = False):
         for t, n in ((self.lin.weight, "weight"), (self.lin.bias, "bias"), (self.bn.weight, "bn.weight"),
@@ -528,6 +529,7 @@ class BlockBuffers:
             _chk(t, F32, None, n)
         blk.cin, blk.cout = self.cin, self.cout
         blk.mma_bf16 = int(bool(self.mma_bf16))
+        blk.frozen_stats = int(bool(self.frozen))
         blk.W, blk.b = _ptr(self.lin.weight), _ptr(self.lin.bias)
         blk.gamma, blk.beta = _ptr(self.bn.weight), _ptr(self.bn.bias)
         blk.running_mean, blk.running_var = _ptr(self.bn.running_mean), _ptr(self.bn.running_var)

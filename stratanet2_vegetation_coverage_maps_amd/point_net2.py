@@ -27,7 +27,7 @@ from torch.nn import Sequential as Seq
 
 from . import executor as X
 from . import hip_ops as ops
-from ._lib import MAX_NEIGHBORS as _MAXN, STAT_SLOTS, StrataHipError
+from ._lib import BN_FROZEN_KEEP, MAX_NEIGHBORS as _MAXN, STAT_SLOTS, StrataHipError
 
 MAX_NEIGHBORS = _MAXN      # radius(..., max_num_neighbors=2000), model/point_net2.py:24 (tests lower it by monkeypatching)
 
@@ -98,7 +98,8 @@ class _PointNet2Fn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[6:])   # grad mode is off inside Function.forward; this is the reliable test
         cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training, geo, drop_keep, need_grad=need_grad)
         ctx.model = model
-        saved.training = training
+        if not isinstance(saved, X.NetSaved):
+            saved.training = training
         ctx.saved = saved if need_grad else None
         ctx.n_params = len(params)
         return cov, proba
@@ -107,11 +108,9 @@ class _PointNet2Fn(torch.autograd.Function):
     def backward(ctx, dcov, dproba):
         if ctx.saved is None:
             raise RuntimeError("PointNet2: backward through a forward that recorded no graph")
-        if not ctx.saved.training:
-            # the backward kernels implement the BATCH-statistics BatchNorm gradient; after an eval-mode forward the right
-            # gradient is the running-statistics one (a*dy), which they do not compute: refuse instead of being wrong
-            raise RuntimeError("PointNet2: backward through an eval-mode forward is not supported by the HIP kernels "
-                               "(call model.train() for the forward pass whose gradients you need)")
+        # (after an eval-mode forward -- BatchNorm on its running statistics, model/point_net2.py:45-53 -- the gradient is the
+        # running-statistics one, gamma * invstd * dy: the forward kept what a training forward keeps and marked its blocks
+        # `frozen`, sn2_block.frozen_stats; round 5)
         grads = ctx.model._backward_impl(ctx.saved, dcov, dproba)
         ctx.saved = None
         return (None, None, None, None, None, None) + tuple(grads)
@@ -250,7 +249,8 @@ class PointNet2(nn.Module):
         start = torch.cuda.Event()
         start.record(cur)
         xyz_d, fs = self._stage_positions(cloud_data, dev, ring=ring)
-        g = self._geometry(xyz_d, fs, defer_join=True, inverted=self.training)       # launched: the device is busy from here on
+        # (the inverted tables: whenever a backward pass may follow -- training, or eval mode under autograd)
+        g = self._geometry(xyz_d, fs, defer_join=True, inverted=self.training or torch.is_grad_enabled())     # launched: the device is busy from here on
         up = ops.shared_stream(dev, "upload")
         up.wait_event(start)                                                          # not for the geometry pass: only for the block's past
         ring.upload(cloud, stream=up, dtype=F32, out=cloud_d, consumer=cur)            # host memcpy + DMA beside the geometry pass
@@ -623,6 +623,10 @@ class PointNet2(nn.Module):
         B, _, N = xyz.shape
         M1, M2 = self._sizes(N)
         cur_stream = torch.cuda.current_stream(dev)
+        # eval mode with gradients wanted: everything a training forward keeps, on the running statistics (SN2_BN_FROZEN_KEEP)
+        frozen = (not training) and bool(need_grad)
+        keep = bool(training) or frozen
+        mode = 1 if training else (BN_FROZEN_KEEP if frozen else 0)
         rows0, packed = None, None
         if geo is not None and getattr(geo, "has_rows0", False) and geo.rows0.shape[0] == B * N:
             rows0 = geo.rows0                    # packed by the geometry pass (`_input_only`)
@@ -636,15 +640,21 @@ class PointNet2(nn.Module):
                     ops.pack_rows(cloud, xyz, out=rows0)
                     packed = torch.cuda.Event()
                     packed.record(pack_stream)
-            geo = self._geometry(xyz, fps_start, defer_join=True, inverted=training)
+            geo = self._geometry(xyz, fps_start, defer_join=True, inverted=keep)
         elif (geo.B, geo.N, geo.M1, geo.M2) != (B, N, M1, M2):
             raise ValueError("prefetched geometry does not match this batch")
         join = getattr(geo, "_join", None)
         geo._join = None
         if join == "ctx":
             raise StrataHipError("a geometry pass launched by the executor with a deferred join must be consumed by the executor")
-        if training and not getattr(geo, "has_inverted", True):
-            # tables prefetched in eval mode, forward in training mode: the backward pass needs the inverted indices
+        if keep and not getattr(geo, "has_inverted", True):
+            # tables prefetched in eval mode, forward in training mode: the backward pass needs the inverted indices -- of 3-NN
+            # tables that a pass with a deferred join is still writing on its side streams (round 5: joined here first; at the
+            # metric's size the indices were built from tables half written)
+            if join is not None:
+                cur_stream.wait_stream(join[0])
+                cur_stream.wait_stream(join[1])
+                join = None
             ops.interp_index(geo.knn3, B, M2, 1, out=geo.inv3)
             ops.interp_index(geo.knn2, B, M1, M2, out=geo.inv2)
             ops.interp_index(geo.knn1, B, N, M1, out=geo.inv1, src_pos=geo.pos1_aos, row_perm=getattr(geo, "rank1", None))
@@ -667,6 +677,8 @@ class PointNet2(nn.Module):
         s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur, bf("fp2_module.nn"))[0]
         s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
         s.aux, s.stats = aux, stats
+        for bb in s.b_sa1 + s.b_sa2 + [s.b_sa3, s.b_fp3, s.b_fp2, s.b_fp1]:
+            bb.frozen = frozen
 
         # ---- level 0 rows: [8 features | x y z 0]
         if packed is not None:
@@ -680,14 +692,14 @@ class PointNet2(nn.Module):
         s.ext1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
         s.arg1 = torch.empty(B * M1, 16, dtype=I32, device=dev)
         s.x1 = torch.empty(B * M1, 16, dtype=F32, device=dev)
-        ops.sa_forward(self._sa1_desc(s), training)
+        ops.sa_forward(self._sa1_desc(s), mode)
         if join is not None:
             cur_stream.wait_stream(join[0])      # chain b of the forked geometry pass: level-2 tables, small 3-NN tables
         # ---- SA2: MLP[19,32]                                                     (:132)
         s.ext2 = torch.empty(B * M2, 32, dtype=F32, device=dev)
         s.arg2 = torch.empty(B * M2, 32, dtype=I32, device=dev)
         s.x2 = torch.empty(B * M2, 32, dtype=F32, device=dev)
-        ops.sa_forward(self._sa2_desc(s), training)
+        ops.sa_forward(self._sa2_desc(s), mode)
         # ---- SA3: MLP[35,64] on cat[x2, pos2] -> per-plot max                    (:133, 37-42)
         s.h_sa3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
         s.h3 = torch.empty(B * M2, 64, dtype=F32, device=dev)
@@ -697,20 +709,20 @@ class PointNet2(nn.Module):
             s.arg3 = torch.empty(B, 64, dtype=I32, device=dev)
             ops.global_level_forward(self._sa3_desc(s), self._fp3_desc(s), s.x3, s.arg3, owner=self)
         else:
-            ops.fp_forward(self._sa3_desc(s), training)
+            ops.fp_forward(self._sa3_desc(s), mode)
             s.x3, s.arg3 = ops.plot_max_forward(s.h_sa3, s.b_sa3.a, s.b_sa3.c, B, M2, 64)
             # ---- FP3 (k=1 from the plot's global feature at the origin), FP2, FP1 (k=3)   (:137-139, 62-67)
-            ops.fp_forward(self._fp3_desc(s), training)
+            ops.fp_forward(self._fp3_desc(s), mode)
         if self.log_embeddings:
             self.last_G_tensor = s.x3
         s.h2 = torch.empty(B * M1, 36, dtype=F32, device=dev)
-        ops.fp_forward(self._fp2_desc(s), training)
+        ops.fp_forward(self._fp2_desc(s), mode)
         if join is not None:
             cur_stream.wait_stream(join[1])      # chain c: the per-point 3-NN table and its inverted index
         cov = torch.empty(B * N, 4, dtype=F32, device=dev)
         proba = torch.empty(B * N, 4, dtype=F32, device=dev)
         s.drop_keep = drop_keep
-        if not training and self.fuse_eval_head and self._act_dtype(B * N) == F32 and ops.SOURCE_SIDE:
+        if not keep and self.fuse_eval_head and self._act_dtype(B * N) == F32 and ops.SOURCE_SIDE:
             # EVAL: FP1 and the head (:139-151) in one pass, the (B*N,36) rows of h1 never reach memory (nothing is kept for a backward)
             s.h1 = None
             d1 = ops.fp_desc(s.b_fp1, B, N, M1, 34, 8, s.h2, None, src_affine=(s.b_fp2.a, s.b_fp2.c), knn=s.knn1,
@@ -718,7 +730,7 @@ class PointNet2(nn.Module):
             ops.fp_head_eval(d1, ops.head_desc(None, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, rows=B * N))
             return cov, proba, s
         s.h1 = torch.empty(B * N, 36, dtype=self._act_dtype(B * N), device=dev)
-        ops.fp_forward(self._fp1_desc(s), training)
+        ops.fp_forward(self._fp1_desc(s), mode)
         # ---- head                                                                  (:141-151)
         ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, drop_mask=drop_keep,
                                        drop_p=self.drop))

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import hip_ops as ops
-from ._lib import STAT_SLOTS
+from ._lib import BN_FROZEN_KEEP, STAT_SLOTS
 from . import point_net2 as _p2
 from .point_net2 import (F32, I32, I64, MLP, FPModule, GlobalSAModule, PointNet2, SAModule, _blocks_of, _Saved)
 
@@ -230,11 +230,15 @@ class PointNet2ThreeSA(PointNet2):
         dev = xyz.device
         B, _, N = xyz.shape
         M1, M2, M3 = self._sizes3(N)
+        # eval mode with gradients wanted: what a training forward keeps, on the running statistics (PointNet2._forward_impl)
+        frozen = (not training) and bool(need_grad)
+        keep = bool(training) or frozen
+        mode = 1 if training else (BN_FROZEN_KEEP if frozen else 0)
         if geo is None:
-            geo = self._geometry(xyz, fps_start, inverted=training)
+            geo = self._geometry(xyz, fps_start, inverted=keep)
         elif (geo.B, geo.N, geo.M1, geo.M2, geo.M3) != (B, N, M1, M2, M3):
             raise ValueError("prefetched geometry does not match this batch")
-        if training and not getattr(geo, "has_inverted", True):
+        if keep and not getattr(geo, "has_inverted", True):
             # tables prefetched in eval mode, forward in training mode: the backward pass needs the inverted indices
             self._inverted_tables(geo)
             geo.has_inverted = True
@@ -256,30 +260,32 @@ class PointNet2ThreeSA(PointNet2):
         s.b_fp2 = _blocks_of(self.fp2_module.nn, aux, stats, cur, bf("fp2_module.nn"))[0]
         s.b_fp1 = _blocks_of(self.fp1_module.nn, aux, stats, cur)[0]
         s.aux, s.stats = aux, stats
+        for bb in s.b_sa1 + s.b_sa2 + s.b_sa3 + [s.b_sa4, s.b_fp4, s.b_fp3, s.b_fp2, s.b_fp1]:
+            bb.frozen = frozen
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)          # noqa: E731
         if getattr(geo, "has_rows0", False) and geo.rows0.shape[0] == B * N:
             s.rows0 = geo.rows0                   # packed by the geometry pass (PointNet2._input_only)
         else:
             s.rows0 = ops.pack_rows(cloud, xyz)
         s.ext1, s.arg1, s.x1 = e(B * M1, 16), e(B * M1, 16, dt=I32), e(B * M1, 16)
-        ops.sa_forward(self._sa1_desc(s), training)
+        ops.sa_forward(self._sa1_desc(s), mode)
         s.ext2, s.arg2, s.x2 = e(B * M2, 32), e(B * M2, 32, dt=I32), e(B * M2, 32)
-        ops.sa_forward(self._sa2_desc(s), training)
+        ops.sa_forward(self._sa2_desc(s), mode)
         s.ext3, s.arg3l, s.x3 = e(B * M3, 64), e(B * M3, 64, dt=I32), e(B * M3, 64)
-        ops.sa_forward(self._sa3l_desc(s), training)
+        ops.sa_forward(self._sa3l_desc(s), mode)
         s.h_sa4 = e(B * M3, 64)
-        ops.fp_forward(self._sa4_desc(s), training)
+        ops.fp_forward(self._sa4_desc(s), mode)
         s.xg, s.argg = ops.plot_max_forward(s.h_sa4, s.b_sa4.a, s.b_sa4.c, B, M3, 64)
         if self.log_embeddings:
             self.last_G_tensor = s.xg
         s.h4 = e(B * M3, 64)
-        ops.fp_forward(self._fp4_desc(s), training)
+        ops.fp_forward(self._fp4_desc(s), mode)
         s.h3 = e(B * M2, 64)
-        ops.fp_forward(self._fp3_desc(s), training)
+        ops.fp_forward(self._fp3_desc(s), mode)
         s.h2 = e(B * M1, 36)
-        ops.fp_forward(self._fp2_desc(s), training)
+        ops.fp_forward(self._fp2_desc(s), mode)
         s.h1 = torch.empty(B * N, 36, dtype=self._act_dtype(B * N), device=dev)
-        ops.fp_forward(self._fp1_desc(s), training)
+        ops.fp_forward(self._fp1_desc(s), mode)
         cov, proba = e(B * N, 4), e(B * N, 4)
         s.drop_keep = drop_keep
         ops.head_forward(ops.head_desc(s.h1, s.b_fp1.a, s.b_fp1.c, self.lin1, self.lin2, cov, proba, drop_mask=drop_keep,

@@ -35,6 +35,36 @@ def test_3sa_forward_backward_vs_oracle(B, N, ratio1):
     assert not fails, "\n".join(fails)
 
 
+def test_3sa_backward_through_an_eval_forward_vs_oracle():
+    """model.eval() with autograd on (tests/test_gpu_network.py::test_backward_through_an_eval_forward_vs_oracle), the variant."""
+    B, N = 2, 4096
+    args = make_args(cuda=0, subsample_size=N, ratio1=0.125, r1=1.0, ratio2=0.25, r2=2.0, ratio3=0.25, r3=4.0)
+    d = make_batch(B, N, first_plot=520)
+    g = torch.Generator().manual_seed(4)
+    sd = network.init_state_dict_3sa(2)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    fs = torch.stack([torch.arange(B) * 5 % N, torch.arange(B) % 7, torch.zeros(B, dtype=torch.long)])
+    d["fps_start"] = fs
+    m = PointNet2ThreeSA(args)
+    m.load_state_dict(sd)
+    m.eval()
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cov, proba = m(d)
+    pred = project_to_plotwise_coverages(cov, d["cloud"], args, model=m)
+    loss, _ = losses.total_loss(pred, proba, d["coverages"].cuda(), d["pdf_all"].cuda(), args.m, args.e)
+    loss.backward()
+    ref = check.train_step(sd, d, args, fps_start=fs, arch="3sa", training=False)
+    fails, report = check.compare(m, cov, proba, loss.item(), ref, pred=pred, tol_grad=2e-3)
+    print(f"\n[3sa {B} x {N}] eval-mode step vs the fp64 oracle:\n  {report}")
+    assert not fails, "\n".join(fails)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), f"{k} changed in an eval-mode step"
+
+
 @pytest.mark.parametrize("pair", [False, True, 4])
 def test_3sa_in_the_pipelined_loop_matches_the_plain_loop(pair):
     """`bench.py --arch 3sa` drives this model through TrainPipeline (geometry passes on side streams -- one per batch, or one
