@@ -49,6 +49,10 @@ int sn2_debug_spin(int blocks, long long clocks, int *out, void *stream);
 /* diagnostic (bench.py's roofline record): which kernels of the per-point layer's source-side backward sn2_fp_backward launches --
  * bit 0 the row pass, 1 the source pass, 2 the merge; 7 (default; 0 = back to it) = all, the only setting that yields gradients */
 int sn2_debug_fp1_backward_parts(int mask);
+/* test hook: which row pass the source-side FORWARD of the per-point layer launches -- 1 (default) the form whose input stream is
+ * fetched one element per lane, four iterations ahead (fp_fwd_rows2_kernel, round 5), 0 the first form (every lane of a row loads
+ * the row's inputs itself); the two must give the same bits */
+int sn2_debug_fp_rows_form(int form);
 #define SN2_PROBE_SINK_WORDS 4096
 int sn2_debug_stream_probe(const float *src, float *dst, size_t n_floats, int mode, float *sink, void *stream);
 int sn2_debug_mfma_probe(int mode, int iters, float *sink, double *flops, void *stream);

@@ -733,6 +733,53 @@ __global__ __launch_bounds__(256) void fp_src_table_kernel(int n_src, int src_st
     }
 }
 
+// The interpolated part of a pre-activation, in ONE spelled-out order of operations -- fma(fma(fma(c, w2, fma(b, w1, a w0)) ...:
+//   s = a w0;  s = fma(b, w1, s);  s = fma(c, w2, s);  acc = fma(s, 1 / sum w, bias)
+// Left to the compiler's contraction, the two row passes below (same source text) fused different products and differed in the
+// last bit of every fourth column.  fp_fwd_rows2_kernel issues the same operations two channels at a time (v_pk_mul_f32 /
+// v_pk_fma_f32: IEEE per component, the same bits).
+__device__ __forceinline__ float interp_bias(float a, float b, float c, float w0, float w1, float w2, float inv, float bias) {
+    float s2;
+    {
+#pragma clang fp contract(off)
+        s2 = a * w0;
+    }
+    s2 = fmaf(b, w1, s2);
+    s2 = fmaf(c, w2, s2);
+    return fmaf(s2, inv, bias);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 interp_bias2(f32x2 a, f32x2 b, f32x2 c, float w0, float w1, float w2, float inv, f32x2 bias) {
+    f32x2 s2;
+    {
+#pragma clang fp contract(off)
+        s2 = a * (f32x2){w0, w0};
+    }
+    s2 = __builtin_elementwise_fma(b, (f32x2){w1, w1}, s2);
+    s2 = __builtin_elementwise_fma(c, (f32x2){w2, w2}, s2);
+    return __builtin_elementwise_fma(s2, (f32x2){inv, inv}, bias);
+}
+// Which iterations (FP_ROWS_PER_IT consecutive rows each) a wave of the row kernels works on: it0, it0 + stride, ... < it_hi.
+// Workgroups go to the XCDs round-robin (blockIdx % 8), and the iterations are dealt the same way when they go wave after wave --
+// every XCD's L2 then holds the table rows of ALL plots (2.4 MB of a 4 MB L2 at config 2) beside the rows streaming through it.
+// With the grid a multiple of 8, XCD x takes the x-th EIGHTH of the rows instead (whole plots where the batch is a multiple of
+// eight plots): its L2 holds an eighth of the table.
+struct RowIters {
+    int it0, stride, it_hi;
+};
+__device__ __forceinline__ RowIters row_iters(int n_it, int wave) {
+    RowIters r;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, wg_x = blockIdx.x >> 3, n_wg_x = gridDim.x >> 3;
+        const int lo = (int)((long)n_it * xcd / 8);
+        r.it_hi = (int)((long)n_it * (xcd + 1) / 8);
+        r.stride = n_wg_x * 4;
+        r.it0 = lo + wg_x * 4 + wave;
+    } else {
+        r.it_hi = n_it, r.stride = (int)gridDim.x * 4, r.it0 = (int)blockIdx.x * 4 + wave;
+    }
+    return r;
+}
 // what a (row, quad) lane of the row kernels reads ahead of its gathers: the row's 3-NN entry and skip columns
 template <int QB>
 struct FpRowIn {
@@ -777,9 +824,12 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
         for (int k = 0; k < CB; ++k) wB[t][k] = o < CO ? Wg[o * CI + CA + k] : 0.f;
     }
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-    const long n_grp = ((long)R + G - 1) / G;
-    const long n_waves = (long)gridDim.x * 4;
-    long grp0 = ((long)blockIdx.x * 4 + wave) * U;
+    // (a wave's turn = U groups of G rows = one "iteration" of row_iters)
+    const RowIters ri = row_iters((int)(((long)R + G * U - 1) / (G * U)), wave);
+    const long n_grp_all = ((long)R + G - 1) / G;
+    const long n_grp = n_grp_all < (long)ri.it_hi * U ? n_grp_all : (long)ri.it_hi * U;
+    const long n_waves = ri.stride;
+    long grp0 = (long)ri.it0 * U;
     // the 3-NN entries and skip columns run one iteration ahead of the gathers that depend on them
     FpRowIn<QB> nx[U];
 #pragma unroll
@@ -791,9 +841,16 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
         for (int u = 0; u < U; ++u) {
             in[u] = nx[u];
             const unsigned base = (in[u].rr / (unsigned)R_per_plot) * (unsigned)S_per_plot;
+#if defined(SN2_FR_DIAG) && (SN2_FR_DIAG & 2)
+            // (diagnostic: no table gathers -- values made from the indices)
+            ta[u][0] = make_float4((float)(base + in[u].i0), 1.f, 2.f, 3.f);
+            ta[u][1] = make_float4((float)in[u].i1, 1.f, 2.f, 3.f);
+            ta[u][2] = make_float4((float)in[u].i2, 1.f, 2.f, 3.f);
+#else
             ta[u][0] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i0) * HS)[q];
             ta[u][1] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i1) * HS)[q];
             ta[u][2] = reinterpret_cast<const float4*>(T + (size_t)(base + in[u].i2) * HS)[q];
+#endif
         }
         const long grp1 = grp0 + n_waves * U;
 #pragma unroll
@@ -803,11 +860,14 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
             const float w0 = in[u].w0, w1 = in[u].w1, w2 = in[u].w2;
             const float inv = 1.0f / ((w0 + w1) + w2);
             const float4 a = ta[u][0], b = ta[u][1], c = ta[u][2];
-            float v[4] = {((a.x * w0 + b.x * w1) + c.x * w2) * inv, ((a.y * w0 + b.y * w1) + c.y * w2) * inv,
-                          ((a.z * w0 + b.z * w1) + c.z * w2) * inv, ((a.w * w0 + b.w * w1) + c.w * w2) * inv};
+            float v[4] = {interp_bias(a.x, b.x, c.x, w0, w1, w2, inv, b4[0]), interp_bias(a.y, b.y, c.y, w0, w1, w2, inv, b4[1]),
+                          interp_bias(a.z, b.z, c.z, w0, w1, w2, inv, b4[2]), interp_bias(a.w, b.w, c.w, w0, w1, w2, inv, b4[3])};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float acc = v[t] + b4[t];
+                float acc = v[t];
+#if defined(SN2_FR_DIAG) && (SN2_FR_DIAG & 4)
+                acc += in[u].sk[0].x + in[u].sk[QB - 1].w;          // (diagnostic: no skip contraction)
+#else
 #pragma unroll
                 for (int b2 = 0; b2 < QB; ++b2) {
                     acc = fmaf(wB[t][4 * b2 + 0], in[u].sk[b2].x, acc);
@@ -815,13 +875,18 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
                     acc = fmaf(wB[t][4 * b2 + 2], in[u].sk[b2].z, acc);
                     acc = fmaf(wB[t][4 * b2 + 3], in[u].sk[b2].w, acc);
                 }
+#endif
                 acc = (in[u].valid && 4 * q + t < CO) ? fmaxf(acc, 0.f) : 0.f;
                 if constexpr (BF) acc = bf16_round(acc);     // the batch statistics describe the rows as they are stored
                 ssum[t] += acc;
                 ssq[t] = fmaf(acc, acc, ssq[t]);
                 v[t] = acc;
             }
+#if defined(SN2_FR_DIAG) && (SN2_FR_DIAG & 1)
+            if (in[u].valid && v[0] == 12345.678f) row_quad_st<BF>(h, in[u].rr, HS, q, v[0], v[1], v[2], v[3]);   // (diagnostic: no stores)
+#else
             if (in[u].valid) row_quad_st<BF>(h, in[u].rr, HS, q, v[0], v[1], v[2], v[3]);
+#endif
         }
     }
     if (!slots) return;
@@ -830,6 +895,203 @@ __global__ __launch_bounds__(256) void fp_fwd_rows_kernel(int R, int R_per_plot,
     for (int t = 0; t < 4; ++t) {
         s_part[t][threadIdx.x] = on ? ssum[t] : 0.f;
         s_part[4 + t][threadIdx.x] = on ? ssq[t] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * CO; e += 256) {
+        const int which = e / CO, c = e - which * CO, cq = c >> 2, ct = c & 3;
+        float acc = 0.f;
+        for (int w = 0; w < 4; ++w)
+            for (int gg = 0; gg < G; ++gg) acc += s_part[which * 4 + ct][w * 64 + cq + QH * gg];
+        slots[(size_t)blockIdx.x * 2 * CO + e] = acc;
+    }
+}
+
+// The same row pass with its INPUT STREAM decoupled from the lanes that consume it (round 5).  fp_fwd_rows_kernel's nine lanes of a
+// row each load the row's 3-NN entry and skip columns themselves, one iteration ahead: 16 registers per row and stage, so one
+// stage is all that fits, and a wave's iteration (14 rows, ~0.3 us of arithmetic) then waits out a memory round trip (~1 us):
+// with every load and store but these switched off the kernel still took 18 us for 29 MB (scripts/time_fp1.py; 2048 waves x
+// 784 B in flight = 1.6 MB: Little's law).  Here a wave fetches an iteration's 42 indices, 42 weights and 14 x QB skip quads
+// with ONE element per lane (three load instructions, six registers per stage), FP_ROWS_PD iterations ahead, hands them to the
+// (row, quad) lanes through a wave-private LDS region, and asks for the NEXT iteration's table rows before it computes the
+// current one.  Same rows per wave, same lane mapping, same arithmetic in the same order as fp_fwd_rows_kernel: same bits,
+// statistics slots included.
+#ifndef SN2_FR_PD
+#define SN2_FR_PD 2       // (2 / 4 / 6 stages: FP1's forward entry 41.1 / 42.3 / 44.5 us at config 2 -- more in flight is not faster here)
+#endif
+#ifndef SN2_FR_OCC
+#define SN2_FR_OCC 2
+#endif
+constexpr int FP_ROWS_PD = SN2_FR_PD;
+template <class F, int... I>
+__device__ __forceinline__ void for_each_stage(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int CA, int CB, int CO, bool BF>
+__global__ __launch_bounds__(256, SN2_FR_OCC) void fp_fwd_rows2_kernel(int R, int R_per_plot, int S_per_plot, int skip_stride,
+                                                              const float* __restrict__ T, const int* __restrict__ knn_idx,
+                                                              const float* __restrict__ knn_w, const float* __restrict__ skip,
+                                                              const float* __restrict__ Wg, const float* __restrict__ biasg,
+                                                              float* __restrict__ h, float* __restrict__ slots) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 2, RPI = G * U, PD = FP_ROWS_PD;
+    static_assert(CB > 0 && CB % 4 == 0, "skip quads");
+    static_assert(3 * RPI <= 64 && RPI * QB <= 64, "an iteration's inputs are one element per lane");
+    static_assert(PD % 2 == 0, "the two exchange regions alternate over the stages");
+    constexpr int LW = 3 * RPI + 3 * RPI + 4 * RPI * QB;                  // words of an exchange region: idx | w | skip quads
+    constexpr int LWP = (LW + 3) / 4 * 4;
+    static_assert((6 * RPI) % 4 == 0, "the skip quads start 16-byte aligned");
+    __shared__ float s_part[8][256];
+    __shared__ __attribute__((aligned(16))) float s_x[4][2][LWP];         // per wave: two regions (this iteration's, the next one's)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % QH, g = lane / QH;
+    const bool on = lane < G * QH;
+    // channel PAIRS (4 q + 2 pr, + 1): the skip weights, the bias and the statistics, for the packed fp32 instructions
+    f32x2 wB[2][CB], b4[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int o = 4 * q + 2 * pr + e;
+            b4[pr][e] = o < CO ? biasg[o] : 0.f;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) wB[pr][k][e] = o < CO ? Wg[o * CI + CA + k] : 0.f;
+        }
+    f32x2 ssum[2] = {{0.f, 0.f}, {0.f, 0.f}}, ssq[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const int n_it_all = (R + RPI - 1) / RPI;                              // iterations: RPI consecutive rows each (3 R < 2^31)
+    const RowIters ri = row_iters(n_it_all, wave);
+    const int n_it = ri.it_hi, n_waves = ri.stride, it0 = ri.it0;          // this wave's iterations: it0 + k n_waves < n_it
+    // ---- the input stream: one element per lane and stage
+    typedef float f32x4 __attribute__((ext_vector_type(4)));              // (an array of HIP's float4 STRUCT stayed in scratch memory)
+    int p_idx[PD];
+    float p_w[PD];
+    f32x4 p_sk[PD];
+    // (every load of the steady state is UNCONDITIONAL, its address clamped into the arrays: a branch around a load makes the
+    // compiler's count of outstanding memory operations unknown and it answers with s_waitcnt vmcnt(0) -- the first version of this
+    // kernel drained its whole pipeline 24 times per unrolled body and ran 2 us faster than the kernel it replaces, not 10)
+    const int last_e = 3 * R - 1, last_it = n_it - 1;
+    const int lane_e = lane < 3 * RPI ? lane : 3 * RPI - 1, lane_s = lane < RPI * QB ? lane : RPI * QB - 1;
+    auto fetch = [&](auto S, int it) {
+        constexpr int s = decltype(S)::value;            // (a run-time stage index left the stage registers in scratch memory)
+        const int itc = it < last_it ? it : last_it;
+        const int e0 = itc * (3 * RPI) + lane_e, e = e0 < last_e ? e0 : last_e;
+        p_idx[s] = knn_idx[e];
+        p_w[s] = knn_w[e];
+        const int rs0 = itc * RPI + lane_s / QB, rs = rs0 < R ? rs0 : R - 1;
+        p_sk[s] = reinterpret_cast<const f32x4*>(skip + (size_t)rs * skip_stride)[lane_s % QB];
+    };
+    // stage s -> exchange region `buf`; the (row, quad) lanes read their rows' indices back and ask for the table rows
+    auto hand_over = [&](auto S, int buf, int it, float4 (&ta)[U][3]) {
+        constexpr int s = decltype(S)::value;
+        float* xw = s_x[wave][buf];
+        xw[lane_e] = __int_as_float(p_idx[s]);                             // (the surplus lanes hold a copy of the last element)
+        xw[3 * RPI + lane_e] = p_w[s];
+        reinterpret_cast<f32x4*>(xw + 6 * RPI)[lane_s] = p_sk[s];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rl = on ? G * u + g : 0;                              // row of the iteration
+            const int row = it * RPI + rl;
+            const bool valid = on && row < R && it < n_it;
+            const unsigned rr = valid ? (unsigned)row : 0u;
+            const int i0 = valid ? __float_as_int(xw[3 * rl + 0]) : 0, i1 = valid ? __float_as_int(xw[3 * rl + 1]) : 0,
+                      i2 = valid ? __float_as_int(xw[3 * rl + 2]) : 0;
+            const unsigned base = (rr / (unsigned)R_per_plot) * (unsigned)S_per_plot;
+#if defined(SN2_FR_DIAG) && (SN2_FR_DIAG & 2)
+            ta[u][0] = make_float4((float)(base + i0), 1.f, 2.f, 3.f);      // (diagnostic: no table gathers)
+            ta[u][1] = make_float4((float)i1, 1.f, 2.f, 3.f);
+            ta[u][2] = make_float4((float)i2, 1.f, 2.f, 3.f);
+#else
+            ta[u][0] = reinterpret_cast<const float4*>(T + (size_t)(base + i0) * HS)[q];
+            ta[u][1] = reinterpret_cast<const float4*>(T + (size_t)(base + i1) * HS)[q];
+            ta[u][2] = reinterpret_cast<const float4*>(T + (size_t)(base + i2) * HS)[q];
+#endif
+        }
+    };
+    auto compute = [&](int buf, int it, const float4 (&ta)[U][3]) {
+        const float* xw = s_x[wave][buf];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rl = on ? G * u + g : 0;
+            const int row = it * RPI + rl;
+            const bool valid = on && row < R && it < n_it;
+            const float w0 = xw[3 * RPI + 3 * rl + 0], w1 = xw[3 * RPI + 3 * rl + 1], w2 = xw[3 * RPI + 3 * rl + 2];
+            float4 sk[QB];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) sk[b] = reinterpret_cast<const float4*>(xw + 6 * RPI)[rl * QB + b];
+            const float inv = 1.0f / ((w0 + w1) + w2);
+            const float4 a = ta[u][0], b = ta[u][1], c = ta[u][2];
+            const f32x2 a2[2] = {{a.x, a.y}, {a.z, a.w}}, b2[2] = {{b.x, b.y}, {b.z, b.w}}, c2[2] = {{c.x, c.y}, {c.z, c.w}};
+            float v[4];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x2 acc = interp_bias2(a2[pr], b2[pr], c2[pr], w0, w1, w2, inv, b4[pr]);
+#if defined(SN2_FR_DIAG) && (SN2_FR_DIAG & 4)
+                acc += (f32x2){sk[0].x + sk[QB - 1].w, sk[0].x};             // (diagnostic: no skip contraction)
+#else
+#pragma unroll
+                for (int k4 = 0; k4 < QB; ++k4) {
+                    acc = __builtin_elementwise_fma(wB[pr][4 * k4 + 0], (f32x2){sk[k4].x, sk[k4].x}, acc);
+                    acc = __builtin_elementwise_fma(wB[pr][4 * k4 + 1], (f32x2){sk[k4].y, sk[k4].y}, acc);
+                    acc = __builtin_elementwise_fma(wB[pr][4 * k4 + 2], (f32x2){sk[k4].z, sk[k4].z}, acc);
+                    acc = __builtin_elementwise_fma(wB[pr][4 * k4 + 3], (f32x2){sk[k4].w, sk[k4].w}, acc);
+                }
+#endif
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float x = (valid && 4 * q + 2 * pr + e < CO) ? fmaxf(acc[e], 0.f) : 0.f;
+                    if constexpr (BF) x = bf16_round(x);     // the batch statistics describe the rows as they are stored
+                    acc[e] = x;
+                    v[2 * pr + e] = x;
+                }
+                ssum[pr] += acc;
+                ssq[pr] = __builtin_elementwise_fma(acc, acc, ssq[pr]);
+            }
+#if defined(SN2_FR_DIAG) && (SN2_FR_DIAG & 1)
+            if (valid && v[0] == 12345.678f) row_quad_st<BF>(h, (size_t)row, HS, q, v[0], v[1], v[2], v[3]);   // (diagnostic: no stores)
+#else
+            if (valid) row_quad_st<BF>(h, (size_t)row, HS, q, v[0], v[1], v[2], v[3]);
+#endif
+        }
+    };
+    // this wave's iterations, rounded up to whole blocks of PD: the surplus ones have no valid row (nothing stored, zeros added to
+    // the statistics) and keep the loop body free of branches
+    const int n_mine = it0 < n_it ? (n_it - it0 + n_waves - 1) / n_waves : 0;
+    const int n_blocks = (n_mine + PD - 1) / PD;
+    if (n_blocks > 0) {
+        using S0 = std::integral_constant<int, 0>;
+        using Stages = std::make_integer_sequence<int, PD>;
+        for_each_stage([&](auto S) { fetch(S, it0 + decltype(S)::value * n_waves); }, Stages{});
+        float4 ta_a[U][3], ta_b[U][3];
+        hand_over(S0{}, 0, it0, ta_a);
+        fetch(S0{}, it0 + PD * n_waves);
+        // the stage of an iteration is its count modulo PD; exchange region and table-row set = its parity.  One step: hand over the
+        // NEXT iteration's inputs (its table rows are then on their way), refill that stage, compute THIS iteration
+        auto step = [&](auto S, int kb) {
+            constexpr int st = decltype(S)::value;
+            using SN = std::integral_constant<int, (st + 1) % PD>;
+            const int it = it0 + (kb * PD + st) * n_waves, itn = it + n_waves;
+            if constexpr (st % 2 == 0) {
+                hand_over(SN{}, 1, itn, ta_b);
+                fetch(SN{}, itn + PD * n_waves);
+                compute(0, it, ta_a);
+            } else {
+                hand_over(SN{}, 0, itn, ta_a);
+                fetch(SN{}, itn + PD * n_waves);
+                compute(1, it, ta_b);
+            }
+            // (this iteration's reads of its region lie in front of the hand-over that refills it, two iterations on)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int kb = 0; kb < n_blocks; ++kb) for_each_stage([&](auto S) { step(S, kb); }, Stages{});
+    }
+    if (!slots) return;
+    // batch statistics: per-lane partials -> LDS -> one slot per workgroup ([sum(C) | sumsq(C)], as stats_to_slot)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s_part[t][threadIdx.x] = on ? ssum[t >> 1][t & 1] : 0.f;
+        s_part[4 + t][threadIdx.x] = on ? ssq[t >> 1][t & 1] : 0.f;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * CO; e += 256) {
@@ -2127,6 +2389,8 @@ __global__ __launch_bounds__(256) void fp_bwd_split_kernel(
     FSTAMP(8);
 }
 
+// which row pass the source-side forward launches: 1 (default) fp_fwd_rows2_kernel, 0 fp_fwd_rows_kernel (same bits)
+static int g_fp_rows_form = (getenv("SN2_FP_ROWS2") && atoi(getenv("SN2_FP_ROWS2")) == 0) ? 0 : 1;
 // (experiment switch) SN2_GRID_MULT: the row kernels' grids times this factor (more, shorter workgroups than the chip holds at
 // once: the hardware then hands the later ones to whichever CU frees up first -- dynamic balancing beside concurrent kernels)
 static const int grid_mult = getenv("SN2_GRID_MULT") ? atoi(getenv("SN2_GRID_MULT")) : 1;
@@ -2181,13 +2445,18 @@ int fp_forward_t(const sn2_fp* p, int mode, hipStream_t st) {
             int grid = sn2_cdiv(n_grp, 8);
             // two workgroups per CU: at 143 VGPRs three waves fit a SIMD, so 1024 workgroups ran as one full round and a
             // third of a second one (0.057 ms; 768: 0.056; 512: 0.052; 384: 0.058)
-            const int cap_fwd_rows = 2 * grid_mult * sn2_cu_count() < SN2_STAT_SLOTS ? 2 * grid_mult * sn2_cu_count() : SN2_STAT_SLOTS;
+            static const int wgs_per_cu = getenv("SN2_FR_WGS_PER_CU") ? atoi(getenv("SN2_FR_WGS_PER_CU")) : 2;      // (experiment switch)
+            const int cap_fwd_rows = wgs_per_cu * grid_mult * sn2_cu_count() < SN2_STAT_SLOTS ? wgs_per_cu * grid_mult * sn2_cu_count() : SN2_STAT_SLOTS;
             if (grid > cap_fwd_rows) grid = cap_fwd_rows;
             // (round 4: a variant with the plot's whole table in LDS -- 144 KB, one 16-wave workgroup per CU, the 226 MB of L2
             // gathers replaced by ds_read_b128 -- ran in 38.1 us against this kernel's 36.5: the gathers are not its bound; at
             // ~14 instructions per row and wave-instruction it is instruction issue, like the head kernels; the skip part's FMA
             // chains as v_pk_fma_f32 pairs -- 32 instructions fewer per two rows -- ran in 38.0 us as well)
-            auto kr = p->act_bf16 ? &fp_fwd_rows_kernel<CA, CB, CO, true> : &fp_fwd_rows_kernel<CA, CB, CO, false>;
+            // (round 5: the row pass with its input stream fetched one element per lane, four iterations ahead;
+            // sn2_debug_fp_rows_form(0) / SN2_FP_ROWS2=0: the first form, kept for cross-checks -- same bits)
+            const bool rows2 = g_fp_rows_form != 0;
+            auto kr = rows2 ? (p->act_bf16 ? &fp_fwd_rows2_kernel<CA, CB, CO, true> : &fp_fwd_rows2_kernel<CA, CB, CO, false>)
+                            : (p->act_bf16 ? &fp_fwd_rows_kernel<CA, CB, CO, true> : &fp_fwd_rows_kernel<CA, CB, CO, false>);
             hipLaunchKernelGGL(kr, dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
                                p->skip_stride, (const float*)p->src_ws, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.b, p->h,
                                training ? p->blk.stat_slots : (float*)nullptr);
@@ -2254,6 +2523,10 @@ int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_
 
 // diagnostic (bench.py): which of the three kernels of the per-point layer's source-side backward run -- bit 0 the row pass, 1 the
 // source pass over the chunk table, 2 the merge (7 = all, the only setting that computes the gradients)
+extern "C" int sn2_debug_fp_rows_form(int form) {
+    g_fp_rows_form = form ? 1 : 0;
+    return 0;
+}
 static int g_fp1_bwd_parts = 7;
 extern "C" int sn2_debug_fp1_backward_parts(int mask) {
     g_fp1_bwd_parts = mask & 7 ? mask & 7 : 7;
@@ -2540,8 +2813,14 @@ constexpr int HEAD_T_QUADS = 64 * 9;   // a wave's 64 consecutive rows of 36 flo
 // form (24-28 us for 92 MB either way: the kernel streams at 3.3-3.8 TB/s and fp32 MFMA has the packed-VALU rate, 2 x the
 // scalar-operand FMA rate); it frees the VALU and scalar cache for whatever runs beside it.  The backward
 // (head_bwd_mfma_kernel, round 4) is built the same way.
+// workgroups per CU the kernel is compiled for = its register budget.  At 4 (128 VGPRs, one spilled) the compiler issued the nine
+// row loads of a turn ONE BY ONE, each behind an s_waitcnt vmcnt(0) of its own (every load into the same four registers): 23.4 us
+// at config 2; at 3 / 2 the loads are in flight together: 22.3 / 22.1 us (scripts/time_head_fwd.py)
+#ifndef SN2_HF_OCC
+#define SN2_HF_OCC 3
+#endif
 template <bool BF>
-__global__ __launch_bounds__(256, 4) void head_fwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
+__global__ __launch_bounds__(256, SN2_HF_OCC) void head_fwd_mfma_kernel(int R, const float* __restrict__ f, const float* __restrict__ fa,
                                                             const float* __restrict__ fc, const float* __restrict__ W1,
                                                             const float* __restrict__ b1, const float* __restrict__ W2,
                                                             const float* __restrict__ b2, float* __restrict__ cov,
@@ -2718,11 +2997,12 @@ __global__ __launch_bounds__(256, 2) void fp_head_eval_kernel(int R, int R_per_p
                 const float w0 = in[u].w0, wa = in[u].w1, wb = in[u].w2;
                 const float inv = 1.0f / ((w0 + wa) + wb);
                 const float4 a = ta[u][0], b = ta[u][1], c = ta[u][2];
-                float v[4] = {((a.x * w0 + b.x * wa) + c.x * wb) * inv, ((a.y * w0 + b.y * wa) + c.y * wb) * inv,
-                              ((a.z * w0 + b.z * wa) + c.z * wb) * inv, ((a.w * w0 + b.w * wa) + c.w * wb) * inv};
+                // (interp_bias: the one spelled-out order of operations of the row kernels -- the same bits as the separate pass)
+                float v[4] = {interp_bias(a.x, b.x, c.x, w0, wa, wb, inv, b4[0]), interp_bias(a.y, b.y, c.y, w0, wa, wb, inv, b4[1]),
+                              interp_bias(a.z, b.z, c.z, w0, wa, wb, inv, b4[2]), interp_bias(a.w, b.w, c.w, w0, wa, wb, inv, b4[3])};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    float acc = v[t] + b4[t];
+                    float acc = v[t];
 #pragma unroll
                     for (int b2q = 0; b2q < QB; ++b2q) {
                         acc = fmaf(wB[t][4 * b2q + 0], in[u].sk[b2q].x, acc);

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
     const int nitems = a.order ? (nA + nB) * G * ((a.B + G - 1) / G) : (ncent + 3) >> 2;
     // items are ordered heaviest first: the waves take them in a snake (round 0: item w, round 1: item 2W-1-w, ...), so the
     // wave with the longest item of a round gets the shortest of the next.  (A shared work counter was tried: 8000 atomics
-    // on one address cost more than the imbalance they removed.)
+    // on one address cost more than the imbalance they removed.  Round 5: dealing the positions so that an XCD's waves take
+    // the items of TWO of the sixteen plots -- 3 MB of feature rows per L2 instead of four plots' 6 MB on two XCDs each --
+    // made all six SA kernels 1-4 % slower: whole plots per XCD are not equal work.)
     for (int round = 0;; ++round) {
         const int qi = round * nwaves + ((round & 1) ? nwaves - 1 - wave : wave);
         if (round * nwaves >= nitems) break;

@@ -95,7 +95,10 @@ class _PointNet2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, xyz, cloud, fps_start, geo, drop_keep, *params):
         training = model.training
-        need_grad = any(ctx.needs_input_grad[6:])   # grad mode is off inside Function.forward; this is the reliable test
+        # will a backward pass follow?  Grad mode is off inside Function.forward, and ctx.needs_input_grad reports the inputs'
+        # requires_grad flags WHATEVER the caller's grad mode (round 5: under torch.no_grad() it said yes, and an eval forward
+        # took the everything-kept path of the eval-mode backward): the callers record torch.is_grad_enabled() in front of apply
+        need_grad = bool(getattr(model, "_grad_mode_at_call", True)) and any(ctx.needs_input_grad[6:])
         cov, proba, saved = model._forward_impl(xyz, cloud, fps_start, training, geo, drop_keep, need_grad=need_grad)
         ctx.model = model
         if not isinstance(saved, X.NetSaved):
@@ -232,6 +235,7 @@ class PointNet2(nn.Module):
                 xyz_d, fs = self._stage_positions(cloud_data, dev)
             self._last_cloud_dev = (cloud, cloud_d)  # lets project_to_plotwise_coverages skip a second H2D copy
             params = self._params()
+            self._grad_mode_at_call = torch.is_grad_enabled()
             cov, proba = _PointNet2Fn.apply(self, xyz_d, cloud_d, fs, geo, self._dropout_keep(cloud_data, cloud_d), *params)
         return cov, proba
 
@@ -258,6 +262,7 @@ class PointNet2(nn.Module):
         from .project_to_2d import remember_upload
         remember_upload(cloud, cloud_d)              # `project_to_plotwise_coverages(pred, clouds, args)` as the reference calls it
         params = self._params()
+        self._grad_mode_at_call = torch.is_grad_enabled()
         return _PointNet2Fn.apply(self, xyz_d, cloud_d, None, g, self._dropout_keep(cloud_data, cloud_d), *params)
 
     def _params(self):

@@ -426,6 +426,45 @@ def test_per_point_layer_source_side_form(N):
         assert err <= 1e-3, f"{k}: {err:.2e}"
 
 
+@pytest.mark.parametrize("B,N,M1", [(3, 24001, 1024), (16, 32768, 1024), (72, 1024, 8), (5, 14001, 3500)])
+def test_the_two_row_passes_of_the_source_side_forward_give_the_same_bits(B, N, M1):
+    """fp_fwd_rows2_kernel (round 5: a wave fetches an iteration's indices, weights and skip quads one element per lane, four
+    iterations ahead, and hands them to the (row, quad) lanes through LDS; the next iteration's table rows are asked for before
+    the current one is computed) against fp_fwd_rows_kernel (every lane of a row loads the row's inputs itself, one iteration
+    ahead): same rows per wave, same arithmetic in the same order -- the activations, BatchNorm statistics and running statistics
+    must be the same BITS, row counts that are no multiple of the 14 rows of an iteration and plots of a few rows included."""
+    from stratanet2_vegetation_coverage_maps_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * N)
+    d = make_batch(B, N, first_plot=3)
+    xyz = d["xyz"].to(dev).float().contiguous()
+    _, pos1_soa, _ = ops.fps(xyz, M1, torch.zeros(B, dtype=torch.int32, device=dev))[:3]
+    knn = ops.three_nn(pos1_soa, xyz, 3)
+    h2 = torch.randn(B * M1, 36, device=dev)
+    a2, c2 = torch.rand(34, device=dev) + 0.5, torch.randn(34, device=dev) * 0.1
+    rows0 = torch.randn(B * N, 12, device=dev)
+    out = {}
+    try:
+        for form in (1, 0):
+            _lib.load().sn2_debug_fp_rows_form(form)
+            lin, bn = torch.nn.Linear(42, 34).to(dev), torch.nn.BatchNorm1d(34).to(dev)
+            with torch.no_grad():
+                g = torch.Generator(device="cpu").manual_seed(5)
+                lin.weight.copy_(torch.randn(34, 42, generator=g) * 0.2)
+                lin.bias.copy_(torch.randn(34, generator=g) * 0.1)
+            blk = ops.BlockBuffers(lin, bn)
+            h1 = torch.full((B * N, 36), 7.0, device=dev)
+            ops.fp_forward(ops.fp_desc(blk, B, N, M1, 34, 8, h2, h1, src_affine=(a2, c2), knn=knn, skip=rows0[:, 0:8]), 1)
+            torch.cuda.synchronize()
+            out[form] = (h1.clone(), blk.aux.clone(), bn.running_mean.clone(), bn.running_var.clone())
+    finally:
+        _lib.load().sn2_debug_fp_rows_form(1)
+    assert B * N > 64 * _lib.STAT_SLOTS, "the case must take the source-side form"
+    assert float(out[1][0][:, :34].abs().max()) > 0 and not (out[1][0][:, :34] == 7.0).any()
+    for a, b, what in zip(out[1], out[0], ("rows", "a | c | mean | invstd", "running_mean", "running_var")):
+        assert torch.equal(a, b), what
+
+
 def test_source_side_form_with_many_tiny_plots():
     """72 plots of 1024 points with 8 level-1 centroids each: more than 65 536 rows, so the per-point layer takes its
     source-side form, but a plot's chunk table has only 57 slots (< 64 = the slots one wave of fp_bwd_src_chunk_kernel owns):
