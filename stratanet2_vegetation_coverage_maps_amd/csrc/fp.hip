@@ -1509,6 +1509,16 @@ __device__ __forceinline__ void stage_inputs(float* __restrict__ s_q, int QS, in
     const int q = lane & (LPR - 1);
     const bool qon = q < QA;
     const int qc = qon ? q : 0;
+    // the skip columns of the few-channel form (CB no multiple of four: the positions of the global SA block) are asked for HERE,
+    // together with the rows of the interpolated part: behind them they were a memory round trip of their own
+    constexpr bool SKIP_SCALAR = CB > 0 && !(CB % 4 == 0 && ((CB / 4) & (CB / 4 - 1)) == 0 && CB <= 64);
+    float skr[SKIP_SCALAR ? CB : 1];
+    if constexpr (SKIP_SCALAR) {
+        const long r = r0 + 16 * g + (lane & 15);
+        const size_t rr = r < R ? (size_t)r : (size_t)(R - 1);
+#pragma unroll
+        for (int k = 0; k < CB; ++k) skr[k] = skip[rr * skip_stride + k];
+    }
     float a4[4] = {1.f, 1.f, 1.f, 1.f}, c4[4] = {0.f, 0.f, 0.f, 0.f};
     if (src_a) {
 #pragma unroll
@@ -1566,10 +1576,8 @@ __device__ __forceinline__ void stage_inputs(float* __restrict__ s_q, int QS, in
     } else if constexpr (CB > 0) {
         if (lane < 16) {
             const int row = 16 * g + lane;
-            const long r = r0 + row;
-            const size_t rr = r < R ? (size_t)r : (size_t)(R - 1);
 #pragma unroll
-            for (int k = 0; k < CB; ++k) s_q[row * QS + CA + k] = skip[rr * skip_stride + k];
+            for (int k = 0; k < CB; ++k) s_q[row * QS + CA + k] = skr[k];
         }
     }
     if (lane < 16) s_q[(16 * g + lane) * QS + CI] = 1.0f;       // the bias column
@@ -1815,8 +1823,30 @@ __device__ __forceinline__ void gl_level_body(const GlArgs& A, float* gl_smem) {
     const int B = A.B, M2 = A.M2;
     const int b_lo = REPAIR ? 0 : (int)blockIdx.x, b_hi = REPAIR ? B : b_lo + 1;       // the plots of this workgroup
     const bool lead = REPAIR || blockIdx.x == 0;                                       // writes the shared results
+    // Both layers' weights come in once per workgroup, coalesced, and the lanes take their tile operands from LDS: sixteen
+    // waves each fetching their own (output, k) elements straight from memory were ~400 cache lines per wave through the CU's
+    // one address unit -- half of the kernel's first phase.  Round 5: every thread's seven loads are ISSUED here, unconditional
+    // (clamped indices), in front of the epoch read and its barrier, and land in LDS behind it: as copy loops `s_w[i] = W[i]`
+    // they were five memory round trips one after the other (each iteration's load waited for by its own store), cold, at the
+    // head of a kernel that is one latency chain (scripts/isa_scan.py).
+    float w3r[3], b3r, bfr;
+    f32x4 wfr[2];                                    // (the native vector type: an array of HIP's float4 struct stays in scratch memory)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w3r[j] = A.sa3.W[min(tid + 1024 * j, 64 * 35 - 1)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wfr[j] = reinterpret_cast<const f32x4*>(A.fp3.W)[min(tid + 1024 * j, 64 * 96 / 4 - 1)];
+    b3r = A.sa3.bias[tid & 63], bfr = A.fp3.bias[tid & 63];
+    unsigned epoch_now = 0;
+    if (tid == 0) epoch_now = __hip_atomic_load(&A.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (tid + 1024 * j < 64 * 35) s_w3[tid + 1024 * j] = w3r[j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (tid + 1024 * j < 64 * 96 / 4) reinterpret_cast<f32x4*>(s_wf)[tid + 1024 * j] = wfr[j];
+    if (tid < 64) s_w3[64 * 35 + tid] = b3r, s_wf[64 * 96 + tid] = bfr;
     if (tid == 0) {
-        s_epoch = __hip_atomic_load(&A.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        s_epoch = epoch_now + 1u;
         s_fail = 0;
     }
     const int nblk = (M2 + 63) >> 6, trips = (nblk + GL_GROUPS - 1) / GL_GROUPS;
@@ -1828,12 +1858,6 @@ __device__ __forceinline__ void gl_level_body(const GlArgs& A, float* gl_smem) {
     // which running statistics workgroup 0 of the launch in front already updated (bit 0: SA3's, bit 1: FP3's)
     unsigned applied = 0;
     if constexpr (REPAIR) applied = __hip_atomic_load(&A.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // Both layers' weights come in once per workgroup, coalesced, and the lanes take their tile operands from LDS: sixteen
-    // waves each fetching their own (output, k) elements straight from memory were ~400 cache lines per wave through the CU's
-    // one address unit -- half of the kernel's first phase.
-    for (int i = tid; i < 64 * 35; i += 1024) s_w3[i] = A.sa3.W[i];
-    for (int i = tid; i < 64 * 96 / 4; i += 1024) reinterpret_cast<float4*>(s_wf)[i] = reinterpret_cast<const float4*>(A.fp3.W)[i];
-    if (tid < 64) s_w3[64 * 35 + tid] = A.sa3.bias[tid], s_wf[64 * 96 + tid] = A.fp3.bias[tid];
     f32x4 V3[4];                                                 // SA3's outputs of the group's (last) block: the max reads them
 #pragma unroll
     for (int t = 0; t < 4; ++t) V3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
