@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = it.le0 + it.eoff * t;
-            jn[t] = e < a.cap ? a.nbr[(size_t)it.lc[t] * a.cap + e] : 0;
+            jn[t] = a.nbr[(size_t)it.lc[t] * a.cap + (e < a.cap ? e : 0)];     // (unconditional: masked below)
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) jn[t] = it.le0 + it.eoff * t < it.ln[t] ? jn[t] : 0;
@@ -260,22 +260,31 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
             f32x4 D1[TO1][4];
             bool val[4];
             int jc[4];
+            // every load of a step is issued HERE, unconditional, before any of them is waited for: the four tiles' rows and the
+            // next step's four indices (from a clamped slot, masked afterwards).  As `en < n ? nbr[..] : 0` the index prefetch was a
+            // load under a branch -- the compiler then cannot count what is outstanding and drained everything behind each tile's
+            // gathers: four memory round trips per step, one after the other, where one is needed (scripts/isa_scan.py; round 5)
+            float bkt[4][KB1];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 jc[t] = jn[t];
                 const int en = e0 + estep + it.le0 + it.eoff * t;
-                jn[t] = en < it.ln[t] ? a.nbr[(size_t)it.lc[t] * a.cap + en] : 0;
+                const bool more = en < it.ln[t];
+                const int jr = a.nbr[(size_t)it.lc[t] * a.cap + (more ? en : 0)];
+                jn[t] = more ? jr : 0;
+                const size_t row = (size_t)it.bt[t] * a.Nsrc + jc[t];
+#pragma unroll
+                for (int kb = 0; kb < KB1 - 1; ++kb) bkt[t][kb] = a.feat[row * a.feat_stride + 4 * kb + q];
+                bkt[t][KB1 - 1] = a.spos[row * a.spos_stride + (q < 3 ? q : 0)];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int e = e0 + it.le0 + it.eoff * t;                            // slot in the list of this lane's centroid
                 val[t] = e < it.ln[t];
-                const size_t row = (size_t)it.bt[t] * a.Nsrc + jc[t];
                 float bk[KB1];
 #pragma unroll
-                for (int kb = 0; kb < KB1 - 1; ++kb) bk[kb] = a.feat[row * a.feat_stride + 4 * kb + q];
-                const float pj = a.spos[row * a.spos_stride + (q < 3 ? q : 0)];
-                bk[KB1 - 1] = q < 3 ? pj - cpq[t] : 1.0f;   // pos_j - pos_i | bias column
+                for (int kb = 0; kb < KB1 - 1; ++kb) bk[kb] = bkt[t][kb];
+                bk[KB1 - 1] = q < 3 ? bkt[t][KB1 - 1] - cpq[t] : 1.0f;   // pos_j - pos_i | bias column
 #pragma unroll
                 for (int io = 0; io < TO1; ++io) {
                     f32x4 acc = {bias1[io][0], bias1[io][1], bias1[io][2], bias1[io][3]};
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = it.le0 + it.eoff * t;
-            jn[t] = e < a.cap ? a.nbr[(size_t)it.lc[t] * a.cap + e] : 0;
+            jn[t] = a.nbr[(size_t)it.lc[t] * a.cap + (e < a.cap ? e : 0)];     // (unconditional: masked below)
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) jn[t] = it.le0 + it.eoff * t < it.ln[t] ? jn[t] : 0;
@@ -628,21 +637,25 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
             bool val[4];
             size_t rows[4];
             int jc[4];
+            // (every load of a step issued before any is waited for, the index prefetch unconditional from a clamped slot: see the
+            // forward kernel)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 jc[t] = jn[t];
                 const int en = e0 + estep + it.le0 + it.eoff * t;
-                jn[t] = en < it.ln[t] ? a.nbr[(size_t)it.lc[t] * a.cap + en] : 0;
+                const bool more = en < it.ln[t];
+                const int jr = a.nbr[(size_t)it.lc[t] * a.cap + (more ? en : 0)];
+                jn[t] = more ? jr : 0;
+                rows[t] = (size_t)it.bt[t] * a.Nsrc + jc[t];
+#pragma unroll
+                for (int kb = 0; kb < KB1 - 1; ++kb) bks[t][kb] = a.feat[rows[t] * a.feat_stride + 4 * kb + q];
+                bks[t][KB1 - 1] = a.spos[rows[t] * a.spos_stride + (q < 3 ? q : 0)];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int e = e0 + it.le0 + it.eoff * t;                            // slot in the list of this lane's centroid
                 val[t] = e < it.ln[t];
-                rows[t] = (size_t)it.bt[t] * a.Nsrc + jc[t];
-#pragma unroll
-                for (int kb = 0; kb < KB1 - 1; ++kb) bks[t][kb] = a.feat[rows[t] * a.feat_stride + 4 * kb + q];
-                const float pj = a.spos[rows[t] * a.spos_stride + (q < 3 ? q : 0)];
-                bks[t][KB1 - 1] = q < 3 ? pj - cpq[t] : 1.0f;
+                bks[t][KB1 - 1] = q < 3 ? bks[t][KB1 - 1] - cpq[t] : 1.0f;
 #pragma unroll
                 for (int io = 0; io < TO1; ++io) {
                     f32x4 v = {bias1[io][0], bias1[io][1], bias1[io][2], bias1[io][3]};
