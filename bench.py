@@ -246,7 +246,7 @@ def algorithmic_bytes(key, B, N, m1, m2, e1, e2, D=20):
 DOMINANT_KERNEL = {
     "sn2_fps:N=32768": "fps_cluster_kernel<8, 8, 8, true>", "sn2_ball_query:N=32768": "ball_query_grid_kernel",
     "sn2_sa_forward:cf=8": "sa_mfma_fwd_kernel<8, 2, 16, 16, 1, false, true>", "sn2_sa_backward:cf=8": "sa_mfma_bwd_kernel<8, 2, 16, 16, 2, false>",
-    "sn2_fp_forward:34+8->34": "fp_fwd_rows_kernel<34, 8, 34, false>",
+    "sn2_fp_forward:34+8->34": "fp_fwd_rows2_kernel<34, 8, 34, false>",
     "sn2_fp_backward:34+8->34": "fp_bwd_rows_kernel<34, 8, 34, 512, false>",
     "sn2_head_forward": "head_fwd_mfma_kernel<false>", "sn2_head_backward": "head_bwd_mfma_kernel<false>",
     "sn2_three_nn:T=32768": "three_nn_grid_kernel", "sn2_pack_rows": "pack_rows_kernel",
@@ -257,7 +257,7 @@ DOMINANT_KERNEL = {
 ENTRY_KERNELS = {
     "sn2_fp_backward:34+8->34": ["fp_bwd_rows_kernel<34, 8, 34, 512, false>", "fp_bwd_src_chunk_kernel<34, 8, 34, false>",
                                  "fp_bwd_src_merge_dw_kernel<34, 8, 34>", "fp_bwd_bn_kernel<34>"],
-    "sn2_fp_forward:34+8->34": ["fp_src_table_kernel<34, 8, 34>", "fp_fwd_rows_kernel<34, 8, 34, false>"],
+    "sn2_fp_forward:34+8->34": ["fp_src_table_kernel<34, 8, 34>", "fp_fwd_rows2_kernel<34, 8, 34, false>"],
 }
 
 

@@ -54,7 +54,7 @@ K["sa_mfma_bwd_kernel<8, 2, 16, 16, 3, false>"] = ("SA1 backward, layer 1", 4 * 
 K["sa_mfma_fwd_kernel<16, 1, 32, 32, 1, false, true>"] = ("SA2 forward", 4 * E2 + 80 * M1 * B + 16 * M2 * B + 256 * M2 * B, 80 * E2, 1216 * E2)
 K["sa_mfma_bwd_kernel<16, 1, 32, 32, 3, false>"] = ("SA2 backward", 4 * E2 + 80 * M1 * B + 16 * M2 * B + 256 * M2 * B, (80 + 64) * E2, (1216 + 1216 + 1024) * E2)
 K["scatter_max_kernel<0>"] = ("plot-wise projection: scatter-max", (8 + 16 + 4) * R + 24 * 400 * B, None, 0)
-K["fp_fwd_rows_kernel<34, 8, 34, false>"] = ("FP1 forward, row pass (source-side form)", (24 + 32 + 144) * R, 3 * 144 * R, 0)
+K["fp_fwd_rows2_kernel<34, 8, 34, false>"] = ("FP1 forward, row pass (source-side form; round 5: pipelined input stream)", (24 + 32 + 144) * R, 3 * 144 * R, 0)
 K["fp_bwd_rows_kernel<34, 8, 34, 512, false>"] = ("FP1 backward, row pass", (288 + 32 + 136) * R, None, 0)
 K["fp_bwd_src_chunk_kernel<34, 8, 34, false>"] = ("FP1 backward, source pass (rows gathered through the chunked inverted index)", (24 + 136) * R, 2 * 136 * R, 0)
 K["fp_bwd_src_merge_dw_kernel<34, 8, 34>"] = ("FP1 backward, partial rows -> G, dsrc, dW_A", (144 + 144 + 136 + 2 * 136) * M1 * B, None, 0)
