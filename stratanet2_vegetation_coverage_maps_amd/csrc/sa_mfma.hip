@@ -81,6 +81,29 @@ __device__ __forceinline__ unsigned seg_min_u32(unsigned v, int W) {
     return v;
 }
 
+// The first links of a wave's chain -- trailer (how many positions there are) -> the position's record -> counts, first indices ->
+// rows -- asked for at the very top of the kernels, in front of the ~50 loads of the weights and BatchNorm constants: the record of
+// the wave's FIRST position is read speculatively as a SOLO / QUAD record (order + 4 qi: inside the table for every wave), which it is
+// for the heavy items that decide how long the kernel runs; a packed (light) position reads its own record later.  With barely more
+// positions than waves (2 560 against 3 072 at config 2) a kernel is one such chain per wave: two round trips fewer (round 5).
+struct SaFirst {
+    int nA, nB;
+    int rec[4];
+};
+__device__ __forceinline__ SaFirst sa_first(const int* __restrict__ order, const int* __restrict__ fallback, int B, int M, int wave) {
+    SaFirst f;
+    const int ncent = B * M;
+    const int* trailer = order ? order + (size_t)4 * ncent + (size_t)16 * B * SN2_SA_PACKED_ITEMS(M) : nullptr;
+    const int* base = order ? order : fallback;                // (unconditional loads: a valid address either way)
+    const int* tr = trailer ? trailer : fallback;
+    const int t0 = tr[0], t1 = tr[1];
+    const int w4 = 4 * (wave < ncent ? wave : 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.rec[t] = base[w4 + t];
+    f.nA = order ? t0 : 0, f.nB = order ? t1 : 0;
+    return f;
+}
+
 // One work item of sn2_sa_order, as every lane sees it.  lane = (q, c), tile t: the message slot (t, c) belongs to centroid
 // lc[t], is entry le0 + eoff * t + (steps done) * estep of its neighbour list, which has ln[t] entries (-1: no centroid).
 //   SOLO  one centroid, 64 entries per step (tile t: entries 16 t + c)        QUAD  four centroids, 16 entries per step each
@@ -92,17 +115,27 @@ struct SaItem {
     int bt[4], estep, eoff, W, nmax;
     bool solo;
 };
+// (`pre`: the four ints at order + 4 qi, loaded ahead by the caller -- the record of position qi if it is a SOLO / QUAD position
+// of a table whose plots are taken all at once; nullptr: none)
 __device__ __forceinline__ bool sa_item(SaItem& it, const int* __restrict__ order, const int* __restrict__ cnt, int B, int M,
-                                        int nA, int nB, int G, int qi, int c) {
+                                        int nA, int nB, int G, int qi, int c, const int* pre = nullptr) {
     const int ncent = B * M;
     if (!order) {                                            // no order table: quads in index order
         it.solo = false, it.estep = 16, it.eoff = 0, it.W = 16, it.nmax = 0, it.le0 = c;
+        // (the four counts are loaded UNCONDITIONALLY -- slot 0 for a missing centroid, masked afterwards -- and together: as
+        // `ci >= 0 ? cnt[ci] : -1` each was a load under a branch, waited for before the next was issued: four round trips)
+        int cn[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ci = 4 * qi + t < ncent ? 4 * qi + t : -1;
             it.lc[t] = ci >= 0 ? ci : 0;
-            it.ln[t] = ci >= 0 ? cnt[ci] : -1;
+            cn[t] = cnt[it.lc[t]];
+            it.ln[t] = ci;
             it.bt[t] = it.lc[t] / M;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            it.ln[t] = it.ln[t] >= 0 ? cn[t] : -1;
             it.nmax = max(it.nmax, __builtin_amdgcn_readfirstlane(it.ln[t]));
         }
         return it.nmax > 0;
@@ -119,8 +152,13 @@ __device__ __forceinline__ bool sa_item(SaItem& it, const int* __restrict__ orde
     const int qp = k * B + pb;
     const int* rec = packed ? order + (size_t)4 * ncent + (size_t)16 * qp : order + (size_t)4 * qp;
     int ent[4];
+    if (pre && !packed && G == B) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ent[t] = rec[packed ? 4 * t + (c >> 2) : t];
+        for (int t = 0; t < 4; ++t) ent[t] = pre[t];                         // (qp == qi there)
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ent[t] = rec[packed ? 4 * t + (c >> 2) : t];
+    }
     const int e0 = __builtin_amdgcn_readfirstlane(ent[0]);
     if (e0 < 0) return false;
     it.solo = !packed && (e0 & SN2_SA_SOLO_FLAG) != 0;
@@ -129,12 +167,17 @@ __device__ __forceinline__ bool sa_item(SaItem& it, const int* __restrict__ orde
     it.eoff = it.solo ? 16 : 0;
     it.le0 = c & (it.W - 1);
     it.nmax = 0;
+    int cn[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bool some = ent[t] >= 0;
         it.lc[t] = some ? (ent[t] & ~(SN2_SA_SOLO_FLAG | SN2_SA_OCT_FLAG)) : 0;
-        it.ln[t] = some ? cnt[it.lc[t]] : -1;
+        cn[t] = cnt[it.lc[t]];                               // (unconditional, all four in flight together: see above)
         it.bt[t] = pb;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        it.ln[t] = ent[t] >= 0 ? cn[t] : -1;
         if (!packed) it.nmax = max(it.nmax, __builtin_amdgcn_readfirstlane(it.ln[t]));
     }
     if (packed) it.nmax = it.W;                              // one step (lists of at most W entries)
@@ -158,6 +201,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int nwaves = gridDim.x * 4;
     const int ncent = a.B * a.M;
+    const SaFirst first = sa_first(a.order, a.cnt, a.B, a.M, wave);
 
     // ---- operand registers, loaded once
     // the bias of the first layer rides in the weight matrix against the constant-1 column of the gathered input -- in fp32.
@@ -214,8 +258,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
         for (int r = 0; r < 4; ++r) ssum[io][r] = ssq[io][r] = 0.f;
 
     // positions of the order table: nA per plot for SOLO / QUAD items, then nB per plot for the packed ones (OCT / HEX)
-    const int* trailer = a.order ? a.order + (size_t)4 * ncent + (size_t)16 * a.B * SN2_SA_PACKED_ITEMS(a.M) : nullptr;
-    const int nA = trailer ? trailer[0] : 0, nB = trailer ? trailer[1] : 0;
+    const int nA = first.nA, nB = first.nB;
     const int G = a.group > 0 && a.group < a.B ? a.group : a.B;
     const int nitems = a.order ? (nA + nB) * G * ((a.B + G - 1) / G) : (ncent + 3) >> 2;
     // items are ordered heaviest first: the waves take them in a snake (round 0: item w, round 1: item 2W-1-w, ...), so the
@@ -228,7 +271,7 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
         if (round * nwaves >= nitems) break;
         if (qi >= nitems) continue;
         SaItem it;
-        if (!sa_item(it, a.order, a.cnt, a.B, a.M, nA, nB, G, qi, c)) continue;          // an empty position
+        if (!sa_item(it, a.order, a.cnt, a.B, a.M, nA, nB, G, qi, c, round == 0 ? first.rec : nullptr)) continue;      // an empty position
         const int nmax = it.nmax, estep = it.estep;
         float cpq[4];
 #pragma unroll
@@ -492,6 +535,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
     const int nwaves = gridDim.x * 4;
     const int ncent = a.B * a.M;
+    const SaFirst first = sa_first(a.order, a.cnt, a.B, a.M, wave);
     float* lds_p = smem + wib * Acc::LDS_FLOATS;
     float* lds_q = lds_p + 64 * PS;
     SASTAMP(0);
@@ -590,8 +634,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
     SASTAMP(1);
     unsigned long long n_items_dbg = 0, n_steps_dbg = 0;
     // positions of the order table: nA per plot for SOLO / QUAD items, then nB per plot for the packed ones (OCT / HEX)
-    const int* trailer = a.order ? a.order + (size_t)4 * ncent + (size_t)16 * a.B * SN2_SA_PACKED_ITEMS(a.M) : nullptr;
-    const int nA = trailer ? trailer[0] : 0, nB = trailer ? trailer[1] : 0;
+    const int nA = first.nA, nB = first.nB;
     const int G = a.group > 0 && a.group < a.B ? a.group : a.B;
     const int nitems = a.order ? (nA + nB) * G * ((a.B + G - 1) / G) : (ncent + 3) >> 2;
     // items are ordered heaviest first: the waves take them in a snake (round 0: item w, round 1: item 2W-1-w, ...), so the
@@ -602,7 +645,7 @@ __global__ __launch_bounds__(256) void sa_mfma_bwd_kernel(const SaBwdArgs a) {
         if (round * nwaves >= nitems) break;
         if (qi >= nitems) continue;
         SaItem it;
-        if (!sa_item(it, a.order, a.cnt, a.B, a.M, nA, nB, G, qi, c)) continue;          // an empty position
+        if (!sa_item(it, a.order, a.cnt, a.B, a.M, nA, nB, G, qi, c, round == 0 ? first.rec : nullptr)) continue;      // an empty position
         if (n_items_dbg == 0) { SASTAMP(2); }
         ++n_items_dbg;
         n_steps_dbg += (it.nmax + it.estep - 1) / it.estep;
