@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
             // every load of a step is issued HERE, unconditional, before any of them is waited for: the four tiles' rows and the
             // next step's four indices (from a clamped slot, masked afterwards).  As `en < n ? nbr[..] : 0` the index prefetch was a
             // load under a branch -- the compiler then cannot count what is outstanding and drained everything behind each tile's
-            // gathers: four memory round trips per step, one after the other, where one is needed (scripts/isa_scan.py; round 5)
+            // gathers: four memory round trips per step, one after the other, where one is needed (scripts/isa_scan.py; round 5).
+            // (Gathering a step's ROWS one step ahead as well -- scripts/sa_stamps.py has the five-step items that decide the
+            // kernels' duration at 3.5 us per step -- made all four SA1 kernels slower, 15.1 -> 18.3 us the statistics pass: most
+            // items are ONE step, and each then gathers a second set of rows nobody reads.)
             float bkt[4][KB1];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
