@@ -101,7 +101,10 @@ int sn2_bn_finalize(const sn2_block* blk, int nslots, const unsigned long long* 
                     hipStream_t st) {
     if (!blk || blk->cout <= 0 || blk->cout > 64 || nslots < 0 || nslots > SN2_STAT_SLOTS) return SN2_EINVAL;
     if (training && (!blk->stat_slots || nslots < 1)) return SN2_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(1), dim3(1024), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
+    // an EVAL pass sums nothing: 64 threads (one per channel).  A 1024-thread workgroup needs a CU with sixteen free wave slots at
+    // once, and beside the full-chip kernels of other passes in flight it waited for them: 88 us on average, seven times per launch
+    // of the parcel loop, on the feature stream's chain (profiles/r05_kernel_stats_inference.csv; round 5)
+    hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(1), dim3(training ? 1024 : 64), 0, st, blk->cout, blk->gamma, blk->beta, blk->running_mean,
                        blk->running_var, blk->a, blk->c, blk->mean, blk->invstd, (const float*)blk->stat_slots, nslots,
                        count_dev, count_imm, training, blk->num_batches_tracked, (const float*)nullptr, (const int*)nullptr,
                        (float*)nullptr, 0L);

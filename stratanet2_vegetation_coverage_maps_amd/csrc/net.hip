@@ -220,6 +220,10 @@ void head_desc(sn2_head* h, const sn2_net_model* m, const sn2_net_dims* d, const
 
 int inverted_tables(const sn2_net_dims* d, const sn2_net_geo* g, int which, void* st) {
     // which: 1 = the two small tables (chain b), 2 = the per-point table (chain c), 3 = all
+    if (which == 3) {               // (a late build: the message totals an eval-mode geometry pass did not make)
+        SN2_TRY(sn2_count_sum(g->cnt1, d->B * d->M1, g->tot1, st));
+        SN2_TRY(sn2_count_sum(g->cnt2, d->B * d->M2, g->tot2, st));
+    }
     if (which & 1) {
         if (!g->inv3 || !g->inv2) return SN2_EINVAL;
         SN2_TRY(sn2_interp_index_perm(g->knn3_idx, g->knn3_w, nullptr, nullptr, d->B, d->M2, 1, g->inv3, st));
@@ -273,7 +277,10 @@ int geometry_impl(const sn2_net_model* m, const sn2_net_dims* d, const sn2_net_g
     }
     // (b) the level-2 chain
     SN2_TRY(sn2_fps_status(g->pos1_soa, B, M1, M2, start1, g->idx2, g->pos2_soa, g->pos2_aos, ws2, 0, io->fps_status, sb));
-    SN2_TRY(sn2_ball_query(g->pos1_soa, B, M1, g->pos2_soa, M2, m->r2_sq, d->cap2, g->nbr2, g->cnt2, g->tot2, ws2, sb));
+    // (the message totals are the counts of the batch-statistics BatchNorms: only a pass a backward may follow -- `inverted` --
+    // needs them; an eval pass over hundreds of plots spent 0.2 ms per level in the one-workgroup sum.  A forward that finds
+    // tables without them builds them with the inverted indices: inverted_tables)
+    SN2_TRY(sn2_ball_query(g->pos1_soa, B, M1, g->pos2_soa, M2, m->r2_sq, d->cap2, g->nbr2, g->cnt2, inverted ? g->tot2 : nullptr, ws2, sb));
     SN2_TRY(sn2_sa_order(g->cnt2, B, M2, g->ord2, sb));
     if (fork) NET_HIP(hipEventRecord(ctx->b_tables, sb));
     SN2_TRY(sn2_three_nn(g->pos3, B, 1, g->pos2_soa, M2, 1, g->knn3_idx, g->knn3_w, nullptr, nullptr, sb));
@@ -292,7 +299,7 @@ int geometry_impl(const sn2_net_model* m, const sn2_net_dims* d, const sn2_net_g
             SN2_TRY(sn2_plot_pixels(io->cloud, 10L * N, B, N, d->p2_diam_pix, g->p2_mm, g->p2_pix, cur));
     }
     // (a)
-    SN2_TRY(sn2_ball_query(g->xyz, B, N, g->pos1_soa, M1, m->r1_sq, d->cap1, g->nbr1, g->cnt1, g->tot1, ws1, cur));
+    SN2_TRY(sn2_ball_query(g->xyz, B, N, g->pos1_soa, M1, m->r1_sq, d->cap1, g->nbr1, g->cnt1, inverted ? g->tot1 : nullptr, ws1, cur));
     SN2_TRY(sn2_sa_order(g->cnt1, B, M1, g->ord1, cur));
     if (fork) {
         NET_HIP(hipEventRecord(ctx->b_done, sb));

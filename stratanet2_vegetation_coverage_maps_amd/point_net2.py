@@ -451,7 +451,8 @@ class PointNet2(nn.Module):
             sb = sc = cur
         with torch.cuda.stream(sb):                                        # (b) the level-2 chain
             ops.fps(g.pos1_soa, M2, fps_start[1], out=(g.idx2, g.pos2_soa, g.pos2_aos, g.ws2))
-            ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, g.tot2, fps_ws=g.ws2,
+            # (the message totals: only where a backward may follow -- `inverted`; sn2_net_geometry)
+            ops.ball_query(g.pos1_soa, g.pos2_soa, self.sa2_module.r, MAX_NEIGHBORS, g.tot2 if inverted else False, fps_ws=g.ws2,
                            out=(g.nbr2, g.cnt2))
             ops.sa_order(g.cnt2, B, M2, out=g.ord2)
             ops.three_nn(g.pos3, g.pos2_soa, 1, out=g.knn3)
@@ -469,7 +470,7 @@ class PointNet2(nn.Module):
         if cloud is not None:
             self._input_only(g, cloud, xyz)
         # (a)
-        ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
+        ops.ball_query(xyz, g.pos1_soa, self.sa1_module.r, MAX_NEIGHBORS, g.tot1 if inverted else False, fps_ws=g.ws1, out=(g.nbr1, g.cnt1))
         ops.sa_order(g.cnt1, B, M1, out=g.ord1)
         g._join = None
         if fork and defer_join:
@@ -660,6 +661,8 @@ class PointNet2(nn.Module):
                 cur_stream.wait_stream(join[0])
                 cur_stream.wait_stream(join[1])
                 join = None
+            ops.count_sum(geo.cnt1, geo.tot1)          # (the message totals an eval-mode geometry pass did not make)
+            ops.count_sum(geo.cnt2, geo.tot2)
             ops.interp_index(geo.knn3, B, M2, 1, out=geo.inv3)
             ops.interp_index(geo.knn2, B, M1, M2, out=geo.inv2)
             ops.interp_index(geo.knn1, B, N, M1, out=geo.inv1, src_pos=geo.pos1_aos, row_perm=getattr(geo, "rank1", None))
