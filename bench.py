@@ -824,6 +824,8 @@ def main():
     # RCCL / the process group create theirs (a pipeline whose side streams were created after a communicator shared queues
     # with them and ran 15 % slower per step: 0.905 instead of 0.787 ms)
     ops.create_shared_streams(dev)
+    # (round 5: the step's own stream at HIGH queue priority -- torch.cuda.Stream(priority=-1), the side streams at 0 -- changed
+    # nothing for the pipelined step, 0.7003 against 0.6994 ms, and made the unpipelined one slower, 2.78 against 1.75 ms)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
