@@ -767,16 +767,16 @@ __device__ __forceinline__ f32x2 interp_bias2(f32x2 a, f32x2 b, f32x2 c, float w
 struct RowIters {
     int it0, stride, it_hi;
 };
-__device__ __forceinline__ RowIters row_iters(int n_it, int wave) {
+__device__ __forceinline__ RowIters row_iters(int n_it, int wave, int wpw = 4) {           // wpw: waves per workgroup
     RowIters r;
     if ((gridDim.x & 7) == 0) {
         const int xcd = blockIdx.x & 7, wg_x = blockIdx.x >> 3, n_wg_x = gridDim.x >> 3;
         const int lo = (int)((long)n_it * xcd / 8);
         r.it_hi = (int)((long)n_it * (xcd + 1) / 8);
-        r.stride = n_wg_x * 4;
-        r.it0 = lo + wg_x * 4 + wave;
+        r.stride = n_wg_x * wpw;
+        r.it0 = lo + wg_x * wpw + wave;
     } else {
-        r.it_hi = n_it, r.stride = (int)gridDim.x * 4, r.it0 = (int)blockIdx.x * 4 + wave;
+        r.it_hi = n_it, r.stride = (int)gridDim.x * wpw, r.it0 = (int)blockIdx.x * wpw + wave;
     }
     return r;
 }
@@ -1166,6 +1166,9 @@ __global__ __launch_bounds__(NT) void fp_bwd_rows_kernel(int R, int skip_stride,
 #pragma unroll
         for (int k = 0; k < CB; ++k) aW[t][k] = 0.f;
     }
+    // (round 5: dealing these rows XCD-aware as in the forward row pass -- XCD x then writes the d pre-activation rows of the plots whose
+    // sources fp_bwd_src_chunk_kernel gathers from XCD x -- made the source pass 2 us faster (some of the rows are still in that L2)
+    // and this pass 1.7 us slower: nothing in sum, scripts/time_fp1_bwd.py)
     const long n_grp = ((long)R + G - 1) / G;
     const long n_waves = (long)gridDim.x * (NT / 64);
     for (long grp0 = ((long)blockIdx.x * (NT / 64) + wave) * U; grp0 < n_grp; grp0 += n_waves * U) {
