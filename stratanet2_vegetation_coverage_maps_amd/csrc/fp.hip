@@ -3100,6 +3100,213 @@ __global__ __launch_bounds__(256, 2) void fp_head_eval_kernel(int R, int R_per_p
     }
 }
 
+// The same kernel with the row side's INPUT STREAM decoupled from the lanes that consume it, as fp_fwd_rows2_kernel (round 5).  The
+// first form's nine lanes of a row load the row's 3-NN entry and skip columns themselves, then gather, then compute, three groups
+// of seven rows at a time: six memory round trips per 63-row turn, one after the other, in front of the head's arithmetic.  Here
+// a wave fetches a whole turn's 189 indices, 189 weights and 63 x QB skip quads with one element per lane and load (eight loads),
+// ONE TURN AHEAD (the loads are issued in front of the head phase of the turn before), hands them to the (row, quad) lanes
+// through LDS, and asks for a batch's table rows before it computes the batch before: one round trip per turn is left in the
+// open.  Turns dealt XCD-aware (row_iters: an XCD's L2 holds its own plots' table rows).  Same operations in the same order:
+// the same bits as the first form (sn2_debug_fp_rows_form(0)) and as the two separate kernels.
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256, 2) void fp_head_eval2_kernel(int R, int R_per_plot, int S_per_plot, int skip_stride,
+                                                               const float* __restrict__ T, const int* __restrict__ knn_idx,
+                                                               const float* __restrict__ knn_w, const float* __restrict__ skip,
+                                                               const float* __restrict__ Wg, const float* __restrict__ biasg,
+                                                               const float* __restrict__ fa, const float* __restrict__ fc,
+                                                               const float* __restrict__ W1, const float* __restrict__ b1,
+                                                               const float* __restrict__ W2, const float* __restrict__ b2,
+                                                               float* __restrict__ cov, float* __restrict__ proba) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, G = 64 / QH, QB = CB / 4, U = 3, ROWS = G * 9;
+    static_assert(CO == 34 && HS == 36 && G == 7 && ROWS == 63, "the head reads rows of 36 floats, 63 per turn");
+    static_assert(CB > 0 && CB % 4 == 0 && QB == 2, "two skip quads per row: 126 quads per turn = two per lane");
+    constexpr int XW = 3 * ROWS + 3 * ROWS + 4 * ROWS * QB + 2;                // idx | w | skip quads (16-byte aligned: 378 % 4 = 2 -> +2)
+    constexpr int XO_W = 3 * ROWS, XO_S = 6 * ROWS + 2;
+    static_assert(XO_S % 4 == 0, "the skip quads start 16-byte aligned");
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    __shared__ float4 s_t[4 * HEAD_T_QUADS];
+    __shared__ __attribute__((aligned(16))) float s_x[4][(XW + 3) / 4 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* st4 = s_t + wave * HEAD_T_QUADS;
+    float* st = reinterpret_cast<float*>(st4);
+    float* zt = st;                    // [64][20] after lin1 has read the rows
+    float* sc = st + 64 * 20;          // [64][8]
+    float* xw = s_x[wave];
+    const int q = lane % QH, g = lane / QH;
+    const bool on = lane < G * QH;
+    const int n = lane & 15, kq = lane >> 4;
+    float wB[4][CB], b4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int o = 4 * q + t;
+        b4[t] = o < CO ? biasg[o] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) wB[t][k] = o < CO ? Wg[o * CI + CA + k] : 0.f;
+    }
+    float w1[9], ak[9], ck[9], w2[4];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+        const int k = 4 * ks + kq;
+        w1[ks] = k < 34 ? W1[n * 34 + k] : 0.f;
+        ak[ks] = k < 34 ? fa[k] : 0.f;
+        ck[ks] = k < 34 ? fc[k] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w2[ks] = n < 5 ? W2[n * 16 + 4 * ks + kq] : 0.f;
+    const float bias1 = b1[n], bias2 = n < 5 ? b2[n] : 0.f;
+    const int n_turns = (R + ROWS - 1) / ROWS;
+    const RowIters ri = row_iters(n_turns, wave);
+    // ---- a turn's inputs, one element per lane and load, unconditional from clamped addresses
+    int p_idx[3];
+    float p_w[3];
+    f32x4v p_sk[2];
+    const int last_e = 3 * R - 1;
+    auto fetch = [&](int turn) {
+        const int tc = turn < ri.it_hi ? turn : ri.it_hi - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int el = lane + 64 * k < 3 * ROWS ? lane + 64 * k : 3 * ROWS - 1;
+            const int e0 = tc * (3 * ROWS) + el, e = e0 < last_e ? e0 : last_e;
+            p_idx[k] = knn_idx[e];
+            p_w[k] = knn_w[e];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int el = lane + 64 * k < ROWS * QB ? lane + 64 * k : ROWS * QB - 1;
+            const int r0 = tc * ROWS + el / QB, r = r0 < R ? r0 : R - 1;
+            p_sk[k] = reinterpret_cast<const f32x4v*>(skip + (size_t)r * skip_stride)[el % QB];
+        }
+    };
+    auto hand_over = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int el = lane + 64 * k < 3 * ROWS ? lane + 64 * k : 3 * ROWS - 1;     // (the surplus lanes rewrite the last element)
+            xw[el] = __int_as_float(p_idx[k]);
+            xw[XO_W + el] = p_w[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int el = lane + 64 * k < ROWS * QB ? lane + 64 * k : ROWS * QB - 1;
+            reinterpret_cast<f32x4v*>(xw + XO_S)[el] = p_sk[k];
+        }
+        WAVE_LDS_SYNC();
+    };
+    // the table rows of batch `bt` (groups 3 bt .. 3 bt + 2) of the turn
+    auto gathers = [&](int turn, int bt, float4 (&ta)[U][3]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rl = on ? (3 * bt + u) * G + g : 0;                     // row of the turn
+            const int row = turn * ROWS + rl;
+            const bool valid = on && row < R;
+            const unsigned rr = valid ? (unsigned)row : 0u;
+            const int i0 = valid ? __float_as_int(xw[3 * rl + 0]) : 0, i1 = valid ? __float_as_int(xw[3 * rl + 1]) : 0,
+                      i2 = valid ? __float_as_int(xw[3 * rl + 2]) : 0;
+            const unsigned base = (rr / (unsigned)R_per_plot) * (unsigned)S_per_plot;
+            ta[u][0] = reinterpret_cast<const float4*>(T + (size_t)(base + i0) * HS)[q];
+            ta[u][1] = reinterpret_cast<const float4*>(T + (size_t)(base + i1) * HS)[q];
+            ta[u][2] = reinterpret_cast<const float4*>(T + (size_t)(base + i2) * HS)[q];
+        }
+    };
+    auto rows_of = [&](int turn, int bt, const float4 (&ta)[U][3]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rl = on ? (3 * bt + u) * G + g : 0;
+            const int row = turn * ROWS + rl;
+            const bool valid = on && row < R;
+            const float w0 = xw[XO_W + 3 * rl + 0], wa = xw[XO_W + 3 * rl + 1], wb = xw[XO_W + 3 * rl + 2];
+            float4 sk[QB];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) sk[b] = reinterpret_cast<const float4*>(xw + XO_S)[rl * QB + b];
+            const float inv = 1.0f / ((w0 + wa) + wb);
+            const float4 a = ta[u][0], b = ta[u][1], c = ta[u][2];
+            float v[4] = {interp_bias(a.x, b.x, c.x, w0, wa, wb, inv, b4[0]), interp_bias(a.y, b.y, c.y, w0, wa, wb, inv, b4[1]),
+                          interp_bias(a.z, b.z, c.z, w0, wa, wb, inv, b4[2]), interp_bias(a.w, b.w, c.w, w0, wa, wb, inv, b4[3])};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float acc = v[t];
+#pragma unroll
+                for (int b2q = 0; b2q < QB; ++b2q) {
+                    acc = fmaf(wB[t][4 * b2q + 0], sk[b2q].x, acc);
+                    acc = fmaf(wB[t][4 * b2q + 1], sk[b2q].y, acc);
+                    acc = fmaf(wB[t][4 * b2q + 2], sk[b2q].z, acc);
+                    acc = fmaf(wB[t][4 * b2q + 3], sk[b2q].w, acc);
+                }
+                v[t] = (valid && 4 * q + t < CO) ? fmaxf(acc, 0.f) : 0.f;
+            }
+            if (on) st4[((3 * bt + u) * G + g) * QH + q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    if (ri.it0 < ri.it_hi) fetch(ri.it0);
+    for (int turn = ri.it0; turn < ri.it_hi; turn += ri.stride) {
+        const long r0 = (long)turn * ROWS;
+        // ---- FP1, rows r0 .. r0 + 62 -> the tile
+        hand_over();
+        float4 ta_a[U][3], ta_b[U][3];
+        gathers(turn, 0, ta_a);
+        gathers(turn, 1, ta_b);
+        rows_of(turn, 0, ta_a);
+        gathers(turn, 2, ta_a);
+        rows_of(turn, 1, ta_b);
+        rows_of(turn, 2, ta_a);
+        if (lane < QH) st4[ROWS * QH + lane] = make_float4(0.f, 0.f, 0.f, 0.f);      // row 63: padding
+        WAVE_LDS_SYNC();
+        fetch(turn + ri.stride);                              // the NEXT turn's inputs travel while the head runs (clamped past the end)
+        // ---- the head on the tile: head_fwd_mfma_kernel's turn
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = f32x4{bias1, bias1, bias1, bias1};
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                const float v = st[(16 * t + n) * 36 + 4 * ks + kq];
+                const float a = (4 * ks + kq < 34) ? fmaf(ak[ks], v, ck[ks]) : 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w1[ks], acc[t], 0, 0, 0);
+            }
+        }
+        WAVE_LDS_SYNC();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zt[(16 * t + 4 * kq + j) * 20 + n] = fmaxf(acc[t][j], 0.f);
+        WAVE_LDS_SYNC();
+        f32x4 s2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s2[t] = f32x4{bias2, bias2, bias2, bias2};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[(16 * t + n) * 20 + 4 * ks + kq], w2[ks], s2[t], 0, 0, 0);
+        }
+        if (n < 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[(16 * t + 4 * kq + j) * 8 + n] = s2[t][j];
+        }
+        WAVE_LDS_SYNC();
+        const long r = r0 + lane;
+        const float4 s03 = *reinterpret_cast<const float4*>(&sc[lane * 8]);
+        const float s4 = sc[lane * 8 + 4];
+        WAVE_LDS_SYNC();
+        const float sv[4] = {s03.x, s03.y, s03.z, s03.w};
+        const float m = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        float e[4], den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            e[i] = expf(sv[i] - m);
+            den += e[i];
+        }
+        float pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pr[i] = e[i] / den;
+        const float dens = 1.0f / (1.0f + expf(-s4));
+        if (lane < ROWS && r < R) {
+            reinterpret_cast<float4*>(proba)[r] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+            reinterpret_cast<float4*>(cov)[r] = make_float4(pr[0] * dens, pr[1] * dens, pr[2] * dens, pr[3] * dens);
+        }
+    }
+}
+
 // The head backward on the matrix cores (round 4; rows of exactly 36 floats).  Its predecessor gave every lane one row: ~1900
 // FMA instructions per row, a third of them on the two weight-gradient outer products through an LDS transposition, behind
 // 144-byte strided row loads and stores (64 lines per instruction): 57 us for 168 MB.  Here a wave takes 64 consecutive rows
@@ -3708,6 +3915,15 @@ extern "C" int sn2_fp_head_eval(const sn2_fp* p, const sn2_head* hd, void* strea
                        p->src_a, p->src_c, p->blk.W, p->src_ws);
     const long turns = ((long)R + 62) / 63;
     int grid = sn2_cdiv(turns, 4);
+    if (g_fp_rows_form != 0 && grid >= 2 * sn2_cu_count()) {
+        // (round 5) the pipelined form: as many workgroups as are resident together (two per CU by its registers), each wave
+        // several turns with the next turn's inputs in flight
+        grid = 2 * sn2_cu_count();
+        hipLaunchKernelGGL((fp_head_eval2_kernel<34, 8, 34>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,
+                           p->skip_stride, (const float*)p->src_ws, p->knn_idx, p->knn_w, p->skip, p->blk.W, p->blk.b, hd->fa, hd->fc,
+                           hd->W1, hd->b1, hd->W2, hd->b2, hd->coverages, hd->proba);
+        SN2_RETURN_LAUNCH();
+    }
     const int cap = 4 * sn2_cu_count();
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL((fp_head_eval_kernel<34, 8, 34>), dim3(grid), dim3(256), 0, st, R, p->R_per_plot, p->S_per_plot,

@@ -510,7 +510,7 @@ def test_source_side_form_with_many_tiny_plots():
     assert worst <= 2e-3
 
 
-@pytest.mark.parametrize("B,N", [(3, 24001), (2, 4096), (5, 10000)])
+@pytest.mark.parametrize("B,N", [(3, 24001), (2, 4096), (5, 10000), (14, 10000)])
 def test_eval_fused_per_point_layer_and_head(B, N):
     """Eval mode runs FP1 and the head as ONE kernel (sn2_fp_head_eval: the rows of h1 stay in LDS).  Against the two separate
     kernels: the same bits where those take the same (source-side) form of FP1 -- more than 65 536 rows --, and equal to
@@ -533,6 +533,18 @@ def test_eval_fused_per_point_layer_and_head(B, N):
         torch.cuda.synchronize()
         out[fused] = (cov.clone(), proba.clone())
     m.fuse_eval_head = True
+    if B * N >= 63 * 4 * 512:
+        # enough turns for the pipelined form of the fused kernel (fp_head_eval2_kernel, round 5: a turn's inputs fetched one
+        # element per lane a turn ahead, table rows asked for a batch ahead): the first form on the same inputs, the same bits
+        from stratanet2_vegetation_coverage_maps_amd import _lib
+        try:
+            _lib.load().sn2_debug_fp_rows_form(0)
+            with torch.no_grad():
+                cov0, proba0 = m(d)
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().sn2_debug_fp_rows_form(1)
+        assert torch.equal(cov0, out[True][0]) and torch.equal(proba0, out[True][1])
     if B * N > 65536:
         assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
     else:
