@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "stratanet2_vegetation_coverage_maps_amd/csrc")
 so = os.path.join(ROOT, "gpurun_out/libsplit_dbg.so")
-srcs = [os.path.join(csrc, f) for f in ("geometry.hip", "sa.hip", "sa_mfma.hip", "fp.hip", "project.hip", "loss.hip", "misc.hip")]
+srcs = [os.path.join(csrc, f) for f in ("geometry.hip", "sa.hip", "sa_mfma.hip", "fp.hip", "project.hip", "loss.hip", "misc.hip", "net.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-DSN2_SPLIT_STAMPS"] + srcs + ["-o", so])
 from stratanet2_vegetation_coverage_maps_amd import _lib
 _lib.LIB_PATH = so
