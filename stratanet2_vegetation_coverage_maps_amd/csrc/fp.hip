@@ -3890,7 +3890,12 @@ extern "C" int sn2_head_forward(const sn2_head* p, void* stream) {
     if (p->zero_fill && ((p->zero_fill_words & 3) || p->zero_fill_words <= 0 || ((uintptr_t)p->zero_fill & 15))) return SN2_EINVAL;
     // check_head: rows of exactly 36 floats (34 channels)
     auto kf = p->act_bf16 ? &head_fwd_mfma_kernel<true> : &head_fwd_mfma_kernel<false>;
-    hipLaunchKernelGGL(kf, dim3(pick_grid(p->R * grid_mult, 256, 2)), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
+    // no more workgroups than are resident together (SN2_HF_OCC per CU; each wave loops over its turns): with 1024 workgroups at
+    // three per CU a quarter of them ran as a second round at a third of the occupancy (round 5; SN2_HF_WGS_PER_CU: experiment switch)
+    static const int hf_wgs = getenv("SN2_HF_WGS_PER_CU") ? atoi(getenv("SN2_HF_WGS_PER_CU")) : SN2_HF_OCC;
+    int hf_grid = pick_grid(p->R * grid_mult, 256, 2);
+    if (hf_wgs > 0 && hf_grid > hf_wgs * sn2_cu_count()) hf_grid = hf_wgs * sn2_cu_count();
+    hipLaunchKernelGGL(kf, dim3(hf_grid), dim3(256), 0, (hipStream_t)stream, p->R, p->f, p->fa,
                        p->fc, p->W1, p->b1, p->W2, p->b2, p->coverages, p->proba, p->drop_mask,
                        p->drop_mask ? p->drop_scale : 1.f, reinterpret_cast<float4*>(p->zero_fill),
                        p->zero_fill ? p->zero_fill_words / 4 : 0L);
