@@ -53,6 +53,9 @@ int sn2_debug_fp1_backward_parts(int mask);
  * fetched one element per lane, four iterations ahead (fp_fwd_rows2_kernel, round 5), 0 the first form (every lane of a row loads
  * the row's inputs itself); the two must give the same bits */
 int sn2_debug_fp_rows_form(int form);
+/* test hook: which kernel builds the source table of the source-side forms -- 1 (default) on the matrix cores (64 rows per wave
+ * through an LDS tile, round 5), 0 one row per lane with scalar weights; the fp32 MFMA accumulates k ascending like the fmaf chain */
+int sn2_debug_fp_table_form(int form);
 #define SN2_PROBE_SINK_WORDS 4096
 int sn2_debug_stream_probe(const float *src, float *dst, size_t n_floats, int mode, float *sink, void *stream);
 int sn2_debug_mfma_probe(int mode, int iters, float *sink, double *flops, void *stream);

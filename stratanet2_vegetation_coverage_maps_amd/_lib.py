@@ -109,6 +109,7 @@ SIGNATURES = {
     "sn2_debug_spin": [c_int, c_longlong, c_void_p, c_void_p],
     "sn2_debug_fp1_backward_parts": [c_int],
     "sn2_debug_fp_rows_form": [c_int],
+    "sn2_debug_fp_table_form": [c_int],
     "sn2_debug_stream_probe": [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p],
     "sn2_debug_mfma_probe": [c_int, c_int, c_void_p, POINTER(c_double), c_void_p],
     "sn2_pack_rows": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -696,6 +696,9 @@ __device__ __forceinline__ void row_quad_st(float* __restrict__ base, size_t row
 // the value a bfloat16 store keeps (for sums that must describe the STORED rows)
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 
+// which kernel builds the source table: 1 (default) fp_src_table_mfma_kernel, 0 fp_src_table_kernel (test hook:
+// sn2_debug_fp_table_form)
+static int g_fp_table_form = (getenv("SN2_FP_TABLE_MFMA") && atoi(getenv("SN2_FP_TABLE_MFMA")) == 0) ? 0 : 1;
 template <int CA, int CB, int CO>
 __global__ __launch_bounds__(256) void fp_src_table_kernel(int n_src, int src_stride, const float* __restrict__ src,
                                                            const float* __restrict__ src_a, const float* __restrict__ src_c,
@@ -731,6 +734,111 @@ __global__ __launch_bounds__(256) void fp_src_table_kernel(int n_src, int src_st
         }
         if (s < n_src) out[j] = acc;
     }
+}
+
+// a wave re-reads LDS words other lanes of the SAME wave wrote: the LDS executes a wave's instructions in order, the compiler
+// must not move the accesses across this point
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// The same table on the matrix cores (round 5): a wave takes 64 consecutive source rows -- fetched with coalesced float4 loads into
+// an LDS tile, the BatchNorm affine of the layer in front applied on the way out of it --, contracts them with W_A held in
+// registers (`v_mfma_f32_16x16x4_f32`, k ascending: the exact fp32 products and the accumulation order of the scalar kernel's
+// fmaf chain), and writes the 64 table rows back through the tile as coalesced float4.  fp_src_table_kernel gives every lane a
+// row and takes its weights through scalar loads, ~1200 FMA instructions per row-lane behind 144-byte strided loads: 243 us for
+// the parcel loop's 1.28 M sources (1.5 TB/s); this form streams.
+template <int CA, int CB, int CO>
+__global__ __launch_bounds__(256) void fp_src_table_mfma_kernel(int n_src, int src_stride, const float* __restrict__ src,
+                                                                const float* __restrict__ src_a, const float* __restrict__ src_c,
+                                                                const float* __restrict__ Wg, float* __restrict__ T) {
+    constexpr int CI = CA + CB, QH = (CO + 3) / 4, HS = 4 * QH, KS = (CA + 3) / 4, TJ = (HS + 15) / 16;
+    // tile row stride: the source row, padded so that the sixteen rows of an A-operand read sit in different banks
+    constexpr int LS = (4 * KS) % 32 == 0 ? 4 * KS + 4 : 4 * KS;
+    static_assert(HS <= LS, "the table rows go back through the tile");
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];            // [4 waves][64][LS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* st = s_tile + (size_t)wave * 64 * LS;
+    const int n = lane & 15, kq = lane >> 4;
+    float wb[TJ][KS], ak[KS], ck[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + kq;
+        ak[ks] = k < CA ? (src_a ? src_a[k] : 1.f) : 0.f;
+        ck[ks] = (k < CA && src_a) ? src_c[k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int o = 16 * j + n;
+            wb[j][ks] = (o < CO && k < CA) ? Wg[o * CI + k] : 0.f;
+        }
+    }
+    const long n_turns = ((long)n_src + 63) / 64;
+    for (long turn = (long)blockIdx.x * 4 + wave; turn < n_turns; turn += (long)gridDim.x * 4) {
+        const long s0 = turn * 64;
+        // ---- 64 rows x KS quads, coalesced; rows past the end: the last row (never written back)
+        const int rows_here = n_src - s0 < 64 ? (int)(n_src - s0) : 64;
+        const float* base = src + (size_t)s0 * src_stride;
+        const int QR = src_stride / 4;                                      // quads of a source row in memory
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int e = lane + 64 * i;                                     // quad e of the 64 x KS quads this wave wants
+            const int r = e / KS, qk = e - r * KS;
+            const int rc = r < rows_here ? r : rows_here - 1;
+            const float4 v = reinterpret_cast<const float4*>(base + (size_t)rc * src_stride)[qk < QR ? qk : QR - 1];
+            *reinterpret_cast<float4*>(&st[r * LS + 4 * qk]) = v;
+        }
+        WAVE_LDS_SYNC();
+        f32x4 acc[4][TJ];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float x = st[(16 * t + n) * LS + 4 * ks + kq];
+                const float a = (4 * ks + kq < CA) ? (src_a ? fmaf(ak[ks], x, ck[ks]) : x) : 0.f;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j][ks], a, acc[t][j], 0, 0, 0);
+            }
+        WAVE_LDS_SYNC();
+        // acc[t][j][r]: output channel 16 j + 4 kq + r of source row 16 t + n  (A = weights: rows of D are channels)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int o = 16 * j + 4 * kq;
+                if (o < HS) *reinterpret_cast<float4*>(&st[(16 * t + n) * LS + o]) = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+            }
+        WAVE_LDS_SYNC();
+        float* out = T + (size_t)s0 * HS;
+#pragma unroll
+        for (int i = 0; i < QH; ++i) {
+            const int e = lane + 64 * i;
+            const int r = e / QH, qo = e - r * QH;
+            if (r < rows_here) reinterpret_cast<float4*>(out + (size_t)r * HS)[qo] = *reinterpret_cast<const float4*>(&st[r * LS + 4 * qo]);
+        }
+        WAVE_LDS_SYNC();
+    }
+}
+template <int CA, int CB, int CO>
+int launch_src_table(int n_src, int src_stride, const float* src, const float* src_a, const float* src_c, const float* W, float* T,
+                     hipStream_t st) {
+    // where it pays: many sources of the 34-channel layer (the parcel loop's 1.28 M: 243 -> 122 us).  Not the 64-channel layer
+    // (68-word tile rows, two workgroups per CU: 85 -> 99 us) and not a training batch's 16 384 sources (64 workgroups, each one
+    // long chain: 6.9 -> 9.1 us).  Both kernels give the same bits (tests), so the choice is free.
+    if (g_fp_table_form != 0 && CA <= 36 && n_src >= 65536 && src_stride >= 4 * ((CA + 3) / 4)) {
+        constexpr int KS = (CA + 3) / 4, LS = (4 * KS) % 32 == 0 ? 4 * KS + 4 : 4 * KS;
+        const size_t lds = (size_t)4 * 64 * LS * sizeof(float);
+        auto k = &fp_src_table_mfma_kernel<CA, CB, CO>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        long grid = ((long)n_src + 255) / 256;
+        const long cap = 4L * sn2_cu_count();
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, n_src, src_stride, src, src_a, src_c, W, T);
+    } else {
+        hipLaunchKernelGGL((fp_src_table_kernel<CA, CB, CO>), dim3(sn2_cdiv(n_src, 64)), dim3(256), 0, st, n_src, src_stride, src, src_a,
+                           src_c, W, T);
+    }
+    SN2_RETURN_LAUNCH();
 }
 
 // The interpolated part of a pre-activation, in ONE spelled-out order of operations -- fma(fma(fma(c, w2, fma(b, w1, a w0)) ...:
@@ -2466,8 +2574,7 @@ int fp_forward_t(const sn2_fp* p, int mode, hipStream_t st) {
     if constexpr (KNN && CB > 0 && CB % 4 == 0 && CB <= 16) {
         if (fp_source_side_ok<CA, CO>(p)) {               // the per-point layer: source-side form
             const int n_src = p->B * p->S_per_plot;
-            hipLaunchKernelGGL((fp_src_table_kernel<CA, CB, CO>), dim3(sn2_cdiv(n_src, 64)), dim3(256), 0, st, n_src,
-                               p->src_stride, p->src, p->src_a, p->src_c, p->blk.W, p->src_ws);
+            SN2_TRY((launch_src_table<CA, CB, CO>(n_src, p->src_stride, p->src, p->src_a, p->src_c, p->blk.W, p->src_ws, st)));
             const long n_grp = sn2_cdiv(R, 64 / ((CO + 3) / 4));
             int grid = sn2_cdiv(n_grp, 8);
             // two workgroups per CU: at 143 VGPRs three waves fit a SIMD, so 1024 workgroups ran as one full round and a
@@ -2550,6 +2657,10 @@ int build_interp_index(const int* knn_idx, const float* knn_w, const float* src_
 
 // diagnostic (bench.py): which of the three kernels of the per-point layer's source-side backward run -- bit 0 the row pass, 1 the
 // source pass over the chunk table, 2 the merge (7 = all, the only setting that computes the gradients)
+extern "C" int sn2_debug_fp_table_form(int form) {
+    g_fp_table_form = form ? 1 : 0;
+    return 0;
+}
 extern "C" int sn2_debug_fp_rows_form(int form) {
     g_fp_rows_form = form ? 1 : 0;
     return 0;
@@ -2828,7 +2939,7 @@ __device__ __forceinline__ void head_row(const float* __restrict__ f, int f_stri
 
 // a wave re-reads LDS words other lanes of the SAME wave wrote: the LDS executes a wave's instructions in order, the compiler
 // must not move the accesses across this point (the regions are reused under different element types)
-#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// (WAVE_LDS_SYNC: defined with fp_src_table_mfma_kernel above)
 constexpr int HEAD_T_QUADS = 64 * 9;   // a wave's 64 consecutive rows of 36 floats: 9216 contiguous bytes, nine quads per lane
 
 // The head forward on the matrix cores (rows of exactly 36 floats).  Per wave and turn 64 consecutive rows:
@@ -3916,8 +4027,7 @@ extern "C" int sn2_fp_head_eval(const sn2_fp* p, const sn2_head* hd, void* strea
     // the layer's BatchNorm on its running statistics -> (a, c) = what the head applies to the rows (hd->fa, hd->fc name the
     // same two vectors: p->blk.a, p->blk.c)
     SN2_TRY(sn2_bn_finalize(&p->blk, 0, nullptr, R, 0, st));
-    hipLaunchKernelGGL((fp_src_table_kernel<34, 8, 34>), dim3(sn2_cdiv(n_src, 64)), dim3(256), 0, st, n_src, p->src_stride, p->src,
-                       p->src_a, p->src_c, p->blk.W, p->src_ws);
+    SN2_TRY((launch_src_table<34, 8, 34>(n_src, p->src_stride, p->src, p->src_a, p->src_c, p->blk.W, p->src_ws, st)));
     const long turns = ((long)R + 62) / 63;
     int grid = sn2_cdiv(turns, 4);
     if (g_fp_rows_form != 0 && grid >= 2 * sn2_cu_count()) {

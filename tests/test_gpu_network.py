@@ -426,7 +426,7 @@ def test_per_point_layer_source_side_form(N):
         assert err <= 1e-3, f"{k}: {err:.2e}"
 
 
-@pytest.mark.parametrize("B,N,M1", [(3, 24001, 1024), (16, 32768, 1024), (72, 1024, 8), (5, 14001, 3500)])
+@pytest.mark.parametrize("B,N,M1", [(3, 24001, 1024), (16, 32768, 1024), (72, 1024, 8), (5, 14001, 3500), (20, 10000, 3300)])
 def test_the_two_row_passes_of_the_source_side_forward_give_the_same_bits(B, N, M1):
     """fp_fwd_rows2_kernel (round 5: a wave fetches an iteration's indices, weights and skip quads one element per lane, four
     iterations ahead, and hands them to the (row, quad) lanes through LDS; the next iteration's table rows are asked for before
@@ -445,8 +445,11 @@ def test_the_two_row_passes_of_the_source_side_forward_give_the_same_bits(B, N, 
     rows0 = torch.randn(B * N, 12, device=dev)
     out = {}
     try:
-        for form in (1, 0):
+        # (form of the row pass, form of the source-table kernel: on the matrix cores -- round 5, where there are at least 65 536
+        # sources: the last case -- or one row per lane)
+        for form, table in ((1, 1), (0, 1), (1, 0)):
             _lib.load().sn2_debug_fp_rows_form(form)
+            _lib.load().sn2_debug_fp_table_form(table)
             lin, bn = torch.nn.Linear(42, 34).to(dev), torch.nn.BatchNorm1d(34).to(dev)
             with torch.no_grad():
                 g = torch.Generator(device="cpu").manual_seed(5)
@@ -456,13 +459,15 @@ def test_the_two_row_passes_of_the_source_side_forward_give_the_same_bits(B, N, 
             h1 = torch.full((B * N, 36), 7.0, device=dev)
             ops.fp_forward(ops.fp_desc(blk, B, N, M1, 34, 8, h2, h1, src_affine=(a2, c2), knn=knn, skip=rows0[:, 0:8]), 1)
             torch.cuda.synchronize()
-            out[form] = (h1.clone(), blk.aux.clone(), bn.running_mean.clone(), bn.running_var.clone())
+            out[(form, table)] = (h1.clone(), blk.aux.clone(), bn.running_mean.clone(), bn.running_var.clone())
     finally:
         _lib.load().sn2_debug_fp_rows_form(1)
+        _lib.load().sn2_debug_fp_table_form(1)
     assert B * N > 64 * _lib.STAT_SLOTS, "the case must take the source-side form"
-    assert float(out[1][0][:, :34].abs().max()) > 0 and not (out[1][0][:, :34] == 7.0).any()
-    for a, b, what in zip(out[1], out[0], ("rows", "a | c | mean | invstd", "running_mean", "running_var")):
-        assert torch.equal(a, b), what
+    assert float(out[(1, 1)][0][:, :34].abs().max()) > 0 and not (out[(1, 1)][0][:, :34] == 7.0).any()
+    for other in ((0, 1), (1, 0)):
+        for a, b, what in zip(out[(1, 1)], out[other], ("rows", "a | c | mean | invstd", "running_mean", "running_var")):
+            assert torch.equal(a, b), (other, what)
 
 
 def test_source_side_form_with_many_tiny_plots():
