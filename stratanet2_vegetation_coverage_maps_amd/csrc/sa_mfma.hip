@@ -96,10 +96,10 @@ __device__ __forceinline__ SaFirst sa_first(const int* __restrict__ order, const
     const int* trailer = order ? order + (size_t)4 * ncent + (size_t)16 * B * SN2_SA_PACKED_ITEMS(M) : nullptr;
     const int* base = order ? order : fallback;                // (unconditional loads: a valid address either way)
     const int* tr = trailer ? trailer : fallback;
-    const int t0 = tr[0], t1 = tr[1];
+    const int t0 = tr[0], t1 = tr[trailer ? 1 : 0];
     const int w4 = 4 * (wave < ncent ? wave : 0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) f.rec[t] = base[w4 + t];
+    for (int t = 0; t < 4; ++t) f.rec[t] = base[order ? w4 + t : 0];      // (without a table: word 0 of the fallback, never used)
     f.nA = order ? t0 : 0, f.nB = order ? t1 : 0;
     return f;
 }
