@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256, (PASS == 1 && CF == 8) ? 3 : 1) void sa_mfma_f
             // gathers: four memory round trips per step, one after the other, where one is needed (scripts/isa_scan.py; round 5).
             // (Gathering a step's ROWS one step ahead as well -- scripts/sa_stamps.py has the five-step items that decide the
             // kernels' duration at 3.5 us per step -- made all four SA1 kernels slower, 15.1 -> 18.3 us the statistics pass: most
-            // items are ONE step, and each then gathers a second set of rows nobody reads.)
+            // items are ONE step, and each then gathers a second set of rows nobody reads.  In the EVAL variant alone -- the parcel
+            // loop: three or four steps per item -- it was slower too: 2139 -> 2241 us per launch for SA1, 701 -> 796 for SA2.)
             float bkt[4][KB1];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
